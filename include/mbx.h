@@ -1,0 +1,113 @@
+/* libmbx -- C-ABI boundary of the MI355X-native Multibox hot path.
+ *
+ * The reference (gvanhorn38/multibox, TF-0.11 Python) has no FFI of its own; its one
+ * host-callback seam is tf.py_func(compute_assignments, ...) at loss.py:81-82 and the
+ * numpy post-processing loop at detect.py:408-443.  Every entry point below names the
+ * reference interface (file:line) it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; device pointers unless marked HOST;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no allocation, no
+ *     synchronisation, no global state: safe to capture into a hipGraph;
+ *   - return 0 (MBX_OK) or a negative mbx_status; never throw across the boundary;
+ *   - scratch memory comes from the caller; *_workspace_bytes() says how much.
+ */
+#ifndef MBX_H
+#define MBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mbx_stream_t; /* hipStream_t */
+
+typedef enum {
+  MBX_OK = 0,
+  MBX_ERR_INVALID_ARG = -1,
+  MBX_ERR_UNSUPPORTED = -2,
+  MBX_ERR_LAUNCH = -3,
+  MBX_ERR_WORKSPACE = -4
+} mbx_status;
+
+int mbx_version(void);
+const char* mbx_status_string(int status);
+
+/* ---------------------------------------------------------------- priors (HOST)
+ * Replaces priors.generate_priors (priors.py:185-314).  float64, bit-exact.
+ * `grids` generalises the hard-coded [8,6,4,3,2,1] (priors.py:196); a grid of 1 gets
+ * the single aspect-1 box (priors.py:206-258).  out = [rows,4] x1,y1,x2,y2.          */
+int mbx_priors_count(int k, const int* grids, int n_grids);
+int mbx_generate_priors(const double* aspect_ratios, int k, double min_scale, double max_scale,
+                        int restrict_to_image_bounds, const int* grids, int n_grids,
+                        double* out /*HOST [rows,4]*/);
+
+/* ------------------------------------------------------- decode + confidences (K12)
+ * loss.py:67-74: decoded = raw_locs + tile(priors); conf = sigmoid(logits) + eps_add.
+ * (model.py:322 applies the sigmoid; eps_add = 1e-10 for the loss, 0 for detect.)
+ * Any output pointer may be NULL.                                                     */
+int mbx_decode_conf(const float* raw_locs /*[B,P,4]*/, const float* logits /*[B,P]*/,
+                    const float* priors /*[P,4]*/, int B, int P, float eps_add,
+                    float* decoded /*[B,P,4]*/, float* conf /*[B,P]*/, mbx_stream_t stream);
+
+/* ------------------------------------------------------------------ matching (A6)
+ * Replaces the tf.py_func(compute_assignments) callback (loss.py:8-53, 81-82).
+ * Inputs exactly as the callback receives them: prior-decoded locations, confidences
+ * with 1e-10 already added, zero-padded gt, counts.  Per image: cost
+ * C[p,j] = (alpha/2)*||l_p - g_j||^2 - log c_p + log(1-c_p) built in float32 in the
+ * reference's operation order (loss.py:21-35), solved as a rectangular linear sum
+ * assignment in float64 (shortest augmenting path; scipy's linear_sum_assignment,
+ * loss.py:40).  match[b,p] = gt index or -1; the reference's 0/1 partition and
+ * row-ordered stacked_gt (loss.py:44-48) follow from it.
+ * status[b]: 0 ok, 1 n_gt > P (infeasible), 2 non-finite cost (scipy raises there).    */
+size_t mbx_match_workspace_bytes(int B, int P, int G);
+int mbx_match(const float* decoded /*[B,P,4]*/, const float* conf /*[B,P]*/,
+              const float* gt /*[B,G,4]*/, const int32_t* n_gt /*[B]*/, float alpha,
+              int B, int P, int G, int32_t* match /*[B,P]*/, int32_t* status /*[B]*/,
+              void* workspace, size_t workspace_bytes, mbx_stream_t stream);
+
+/* ---------------------------------------------------------------- loss fwd+bwd (A7)
+ * loss.py:88-101 given the matching: loc_loss = alpha * 1/2 sum (decoded-gt)^2 over
+ * matched rows; conf_loss = -sum log(c_matched) - sum log(1 - c_unmatched + 1e-10),
+ * c = sigmoid(logit) + 1e-10.  Also the gradients w.r.t. raw_locs and the logits (no
+ * gradient through the matching: py_func, loss.py:82).  loss2 = {loc_loss, conf_loss}.
+ * grad_scale multiplies both gradients (1 for the reference's batch-sum loss).
+ * conf_is_logit = 1: `conf_in` holds logits (gradient goes through the sigmoid of
+ * model.py:322); 0: `conf_in` holds sigmoid outputs as loss.add_loss receives them
+ * (d_logits then is the gradient w.r.t. those confidences).                           */
+size_t mbx_loss_workspace_bytes(int B);
+int mbx_loss_fwd_bwd(const float* decoded /*[B,P,4]*/, const float* conf_in /*[B,P]*/,
+                     int conf_is_logit, const float* gt /*[B,G,4]*/,
+                     const int32_t* match /*[B,P]*/, float alpha, float grad_scale, int B, int P,
+                     int G, float* loss2 /*[2]*/,
+                     float* d_raw_locs /*[B,P,4] or NULL*/, float* d_logits /*[B,P] or NULL*/,
+                     void* workspace, size_t workspace_bytes, mbx_stream_t stream);
+
+/* ------------------------------------------------- detect post-processing (A9-A12)
+ * Replaces the per-patch numpy loop detect.py:408-436: decode + clip [0,1]
+ * (412-413), filter_proposals (74-104, strict inequalities), sort by confidence
+ * descending and keep max_to_keep (423-427), convert_proposals to image coordinates in
+ * float64 incl. the flip (106-131).  Ties in confidence: higher prediction index first
+ * (the reference's order among ties is undefined).                                   */
+typedef struct {
+  int32_t offset_y, offset_x; /* batched_offsets  (detect.py:190-281) */
+  int32_t patch_h, patch_w;   /* batched_dims */
+  int32_t image_h, image_w;   /* batched_heights_widths */
+  int32_t is_flipped;
+  int32_t max_to_keep;
+  float restrictions[4];      /* x1,y1,x2,y2 (detect.py:50-54) */
+} mbx_patch_meta;
+
+int mbx_decode_filter_topk(const float* raw_locs /*[B,P,4]*/, const float* conf /*[B,P]*/,
+                           const float* priors /*[P,4]*/, const mbx_patch_meta* meta /*[B]*/,
+                           int B, int P, int k_max, double* out_boxes /*[B,k_max,4]*/,
+                           float* out_scores /*[B,k_max]*/, int32_t* out_index /*[B,k_max]*/,
+                           int32_t* out_count /*[B]*/, mbx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBX_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of libmbx.so (the C-ABI in include/mbx.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  Device
+pointers are passed as integers (``tensor.data_ptr()``); the stream is
+``torch.cuda.current_stream().cuda_stream``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmbx.so")
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+D = C.c_double
+SZ = C.c_size_t
+
+
+class PatchMeta(C.Structure):
+    """mbx_patch_meta (include/mbx.h); the per-patch columns of detect.py:190-281."""
+    _fields_ = [("offset_y", C.c_int32), ("offset_x", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32),
+                ("image_h", C.c_int32), ("image_w", C.c_int32), ("is_flipped", C.c_int32),
+                ("max_to_keep", C.c_int32), ("restrictions", C.c_float * 4)]
+
+
+_SIGS = {
+    "mbx_version": (I, []),
+    "mbx_status_string": (C.c_char_p, [I]),
+    "mbx_priors_count": (I, [I, P, I]),
+    "mbx_generate_priors": (I, [P, I, D, D, I, P, I, P]),
+    "mbx_decode_conf": (I, [P, P, P, I, I, F, P, P, P]),
+    "mbx_match_workspace_bytes": (SZ, [I, I, I]),
+    "mbx_match": (I, [P, P, P, P, F, I, I, I, P, P, P, SZ, P]),
+    "mbx_loss_workspace_bytes": (SZ, [I]),
+    "mbx_loss_fwd_bwd": (I, [P, P, I, P, P, F, F, I, I, I, P, P, P, P, SZ, P]),
+    "mbx_decode_filter_topk": (I, [P, P, P, P, I, I, I, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+class MbxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmbx.so once.  Raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MbxError("libmbx.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(needs hipcc); there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)      # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().mbx_status_string(int(status))
+        raise MbxError("%s failed: %s (%d)" % (what or "libmbx call", msg.decode() if msg else "?", status))
+
+
+def declared_symbols():
+    return sorted(_SIGS)

@@ -1,0 +1,26 @@
+// Shared helpers for libmbx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mbx.h"
+
+#define MBX_LAUNCH_CHECK()                                    \
+  do {                                                        \
+    if (hipGetLastError() != hipSuccess) return MBX_ERR_LAUNCH; \
+  } while (0)
+
+static inline hipStream_t mbx_s(mbx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ int mbx_lane() { return threadIdx.x & 63; }
+
+// 64-lane butterfly reductions (wave = 64 on gfx950).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

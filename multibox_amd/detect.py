@@ -1,0 +1,88 @@
+"""Detection post-processing -- host mirror of the reference's detect.py loop on libmbx.
+
+``postprocess`` replaces the per-patch numpy loop detect.py:408-443 with one launch of
+``mbx_decode_filter_topk``; ``extract_patches`` keeps the reference's offsets and
+restrictions (detect.py:20-72).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def extract_patches(image, patch_dims, strides, non_edge_restriction=0.1):
+    """detect.py:20-72: same return list [patches, offsets(y,x), restrictions, count]."""
+    H, W = image.shape[:2]
+    ph, pw = patch_dims
+    sh, sw = strides
+    hs = list(range(0, H - ph + 1, sh))
+    ws = list(range(0, W - pw + 1, sw))
+    n = len(hs) * len(ws)
+    patches = np.zeros((n, ph, pw, 3), np.float32)
+    offs = np.zeros((n, 2), np.int32)
+    res = np.zeros((n, 4), np.float32)
+    i = 0
+    for h in hs:
+        for w in ws:
+            patches[i] = image[h:h + ph, w:w + pw]
+            offs[i] = (h, w)
+            res[i] = (0.0 if w == 0 else non_edge_restriction, 0.0 if h == 0 else non_edge_restriction,
+                      1.0 if w + pw == W else 1.0 - non_edge_restriction,
+                      1.0 if h + ph == H else 1.0 - non_edge_restriction)
+            i += 1
+    return [patches, offs, res, np.int32(n)]
+
+
+def make_patch_meta(offsets, dims, is_flipped, restrictions, max_to_keep, image_hw, device="cuda"):
+    """Pack the per-patch columns fetched at detect.py:398-406 into mbx_patch_meta[B] on the device."""
+    B = len(offsets)
+    arr = (_lib.PatchMeta * B)()
+    for b in range(B):
+        m = arr[b]
+        m.offset_y, m.offset_x = int(offsets[b][0]), int(offsets[b][1])
+        m.patch_h, m.patch_w = int(dims[b][0]), int(dims[b][1])
+        m.image_h, m.image_w = int(image_hw[b][0]), int(image_hw[b][1])
+        m.is_flipped = int(np.ravel(is_flipped[b])[0])
+        m.max_to_keep = int(np.ravel(max_to_keep[b])[0])
+        for i in range(4):
+            m.restrictions[i] = float(restrictions[b][i])
+    raw = np.frombuffer(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device)
+
+
+class DetectPostprocess:
+    """Preallocated outputs for B patches x k_max detections (k_max >= every max_to_keep)."""
+
+    def __init__(self, bbox_priors, batch_size, k_max=200, device="cuda"):
+        self.priors = torch.as_tensor(bbox_priors, dtype=torch.float32).to(device).contiguous()
+        self.P, self.B, self.K = self.priors.shape[0], int(batch_size), int(k_max)
+        self.boxes = torch.empty((self.B, self.K, 4), dtype=torch.float64, device=device)
+        self.scores = torch.empty((self.B, self.K), dtype=torch.float32, device=device)
+        self.index = torch.empty((self.B, self.K), dtype=torch.int32, device=device)
+        self.count = torch.empty((self.B,), dtype=torch.int32, device=device)
+
+    def __call__(self, raw_locs, confs, meta):
+        """raw_locs [B,P,4] f32, confs [B,P] f32 (sigmoid outputs), meta uint8 tensor from make_patch_meta."""
+        B, P = self.B, self.P
+        assert raw_locs.shape == (B, P, 4) and confs.numel() == B * P and meta.numel() == B * ctypes.sizeof(_lib.PatchMeta)
+        assert raw_locs.is_contiguous() and confs.is_contiguous() and raw_locs.dtype == confs.dtype == torch.float32
+        _lib.check(_lib.lib().mbx_decode_filter_topk(raw_locs.data_ptr(), confs.data_ptr(), self.priors.data_ptr(),
+                                                     meta.data_ptr(), B, P, self.K, self.boxes.data_ptr(),
+                                                     self.scores.data_ptr(), self.index.data_ptr(),
+                                                     self.count.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "mbx_decode_filter_topk")
+        return self.boxes, self.scores, self.index, self.count
+
+
+def results_to_json_records(boxes, scores, count, image_ids):
+    """detect.py:438-443: list of {"image_id", "bbox", "score"} in patch order."""
+    boxes, scores, count = boxes.cpu().numpy(), scores.cpu().numpy(), count.cpu().numpy()
+    out = []
+    for b in range(boxes.shape[0]):
+        for k in range(int(count[b])):
+            out.append({"image_id": int(image_ids[b]), "bbox": boxes[b, k].tolist(), "score": float(scores[b, k])})
+    return out

@@ -1,0 +1,68 @@
+"""Prior (default box) generation -- host mirror of the reference's priors.py.
+
+``generate_priors`` has the reference's signature and return type
+(priors.py:185: a Python list of ``[x1, y1, x2, y2]``) and is computed by the C-ABI
+``mbx_generate_priors`` (float64, bit-exact).  ``priors.pkl`` keeps the reference's
+format (README.md:10-18: a pickle of that list).
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_GRIDS = (8, 6, 4, 3, 2, 1)   # priors.py:196
+
+
+def head_grids(input_size=299):
+    """Grid sizes of the detection heads for a given INPUT_SIZE (model.py:198-293).
+
+    The backbone emits f x f features (8 at 299, 14 at 512); the heads emit
+    f, f-2, ceil(f/2), ceil(f/2)-1, ceil(f/2)-2 cells and one (f-7)^2 'global' head.
+    At 299 this is the reference's hard-coded [8,6,4,3,2,1]; other sizes are the
+    build's generalisation, returned as (grids, cells_of_last_head).
+    """
+    s = input_size
+    s = (s - 3) // 2 + 1          # Conv2d_1a 3x3 s2 VALID
+    s = s - 2                     # Conv2d_2a 3x3 VALID
+    s = (s - 3) // 2 + 1          # MaxPool_3a
+    s = s - 2                     # Conv2d_4a 3x3 VALID
+    s = (s - 3) // 2 + 1          # MaxPool_5a
+    s = (s - 3) // 2 + 1          # Mixed_6a
+    f = (s - 3) // 2 + 1          # Mixed_7a
+    h = (f + 1) // 2
+    return [f, f - 2, h, h - 1, h - 2], (f - 7) ** 2
+
+
+def generate_priors(aspect_ratios, min_scale=0.1, max_scale=0.95, restrict_to_image_bounds=True, grids=None):
+    """priors.py:185-314 through libmbx.  Returns list of [x1,y1,x2,y2] Python floats."""
+    return generate_priors_array(aspect_ratios, min_scale, max_scale, restrict_to_image_bounds, grids).tolist()
+
+
+def generate_priors_array(aspect_ratios, min_scale=0.1, max_scale=0.95, restrict_to_image_bounds=True, grids=None):
+    l = _lib.lib()
+    ars = np.ascontiguousarray(aspect_ratios, dtype=np.float64)
+    g = np.ascontiguousarray(DEFAULT_GRIDS if grids is None else grids, dtype=np.int32)
+    n = l.mbx_priors_count(len(ars), g.ctypes.data, len(g))
+    if n < 0:
+        _lib.check(n, "mbx_priors_count")
+    out = np.zeros((n, 4), np.float64)
+    _lib.check(l.mbx_generate_priors(ars.ctypes.data, len(ars), float(min_scale), float(max_scale),
+                                     int(bool(restrict_to_image_bounds)), g.ctypes.data, len(g), out.ctypes.data),
+               "mbx_generate_priors")
+    return out
+
+
+def save_priors(path, priors):
+    """README.md:16-17 format: pickle of list-of-lists (plain floats; protocol 2 so py2 can read it)."""
+    with open(path, "wb") as f:
+        pickle.dump([[float(v) for v in row] for row in priors], f, protocol=2)
+
+
+def load_priors(path):
+    """train.py:368-370 / detect.py:511-513: accepts py2 text-mode pickles with numpy scalars."""
+    with open(path, "rb") as f:
+        p = pickle.load(f, encoding="latin1")
+    return np.array(p).astype(np.float32)

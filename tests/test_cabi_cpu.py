@@ -1,0 +1,67 @@
+"""CPU-side checks of the C-ABI: the library loads, exports every symbol include/mbx.h
+declares, and the HOST entry point (priors) is bit-exact.  No device compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import _lib
+    return _lib.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    from multibox_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mbx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mbx_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libmbx.so does not export %s" % name
+    assert sorted(_lib.declared_symbols()) == declared, "ctypes table and header disagree"
+
+
+def test_status_strings(lib):
+    assert lib.mbx_status_string(0) == b"ok"
+    assert lib.mbx_status_string(-4) != lib.mbx_status_string(-1)
+    assert lib.mbx_version() >= 100
+
+
+def test_priors_cabi_bit_exact(lib, golden):
+    from multibox_amd import priors as P
+    g = golden.priors
+    for name, kw in [("k5_restrict", {}), ("k5_clip", dict(restrict_to_image_bounds=False)),
+                     ("k7_restrict", {}), ("k8_restrict", {}), ("k5_scales", dict(min_scale=0.2, max_scale=0.8))]:
+        out = P.generate_priors_array(g[name + "_ars"], **kw)
+        assert out.tobytes() == g[name].tobytes(), name
+    lst = P.generate_priors([1, 2, 3, 1 / 2., 1 / 3.])
+    assert isinstance(lst, list) and len(lst) == 646 and isinstance(lst[0][0], float)
+
+
+def test_priors_pickle_roundtrip(lib, tmp_path):
+    from multibox_amd import priors as P
+    p = P.generate_priors([1, 2, 3, 1 / 2., 1 / 3.])
+    f = str(tmp_path / "priors.pkl")
+    P.save_priors(f, p)
+    q = P.load_priors(f)
+    assert q.dtype == np.float32 and q.shape == (646, 4)
+    assert np.array_equal(q, np.array(p).astype(np.float32))
+
+
+def test_priors_bad_args(lib):
+    from multibox_amd import priors as P, _lib
+    with pytest.raises(_lib.MbxError):
+        P.generate_priors_array([1.0], grids=[0])
+
+
+def test_head_grids():
+    from multibox_amd.priors import head_grids
+    assert head_grids(299) == ([8, 6, 4, 3, 2], 1)
+    assert head_grids(512) == ([14, 12, 7, 6, 5], 49)

@@ -1,0 +1,186 @@
+"""GPU parity: libmbx matching / loss / decode kernels vs the oracle and the golden fixtures.
+
+Bar: match indices, partitions, stacked gt, detection scores/boxes bit-exact; loss
+values rtol 1e-5 (the reference's TF reduction order is un-vendored); gradients rtol 1e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MATCH_CASES = ["b2_p646_g5", "b4_p646_g13", "b3_p904_g100", "b2_p646_g13_wide", "b8_p646_g13_rand", "sat_alpha1"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _priors_for(golden, P):
+    return golden.priors["k5_restrict" if P == 646 else "k7_restrict"].astype(np.float32)
+
+
+@pytest.mark.parametrize("case", MATCH_CASES)
+def test_match_golden_exact(torch_cuda, golden, case):
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    g = golden.matching
+    raw, confs, gt, n = g[case + "_raw"], g[case + "_confs"], g[case + "_gt"], g[case + "_n"]
+    B, P = raw.shape[:2]
+    priors = _priors_for(golden, P)
+    alpha = 1.0 if case == "sat_alpha1" else 1000.0
+    dec = (raw + priors[None]).astype(np.float32)
+    c = (confs + np.float32(1e-10)).astype(np.float32)
+    part, stacked = L.compute_assignments(torch.from_numpy(dec).cuda().reshape(-1, 4), torch.from_numpy(c).cuda().reshape(-1),
+                                          torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda(), B, alpha)
+    assert part.dtype == torch.int32
+    assert np.array_equal(part.cpu().numpy(), g[case + "_part"])
+    assert stacked.cpu().numpy().tobytes() == g[case + "_stacked"].tobytes()
+
+
+@pytest.mark.parametrize("B,P,G,seed", [(64, 646, 13, 0), (16, 904, 100, 1), (4, 3199, 100, 2), (3, 70, 5, 3), (2, 13, 13, 4)])
+def test_match_vs_oracle_random(torch_cuda, B, P, G, seed):
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(seed)
+    dec = rng.uniform(0, 1, (B, P, 4)).astype(np.float32)
+    c = (R.sigmoid_f32(rng.randn(B, P) * 2 - 1) + np.float32(1e-10)).astype(np.float32)
+    n = rng.randint(0, min(G, P) + 1, B).astype(np.int32)
+    n[0] = min(G, P)
+    if B > 1:
+        n[1] = 0
+    gt = np.zeros((B, G, 4), np.float32)
+    for b in range(B):
+        gt[b, :n[b]] = rng.uniform(0, 1, (n[b], 4))
+    _, _, m_ref = R.compute_assignments(dec.reshape(-1, 4), c.reshape(-1), gt, n, B, 1000.0)
+    m, st = L.match_boxes(torch.from_numpy(dec).cuda(), torch.from_numpy(c).cuda(), torch.from_numpy(gt).cuda(),
+                          torch.from_numpy(n).cuda(), 1000.0)
+    assert st.cpu().numpy().max() == 0
+    m = m.cpu().numpy()
+    assert np.array_equal(m, m_ref)
+    # size-independent properties: every gt matched once, distinct predictions
+    for b in range(B):
+        assert sorted(m[b][m[b] >= 0].tolist()) == list(range(n[b]))
+
+
+def test_match_error_status(torch_cuda):
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    B, P, G = 3, 8, 12
+    dec = torch.rand(B, P, 4, device="cuda")
+    c = torch.rand(B, P, device="cuda") * 0.9 + 0.05
+    gt = torch.rand(B, G, 4, device="cuda")
+    n = torch.tensor([12, 2, 2], dtype=torch.int32, device="cuda")     # image 0: n > P
+    dec[2, 3, 1] = float("nan")                                        # image 2: non-finite
+    m, st = L.match_boxes(dec, c, gt, n, 1000.0)
+    assert st.cpu().tolist() == [1, 0, 2]
+    with pytest.raises(ValueError):
+        L.compute_assignments(dec.reshape(-1, 4), c.reshape(-1), gt, n, B, 1000.0)
+
+
+@pytest.mark.parametrize("case", ["b4_p646_g13", "b3_p904_g100", "sat_alpha1"])
+def test_loss_fwd_bwd_vs_oracle(torch_cuda, golden, case):
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    from oracle import ref_numpy as R
+    g = golden.matching
+    raw, logits, gt, n = g[case + "_raw"], g[case + "_logits"], g[case + "_gt"], g[case + "_n"]
+    B, P = raw.shape[:2]
+    priors = _priors_for(golden, P)
+    alpha = 1.0 if case == "sat_alpha1" else 1000.0
+    ml = L.MultiboxLoss(priors, B, gt.shape[1], alpha)
+    loss2, dl, dz = ml.forward_backward(torch.from_numpy(raw).cuda(), torch.from_numpy(logits).cuda(),
+                                        torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    torch.cuda.synchronize()
+    ref = R.add_loss(raw, R.sigmoid_f32(logits), gt, n, priors, alpha)
+    assert np.array_equal(ml.match.cpu().numpy(), ref["match"])
+    l2 = loss2.cpu().numpy()
+    assert np.isclose(l2[0], ref["loc_loss"], rtol=1e-5) and np.isclose(l2[1], ref["conf_loss"], rtol=1e-5)
+    rdl, rdz = R.add_loss_grads(raw, logits, gt, priors, alpha, ref["match"])
+    assert np.allclose(dl.cpu().numpy(), rdl, rtol=1e-4, atol=1e-6)
+    assert np.allclose(dz.cpu().numpy(), rdz, rtol=1e-4, atol=1e-6)
+
+
+def test_add_loss_reference_api_known_answers(torch_cuda):
+    """model_tests.py:104-263 on the loss: signs, exact zero location loss with no gt."""
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(0)
+    P = 646
+    priors = rng.uniform(0, 1, (P, 4)).astype(np.float32)
+    raw = (rng.randn(2, P, 4) * 0.1).astype(np.float32)
+    confs = R.sigmoid_f32(rng.randn(2, P, 1))
+    gt = np.zeros((2, 5, 4), np.float32)
+    gt[0, 0] = [.1, .1, .9, .9]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for sl, n in [(slice(0, 1), [1]), (slice(0, 1), [0]), (slice(0, 2), [1, 0])]:
+        loc, conf = L.add_loss(T(raw[sl]), T(confs[sl]), T(gt[sl]), T(np.array(n, np.int32)), priors, 1.0)
+        ref = R.add_loss(raw[sl], confs[sl].reshape(len(n), P), gt[sl], n, priors, 1.0)
+        assert np.isclose(float(loc), ref["loc_loss"], rtol=1e-5) and np.isclose(float(conf), ref["conf_loss"], rtol=1e-5)
+        if sum(n) == 0:
+            assert float(loc) == 0.0
+        else:
+            assert float(loc) > 0
+        assert float(conf) > 0
+
+
+def _meta_from_golden(g):
+    from multibox_amd import detect as D
+    return D.make_patch_meta(g["meta_offset"], g["meta_dims"], g["meta_flipped"], g["meta_restrictions"],
+                             g["meta_max_to_keep"], g["meta_image_hw"])
+
+
+@pytest.mark.parametrize("k", ["k5", "k7"])
+def test_decode_filter_topk_golden(torch_cuda, golden, k):
+    torch = torch_cuda
+    from multibox_amd import detect as D
+    g = golden.detect
+    priors = golden.priors[k + "_restrict"].astype(np.float32)
+    raw, confs = g[k + "_raw"], g[k + "_confs"]
+    B, P = raw.shape[:2]
+    pp = D.DetectPostprocess(priors, B, k_max=200)
+    boxes, scores, index, count = pp(torch.from_numpy(raw).cuda(), torch.from_numpy(confs.reshape(B, P)).cuda(), _meta_from_golden(g))
+    boxes, scores, count = boxes.cpu().numpy(), scores.cpu().numpy(), count.cpu().numpy()
+    assert np.array_equal(count, g[k + "_counts"])
+    for b in range(B):
+        eb, es = g["%s_b%d_boxes" % (k, b)], g["%s_b%d_scores" % (k, b)]
+        assert scores[b, :count[b]].tobytes() == es.tobytes()
+        if len(np.unique(es)) == len(es):
+            assert boxes[b, :count[b]].tobytes() == eb.tobytes()
+        else:
+            assert sorted(map(tuple, boxes[b, :count[b]])) == sorted(map(tuple, eb))
+
+
+def test_decode_filter_topk_full_size_properties(torch_cuda, golden):
+    """BASELINE config 4: B=256 patches, k=7 -> P=904, whole-image restrictions, max_to_keep 200."""
+    torch = torch_cuda
+    from multibox_amd import detect as D
+    from oracle import ref_numpy as R
+    priors = golden.priors["k7_restrict"].astype(np.float32)
+    B, P = 256, priors.shape[0]
+    rng = np.random.RandomState(5)
+    raw = (rng.randn(B, P, 4) * 0.05).astype(np.float32)
+    confs = R.sigmoid_f32(rng.randn(B, P) * 2)
+    confs[0, :300] = 0.5                                     # a big tie group
+    offs = np.zeros((B, 2), np.int32)
+    dims = np.tile([[480, 640]], (B, 1))
+    flips = (np.arange(B) % 2).astype(np.int32)
+    res = np.tile([[0, 0, 1, 1]], (B, 1)).astype(np.float32)
+    mtk = np.full((B,), 200, np.int32)
+    mtk[3] = 0
+    meta = D.make_patch_meta(offs, dims, flips, res, mtk, dims)
+    pp = D.DetectPostprocess(priors, B, k_max=200)
+    boxes, scores, index, count = [t.cpu().numpy() for t in pp(torch.from_numpy(raw).cuda(), torch.from_numpy(confs).cuda(), meta)]
+    assert count[3] == 0 and (np.delete(count, 3) == 200).all()
+    for b in [0, 1, 2, 100, 255]:
+        rb, rs, ridx = R.detect_postprocess(raw[b], confs[b], priors, res[b], mtk[b], offs[b], dims[b], dims[b], flips[b])
+        assert np.array_equal(index[b, :count[b]], ridx)      # same tie rule as the oracle
+        assert scores[b, :count[b]].tobytes() == rs.tobytes()
+        assert boxes[b, :count[b]].tobytes() == rb.tobytes()
+        assert (np.diff(scores[b, :count[b]]) <= 0).all()     # sortedness
