@@ -107,6 +107,53 @@ int mbx_decode_filter_topk(const float* raw_locs /*[B,P,4]*/, const float* conf 
                            float* out_scores /*[B,k_max]*/, int32_t* out_index /*[B,k_max]*/,
                            int32_t* out_count /*[B]*/, mbx_stream_t stream);
 
+/* ------------------------------------------------------------ convolution stack (A2-A4)
+ * Replaces slim.conv2d (+ batch_norm + relu) of model.py:6-324 and its TF gradients
+ * (train.py:263).  Activations are NHWC bf16 *views*: element (n,h,w,c) of a tensor lives at
+ * base[n*img_stride + (h*W + w)*ld + c], so a branch can read/write a channel slice of a
+ * wider concat buffer (tf.concat(3, ...) of model.py:18,38,58,138,159,182 costs nothing).
+ * Filters are bf16 [C_out][R][S][C_in] (KRSC), contiguous.  Accumulation is fp32 on MFMA
+ * (v_mfma_f32_16x16x32_bf16).  C_in, ld and slice offsets must be multiples of 8.
+ *
+ * mbx_conv_desc.transposed = 1 computes the data gradient: the same kernel run on dy with
+ * the spatially flipped, channel-transposed filter ([C_in][R][S][C_out], see
+ * mbx_filter_prepare) and an input dilated by `stride`.                                 */
+typedef enum {
+  MBX_EPI_STORE = 0,    /* y = acc                     (bf16; pre-BN activations, gradients) */
+  MBX_EPI_AFFINE = 1,   /* y = act(acc*scale[c] + shift[c])       (frozen / folded batch norm) */
+  MBX_EPI_RESIDUAL = 2, /* y = act(skip + rscale*(acc + shift[c]))           (model.py:19-23) */
+  MBX_EPI_STORE_F32 = 3 /* y = acc as float32            (head outputs, model.py:213-293)     */
+} mbx_epilogue;
+
+typedef struct {
+  /* input view */
+  const void* x; int64_t x_img_stride; int32_t ldx;
+  int32_t N, H_in, W_in, C_in;
+  /* filter */
+  const void* w; int32_t C_out, R, S;
+  /* geometry */
+  int32_t stride, transposed, pad_t, pad_l, H_out, W_out;
+  /* output view */
+  void* y; int64_t y_img_stride; int32_t ldy;
+  /* epilogue */
+  int32_t epilogue, relu, accumulate;     /* accumulate: y += result (bf16 STORE only)        */
+  const float* scale; const float* shift; /* per output channel, may be NULL                 */
+  const void* skip; int64_t skip_img_stride; int32_t ld_skip; float rscale;
+  float* stats_partial; /* [mbx_conv_stats_rows()][C_out][2] partial sum / sum-of-squares of the stored
+                           y (bf16-rounded) for batch-norm statistics, or NULL              */
+} mbx_conv_desc;
+
+int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
+int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
+
+/* Weight gradient (TF autodiff of slim.conv2d, train.py:263):
+ * dw[k][r][s][c] += sum_{n,oh,ow} dy[n,oh,ow,k] * x[n, oh*stride-pad_t+r, ow*stride-pad_l+s, c]
+ * dw is float32 KRSC, ACCUMULATED with atomics (zero it first).  desc gives x / geometry as
+ * in the forward call; dy is an [N,H_out,W_out,C_out] bf16 view.  `db` (float32 [C_out],
+ * may be NULL) accumulates sum dy for a bias gradient.                                     */
+int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const void* dy,
+                   int64_t dy_img_stride, int32_t ld_dy, float* dw, float* db, mbx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,9 @@ _SIGS = {
     "mbx_loss_workspace_bytes": (SZ, [I]),
     "mbx_loss_fwd_bwd": (I, [P, P, I, P, P, F, F, I, I, I, P, P, P, P, SZ, P]),
     "mbx_decode_filter_topk": (I, [P, P, P, P, I, I, I, P, P, P, P, P]),
+    "mbx_conv_stats_rows": (I, [P]),
+    "mbx_conv": (I, [P, P]),
+    "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
 }
 
 _lib = None
@@ -53,6 +56,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MbxError("libmbx.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(needs hipcc); there is no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; load it FIRST so libmbx binds to the same HIP
+        # runtime instance (two runtimes in one process: "no ROCm-capable device is detected").
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)      # AttributeError if the export is missing

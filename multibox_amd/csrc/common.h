@@ -4,9 +4,18 @@
 #include <stdint.h>
 #include "../../include/mbx.h"
 
-#define MBX_LAUNCH_CHECK()                                    \
-  do {                                                        \
-    if (hipGetLastError() != hipSuccess) return MBX_ERR_LAUNCH; \
+#include <stdio.h>
+// Launch checking: MBX_ENTER() drops any stale error another library left in the runtime's
+// per-thread slot; MBX_LAUNCH_CHECK() then sees only this launch's own error.
+#define MBX_ENTER() (void)hipGetLastError()
+#define MBX_LAUNCH_CHECK()                                                              \
+  do {                                                                                  \
+    hipError_t mbx_e_ = hipGetLastError();                                              \
+    if (mbx_e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "[libmbx] %s:%d launch failed: %s\n", __FILE__, __LINE__,         \
+              hipGetErrorString(mbx_e_));                                               \
+      return MBX_ERR_LAUNCH;                                                            \
+    }                                                                                   \
   } while (0)
 
 static inline hipStream_t mbx_s(mbx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1,0 +1,520 @@
+// libmbx: implicit-GEMM convolution on MFMA (gfx950), forward + data gradient in one kernel,
+// and the weight-gradient kernel.  NHWC bf16 views, KRSC bf16 filters, fp32 accumulate.
+//
+// GEMM view (forward):  Y[m, n] = sum_k P[m, k] * W[n, k]
+//   m = (img, oh, ow) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
+// The MFMA is issued with the FILTER tile as the A operand and the PIXEL tile as the B operand
+// (v_mfma_f32_16x16x32_bf16: D[row = channel][col = pixel]), so each lane ends up holding four
+// CONSECUTIVE channels of one pixel -> 8-byte bf16 stores into NHWC.
+//
+// LDS tiles are [rows][64 k] bf16 = 128-B rows of eight 16-B chunks, XOR-swizzled
+// (chunk ^ (row & 7)) so the ds_read_b128 fragment reads are bank-conflict free; two buffers,
+// one barrier per 64-deep K step, next tile's global loads in flight during the MFMAs.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+struct ConvK {
+  const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
+  const unsigned short* w; int C_out, S, Ktot;
+  int mul, shift, pad_t, pad_l, W_out, HW_out, M;
+  void* y; int y_img_stride, ldy;
+  int epi, relu, accumulate;
+  const float* scale; const float* shiftv;
+  const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
+  float* stats;
+  int tiles_m, tiles_n;
+};
+
+constexpr int kThreads = 256;
+
+// XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each
+// XCD a contiguous run of logical tiles so that tiles sharing a pixel panel share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN, int WNW, int WMW>
+__global__ void __launch_bounds__(kThreads)
+conv_igemm_kernel(const ConvK p) {
+  static_assert(WNW * WMW == 4, "four waves");
+  constexpr int TN = BN / WNW, TM = BM / WMW, NI = TN / 16, MI = TM / 16;
+  constexpr int PI = BM / 32, WI = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* sP = smem;                    // [2][BM*8]
+  u32x4* sW = smem + 2 * BM * 8;       // [2][BN*8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WNW, wm = wave / WNW;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- loader state: thread owns 16-B chunk `chunk` of rows lrow + 32*i
+  const int chunk = tid & 7, lrow = tid >> 3;
+  int hb[PI], wb[PI], xb[PI];
+  bool mv[PI];
+#pragma unroll
+  for (int i = 0; i < PI; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    mv[i] = m < p.M;
+    const int mm = mv[i] ? m : 0;
+    const int img = mm / p.HW_out, rem = mm - img * p.HW_out;
+    const int oh = rem / p.W_out, ow = rem - oh * p.W_out;
+    hb[i] = oh * p.mul - p.pad_t;
+    wb[i] = ow * p.mul - p.pad_l;
+    xb[i] = img * p.x_img_stride;
+  }
+  int wo[WI];
+  bool wv[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int n = n0 + lrow + 32 * i;
+    wv[i] = n < p.C_out;
+    wo[i] = (wv[i] ? n : 0) * p.Ktot;
+  }
+  u32x4 rp[PI], rw[WI];
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int sw_st = chunk ^ (lrow & 7);
+  const int nk = (p.Ktot + 63) >> 6;
+  // One code instance of load / compute / store: iteration kt = -1 only stages tile 0.
+  for (int kt = -1; kt < nk; ++kt) {
+    const bool stage = kt + 1 < nk;
+    if (stage) {                                     // global -> registers, tile kt+1
+      const int k = (kt + 1) * 64 + chunk * 8;
+      const bool kv = k < p.Ktot;
+      const int kk = kv ? k : 0;
+      const int tap = kk / p.C_in, c = kk - tap * p.C_in;
+      const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int i = 0; i < PI; ++i) {
+        int hn = hb[i] + r, wn_ = wb[i] + s;
+        bool ok = mv[i] && kv;
+        if (p.shift) { ok = ok && (((hn | wn_) & 1) == 0); hn >>= 1; wn_ >>= 1; }
+        ok = ok && ((unsigned)hn < (unsigned)p.H_in) && ((unsigned)wn_ < (unsigned)p.W_in);
+        rp[i] = ok ? *reinterpret_cast<const u32x4*>(p.x + xb[i] + (hn * p.W_in + wn_) * p.ldx + c) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        rw[i] = (wv[i] && kv) ? *reinterpret_cast<const u32x4*>(p.w + wo[i] + k) : zero;
+    }
+    if (kt >= 0) {                                   // MFMA on tile kt
+      const u32x4* cW = sW + (kt & 1) * BN * 8;
+      const u32x4* cP = sP + (kt & 1) * BM * 8;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 wf[NI], pf[MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+          const int row = wn * TN + a * 16 + frow;
+          wf[a] = __builtin_bit_cast(bf16x8, cW[row * 8 + ((kk * 4 + fch) ^ (row & 7))]);
+        }
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+          const int row = wm * TM + b * 16 + frow;
+          pf[b] = __builtin_bit_cast(bf16x8, cP[row * 8 + ((kk * 4 + fch) ^ (row & 7))]);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (stage) {                                     // registers -> LDS buffer (kt+1)&1
+      u32x4* dP = sP + ((kt + 1) & 1) * BM * 8;
+      u32x4* dW = sW + ((kt + 1) & 1) * BN * 8;
+#pragma unroll
+      for (int i = 0; i < PI; ++i) dP[(lrow + 32 * i) * 8 + sw_st] = rp[i];
+#pragma unroll
+      for (int i = 0; i < WI; ++i) dW[(lrow + 32 * i) * 8 + sw_st] = rw[i];
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // lane: pixel = tile col (lane & 15), channels = (lane >> 4) * 4 + {0..3}
+  int yo[MI], so[MI];
+  bool mok[MI];
+#pragma unroll
+  for (int b = 0; b < MI; ++b) {
+    const int m = m0 + wm * TM + b * 16 + frow;
+    mok[b] = m < p.M;
+    const int mm = mok[b] ? m : 0;
+    const int img = mm / p.HW_out, pix = mm - img * p.HW_out;
+    yo[b] = img * p.y_img_stride + pix * p.ldy;
+    so[b] = img * p.skip_img_stride + pix * p.ld_skip;
+  }
+  float s1[NI][4], s2[NI][4];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    const int c0 = n0 + wn * TN + a * 16 + fch * 4;
+    if (c0 >= p.C_out) continue;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.epi == MBX_EPI_AFFINE || p.epi == MBX_EPI_RESIDUAL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (c0 + r < p.C_out) {
+          if (p.scale) sc[r] = p.scale[c0 + r];
+          if (p.shiftv) sh[r] = p.shiftv[c0 + r];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      if (!mok[b]) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if (p.epi == MBX_EPI_STORE_F32) {
+        float* yp = reinterpret_cast<float*>(p.y) + yo[b] + c0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r < p.C_out) yp[r] = v[r];
+        continue;
+      }
+      unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
+      if (p.epi == MBX_EPI_AFFINE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      } else if (p.epi == MBX_EPI_RESIDUAL) {
+        const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
+        const float k0 = bf2f(sk.x & 0xffffu), k1 = bf2f(sk.x >> 16), k2 = bf2f(sk.y & 0xffffu), k3 = bf2f(sk.y >> 16);
+        v[0] = k0 + p.rscale * (v[0] + sh[0]);
+        v[1] = k1 + p.rscale * (v[1] + sh[1]);
+        v[2] = k2 + p.rscale * (v[2] + sh[2]);
+        v[3] = k3 + p.rscale * (v[3] + sh[3]);
+      } else if (p.accumulate) {
+        const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
+        v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
+        v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      unsigned short q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
+      *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
+      if (p.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
+      }
+    }
+  }
+
+  if (p.stats) {
+    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes,
+    // then over the WMW pixel-waves through LDS (free after the K loop's last barrier).
+    float* red = reinterpret_cast<float*>(smem);   // [WMW][BN][2]
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x1 = s1[a][r], x2 = s2[a][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        if (frow == 0) {
+          const int cl = wn * TN + a * 16 + fch * 4 + r;
+          red[(wm * BN + cl) * 2 + 0] = x1;
+          red[(wm * BN + cl) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.C_out) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+      float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
+      o[0] = x1;
+      o[1] = x2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- weight gradient
+// dW[n][kc] += sum_m dY[m][n] * P[m][kc]; GEMM whose reduction runs over PIXELS, the slow NHWC
+// dimension of both operands: tiles are staged [pixel][channel] exactly as they lie in HBM and
+// the MFMA fragments (8 consecutive pixels of one channel) come out of LDS through the gfx950
+// transpose read ds_read_b64_tr_b16.  Split over pixels across blockIdx.y, fp32 atomics.
+struct WgradK {
+  const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
+  const unsigned short* dy; int dy_img_stride, ld_dy;
+  int C_out, S, Ktot, stride, pad_t, pad_l, W_out, HW_out, M;
+  float* dw; float* db;
+  int tiles_n, tiles_k, m_per_split;
+};
+
+__device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* tile, int row0, int cb, int lane) {
+  // rows row0 + 8*(lane>>4) + {0..7}, columns 16*cb + (lane & 15); tile rows are 256 B (16 chunks)
+  const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+  const int r_lo = row0 + 8 * g + q, r_hi = r_lo + 4;
+  const int ch = 2 * cb + (pp >> 1);
+  const unsigned short* a_lo = tile + r_lo * 128 + ((ch ^ wg_swz(r_lo)) << 3) + ((pp & 1) << 2);
+  const unsigned short* a_hi = tile + r_hi * 128 + ((ch ^ wg_swz(r_hi)) << 3) + ((pp & 1) << 2);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_hi));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(kThreads)
+conv_wgrad_kernel(const WgradK p) {
+  // block tile: 128 output channels x 128 k-columns, 64 pixels per step
+  __shared__ __attribute__((aligned(16))) unsigned short sY[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned short sX[2][64 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_k = blockIdx.x / p.tiles_n;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  const int lrow = tid >> 2, cq = tid & 3;           // row 0..63, chunks cq + 4*i
+  // fixed per-thread k-column decode (chunk of 8 input channels at one tap)
+  int tr_[4], ts_[4], tc_[4];
+  bool kv[4], nv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + (cq + 4 * i) * 8;
+    kv[i] = k < p.Ktot;
+    const int kk = kv[i] ? k : 0;
+    const int tap = kk / p.C_in;
+    tc_[i] = kk - tap * p.C_in;
+    tr_[i] = tap / p.S;
+    ts_[i] = tap - tr_[i] * p.S;
+    nv[i] = n0 + (cq + 4 * i) * 8 < p.C_out;
+  }
+  u32x4 ry[4], rx[4];
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                                   // bias gradient: channel n0 + tid (tid < 128)
+  const bool do_bias = p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
+  const int sw_st = wg_swz(lrow);
+
+  // One code instance of load / compute / store; the first iteration only stages step 0.
+  int it = -1;
+  for (int ms = m_begin - 64; ms < m_end; ms += 64, ++it) {
+    const bool stage = ms + 64 < m_end;
+    if (stage) {
+      const int m = ms + 64 + lrow;
+      const bool mv = m < m_end;
+      const int mm = mv ? m : 0;
+      const int img = mm / p.HW_out, pix = mm - img * p.HW_out;
+      const int oh = pix / p.W_out, ow = pix - oh * p.W_out;
+      const int hb = oh * p.stride - p.pad_t, wb = ow * p.stride - p.pad_l;
+      const unsigned short* yrow = p.dy + img * p.dy_img_stride + pix * p.ld_dy + n0;
+      const unsigned short* ximg = p.x + img * p.x_img_stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ry[i] = (mv && nv[i]) ? *reinterpret_cast<const u32x4*>(yrow + (cq + 4 * i) * 8) : zero;
+        const int h = hb + tr_[i], w = wb + ts_[i];
+        const bool ok = mv && kv[i] && ((unsigned)h < (unsigned)p.H_in) && ((unsigned)w < (unsigned)p.W_in);
+        rx[i] = ok ? *reinterpret_cast<const u32x4*>(ximg + (h * p.W_in + w) * p.ldx + tc_[i]) : zero;
+      }
+    }
+    if (it >= 0) {
+      const unsigned short* cY = sY[it & 1];
+      const unsigned short* cX = sX[it & 1];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 yf[4], xf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) yf[a] = tr_frag(cY, kk * 32, wn * 4 + a, lane);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xf[b] = tr_frag(cX, kk * 32, wk * 4 + b, lane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+      }
+      if (do_bias) {
+        const int ch = tid >> 3, e = tid & 7;
+        for (int r = 0; r < 64; ++r) bsum += bf2f(cY[r * 128 + ((ch ^ wg_swz(r)) << 3) + e]);
+      }
+    }
+    if (stage) {
+      unsigned short* dY = sY[(it + 1) & 1];
+      unsigned short* dX = sX[(it + 1) & 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = (cq + 4 * i) ^ sw_st;
+        *reinterpret_cast<u32x4*>(&dY[lrow * 128 + ch * 8]) = ry[i];
+        *reinterpret_cast<u32x4*>(&dX[lrow * 128 + ch * 8]) = rx[i];
+      }
+    }
+    __syncthreads();
+  }
+  // D[row = channel (lane>>4)*4 + r][col = k-column lane & 15]
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
+      if (kc >= p.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r]);
+    }
+  }
+  if (do_bias) atomicAdd(p.db + n0 + tid, bsum);
+}
+
+// ------------------------------------------------------------------------------- host side
+struct TileCfg { int BM, BN; float eff; };
+const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f}};
+
+int pick_cfg(long M, int C_out) {
+  int best = 0;
+  double best_t = 1e300;
+  for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
+    const TileCfg& c = kCfgs[i];
+    const long tiles = ((M + c.BM - 1) / c.BM) * ((C_out + c.BN - 1) / c.BN);
+    const long lds = 2L * (c.BM + c.BN) * 128;
+    long per_cu = (160 * 1024) / lds;
+    if (per_cu > 2) per_cu = 2;
+    const long rounds = (tiles + 256 * per_cu - 1) / (256 * per_cu);
+    const double t = (double)rounds * c.BM * c.BN / c.eff;
+    if (t < best_t) { best_t = t; best = i; }
+  }
+  return best;
+}
+
+template <int BM, int BN, int WNW, int WMW>
+int launch_igemm(ConvK& k, hipStream_t s) {
+  k.tiles_m = (k.M + BM - 1) / BM;
+  k.tiles_n = (k.C_out + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+int check_desc(const mbx_conv_desc* d) {
+  if (!d || !d->x || !d->N || d->N < 0) return MBX_ERR_INVALID_ARG;
+  if (d->C_in <= 0 || d->C_in % 8 || d->ldx % 8 || d->ldx < d->C_in) return MBX_ERR_INVALID_ARG;
+  if (d->R <= 0 || d->S <= 0 || d->C_out <= 0 || d->H_out <= 0 || d->W_out <= 0) return MBX_ERR_INVALID_ARG;
+  if (d->stride != 1 && d->stride != 2) return MBX_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(d->x) & 15)) return MBX_ERR_INVALID_ARG;
+  const long long xe = (long long)d->N * d->x_img_stride;
+  if (xe >= (1LL << 31) || (long long)d->N * d->H_out * d->W_out >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  return MBX_OK;
+}
+
+}  // namespace
+
+extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
+  if (!d) return MBX_ERR_INVALID_ARG;
+  const long M = (long)d->N * d->H_out * d->W_out;
+  const TileCfg& c = kCfgs[pick_cfg(M, d->C_out)];
+  return (int)((M + c.BM - 1) / c.BM);
+}
+
+extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
+  int st = check_desc(d);
+  if (st != MBX_OK) return st;
+  if (!d->w || !d->y) return MBX_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(d->w) & 15)) return MBX_ERR_INVALID_ARG;
+  const bool f32 = d->epilogue == MBX_EPI_STORE_F32;
+  if (!f32 && (d->C_out % 4 || d->ldy % 4 || (reinterpret_cast<uintptr_t>(d->y) & 7))) return MBX_ERR_INVALID_ARG;
+  if (d->epilogue == MBX_EPI_RESIDUAL && (!d->skip || d->ld_skip % 4 || (reinterpret_cast<uintptr_t>(d->skip) & 7)))
+    return MBX_ERR_INVALID_ARG;
+  if ((long long)d->N * d->y_img_stride >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  if (d->stats_partial && d->epilogue != MBX_EPI_STORE) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  ConvK k;
+  k.x = reinterpret_cast<const unsigned short*>(d->x);
+  k.x_img_stride = (int)d->x_img_stride; k.ldx = d->ldx; k.H_in = d->H_in; k.W_in = d->W_in; k.C_in = d->C_in;
+  k.w = reinterpret_cast<const unsigned short*>(d->w);
+  k.C_out = d->C_out; k.S = d->S; k.Ktot = d->R * d->S * d->C_in;
+  if (d->transposed) { k.mul = 1; k.shift = d->stride == 2 ? 1 : 0; } else { k.mul = d->stride; k.shift = 0; }
+  k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
+  k.M = d->N * k.HW_out;
+  k.y = d->y; k.y_img_stride = (int)d->y_img_stride; k.ldy = d->ldy;
+  k.epi = d->epilogue; k.relu = d->relu; k.accumulate = d->accumulate;
+  k.scale = d->scale; k.shiftv = d->shift;
+  k.skip = reinterpret_cast<const unsigned short*>(d->skip);
+  k.skip_img_stride = (int)d->skip_img_stride; k.ld_skip = d->ld_skip; k.rscale = d->rscale;
+  k.stats = d->stats_partial;
+  hipStream_t s = mbx_s(stream);
+  switch (pick_cfg(k.M, k.C_out)) {
+    case 0: return launch_igemm<128, 128, 2, 2>(k, s);
+    case 1: return launch_igemm<128, 64, 2, 2>(k, s);
+    case 2: return launch_igemm<64, 128, 2, 2>(k, s);
+    case 3: return launch_igemm<128, 32, 1, 4>(k, s);
+    default: return launch_igemm<64, 64, 2, 2>(k, s);
+  }
+}
+
+extern "C" int mbx_conv_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
+                              float* dw, float* db, mbx_stream_t stream) {
+  int st = check_desc(d);
+  if (st != MBX_OK) return st;
+  if (!dy || !dw || d->transposed) return MBX_ERR_INVALID_ARG;
+  if (ld_dy % 8 || ld_dy < ((d->C_out + 7) / 8) * 8 || (reinterpret_cast<uintptr_t>(dy) & 15)) return MBX_ERR_INVALID_ARG;
+  if ((long long)d->N * dy_img_stride >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  MBX_ENTER();
+  WgradK k;
+  k.x = reinterpret_cast<const unsigned short*>(d->x);
+  k.x_img_stride = (int)d->x_img_stride; k.ldx = d->ldx; k.H_in = d->H_in; k.W_in = d->W_in; k.C_in = d->C_in;
+  k.dy = reinterpret_cast<const unsigned short*>(dy); k.dy_img_stride = (int)dy_img_stride; k.ld_dy = ld_dy;
+  k.C_out = d->C_out; k.S = d->S; k.Ktot = d->R * d->S * d->C_in;
+  k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
+  k.M = d->N * k.HW_out;
+  k.dw = dw; k.db = db;
+  k.tiles_n = (k.C_out + 127) / 128;
+  k.tiles_k = (k.Ktot + 127) / 128;
+  const int tiles = k.tiles_n * k.tiles_k;
+  // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
+  int splits = (512 + tiles - 1) / tiles;
+  const int max_splits = (k.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int mps = (k.M + splits - 1) / splits;
+  mps = ((mps + 63) / 64) * 64;
+  splits = (k.M + mps - 1) / mps;
+  k.m_per_split = mps;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(kThreads), 0, mbx_s(stream), k);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}

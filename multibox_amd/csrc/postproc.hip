@@ -340,6 +340,7 @@ extern "C" int mbx_decode_conf(const float* raw_locs, const float* logits, const
   const int total = B * P;
   int blocks = (total + kThreads - 1) / kThreads;
   if (blocks > 2048) blocks = 2048;
+  MBX_ENTER();
   hipLaunchKernelGGL(decode_conf_kernel, dim3(blocks), dim3(kThreads), 0, mbx_s(stream),
                      reinterpret_cast<const float4*>(raw_locs), logits, reinterpret_cast<const float4*>(priors),
                      total, P, eps_add, reinterpret_cast<float4*>(decoded), conf);
@@ -358,6 +359,7 @@ extern "C" int mbx_match(const float* decoded, const float* conf, const float* g
   if (B == 0) return MBX_OK;
   const size_t lds = match_lds_bytes(P, G);
   if (lds > 150 * 1024) return MBX_ERR_UNSUPPORTED;        // P > ~4200 at G=100
+  MBX_ENTER();
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return MBX_ERR_LAUNCH;
@@ -378,6 +380,7 @@ extern "C" int mbx_loss_fwd_bwd(const float* decoded, const float* logits, int c
   if (!decoded || !logits || !gt || !match || !loss2 || B <= 0 || P <= 0 || G <= 0) return MBX_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < mbx_loss_workspace_bytes(B)) return MBX_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(workspace);
+  MBX_ENTER();
   hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(kThreads), 0, mbx_s(stream),
                      reinterpret_cast<const float4*>(decoded), logits, conf_is_logit,
                      reinterpret_cast<const float4*>(gt), match, alpha, grad_scale, P, G, partial, reinterpret_cast<float4*>(d_raw_locs), d_logits);
@@ -399,6 +402,7 @@ extern "C" int mbx_decode_filter_topk(const float* raw_locs, const float* conf, 
   while (N < P) N <<= 1;
   if (N > 16384) return MBX_ERR_UNSUPPORTED;
   const size_t lds = (size_t)N * sizeof(unsigned long long);
+  MBX_ENTER();
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_filter_topk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MBX_ERR_LAUNCH;

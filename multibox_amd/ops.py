@@ -1,0 +1,111 @@
+"""Thin Python launchers over the libmbx convolution-stack entry points (include/mbx.h).
+
+``View`` is an NHWC bf16 tensor *view*: a channel slice [ch_off, ch_off+C) of a buffer whose
+pixel stride is ``ld`` -- how tf.concat(3, ...) of model.py is made free.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+EPI_STORE, EPI_AFFINE, EPI_RESIDUAL, EPI_STORE_F32 = 0, 1, 2, 3
+
+
+class ConvDesc(C.Structure):
+    """mbx_conv_desc (include/mbx.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("x_img_stride", C.c_int64), ("ldx", C.c_int32),
+        ("N", C.c_int32), ("H_in", C.c_int32), ("W_in", C.c_int32), ("C_in", C.c_int32),
+        ("w", C.c_void_p), ("C_out", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
+        ("stride", C.c_int32), ("transposed", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("H_out", C.c_int32), ("W_out", C.c_int32),
+        ("y", C.c_void_p), ("y_img_stride", C.c_int64), ("ldy", C.c_int32),
+        ("epilogue", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("skip", C.c_void_p), ("skip_img_stride", C.c_int64), ("ld_skip", C.c_int32), ("rscale", C.c_float),
+        ("stats_partial", C.c_void_p),
+    ]
+
+
+class View:
+    """Channel-slice view of an NHWC buffer [N, H, W, ld] (bf16 unless elem_size says otherwise)."""
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "ch_off", "elem_size")
+
+    def __init__(self, buf, N, H, W, C, ld=None, ch_off=0, elem_size=2):
+        self.buf, self.N, self.H, self.W, self.C = buf, N, H, W, C
+        self.ld = C if ld is None else ld
+        self.ch_off, self.elem_size = ch_off, elem_size
+        assert buf.numel() * buf.element_size() >= N * H * W * self.ld * elem_size, "view larger than its buffer"
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.ch_off * self.elem_size
+
+    @property
+    def img_stride(self):
+        return self.H * self.W * self.ld
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def slice(self, off, C):
+        assert off + C <= self.C
+        return View(self.buf, self.N, self.H, self.W, C, self.ld, self.ch_off + off, self.elem_size)
+
+    def tensor(self):
+        """Materialise as a [N,H,W,C] tensor (tests / debugging)."""
+        dt = self.buf.dtype
+        flat = self.buf.reshape(-1)[: self.N * self.H * self.W * self.ld].reshape(self.N, self.H, self.W, self.ld)
+        return flat[..., self.ch_off:self.ch_off + self.C]
+
+    @staticmethod
+    def alloc(N, H, W, C, ld=None, dtype=torch.bfloat16, device="cuda", zero=False):
+        ld = C if ld is None else ld
+        f = torch.zeros if zero else torch.empty
+        return View(f((N, H, W, ld), dtype=dtype, device=device), N, H, W, C, ld, 0, torch.empty((), dtype=dtype).element_size())
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed=0, epilogue=EPI_STORE, relu=0,
+              accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None):
+    d = ConvDesc()
+    d.x, d.x_img_stride, d.ldx = x.ptr, x.img_stride, x.ld
+    d.N, d.H_in, d.W_in, d.C_in = x.N, x.H, x.W, x.C
+    d.w, d.C_out, d.R, d.S = (w.data_ptr() if w is not None else None), C_out, R, S
+    d.stride, d.transposed, d.pad_t, d.pad_l = stride, transposed, pad_t, pad_l
+    d.H_out, d.W_out = y.H, y.W
+    d.y, d.y_img_stride, d.ldy = y.ptr, y.img_stride, y.ld
+    d.epilogue, d.relu, d.accumulate = epilogue, int(relu), int(accumulate)
+    d.scale, d.shift = _p(scale), _p(shift)
+    if skip is not None:
+        d.skip, d.skip_img_stride, d.ld_skip = skip.ptr, skip.img_stride, skip.ld
+    d.rscale = float(rscale)
+    d.stats_partial = _p(stats)
+    return d
+
+
+def conv(desc: ConvDesc):
+    _lib.check(_lib.lib().mbx_conv(C.byref(desc), _stream()), "mbx_conv")
+
+
+def conv_stats_rows(desc: ConvDesc):
+    r = _lib.lib().mbx_conv_stats_rows(C.byref(desc))
+    if r < 0:
+        _lib.check(r, "mbx_conv_stats_rows")
+    return r
+
+
+def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
+    _lib.check(_lib.lib().mbx_conv_wgrad(C.byref(desc), dy.ptr, dy.img_stride, dy.ld, dw.data_ptr(), _p(db), _stream()),
+               "mbx_conv_wgrad")

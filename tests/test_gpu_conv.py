@@ -1,0 +1,211 @@
+"""GPU parity of the MFMA implicit-GEMM convolution kernels (forward, data gradient, weight
+gradient) against a torch-CPU float32 convolution on the same bf16-rounded inputs.
+
+Tolerance (bf16 in/out, fp32 accumulate): the kernel's result must be within ~1 bf16 ulp of
+the float32 reference: |out - ref| <= 2^-7 |ref| + 2e-3 * max|ref|  (stated, used below);
+float32 outputs (weight gradients, head outputs): rtol 2e-3 of max|ref|.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+    return torch
+
+
+def bf16_round(torch, t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def ref_conv(torch, x, w, stride, pads):
+    """x [N,H,W,C] f32, w [K,R,S,C] f32, pads (t,l,b,r) -> [N,Ho,Wo,K] f32 on CPU."""
+    import torch.nn.functional as F
+    xt = F.pad(x.permute(0, 3, 1, 2), (pads[1], pads[3], pads[0], pads[2]))
+    return F.conv2d(xt, w.permute(0, 3, 1, 2), stride=stride).permute(0, 2, 3, 1).contiguous()
+
+
+def close(torch, out, ref, f32=False):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    mx = float(ref.abs().max()) + 1e-20
+    if f32:
+        err = float((out - ref).abs().max())
+        return err <= 2e-3 * mx, "max err %.3g vs max|ref| %.3g" % (err, mx)
+    bad = (out - ref).abs() > (2.0 ** -7) * ref.abs() + 2e-3 * mx
+    return int(bad.sum()) == 0, "%d/%d out of tolerance, max err %.3g, max|ref| %.3g" % (
+        int(bad.sum()), bad.numel(), float((out - ref).abs().max()), mx)
+
+
+# name, N, H, W, Cin, Cout, R, S, stride, (pt, pl, pb, pr)
+GEOMS = [
+    ("1x1_320_96", 2, 35, 35, 320, 96, 1, 1, 1, (0, 0, 0, 0)),
+    ("1x1_1088_320", 3, 17, 17, 1088, 320, 1, 1, 1, (0, 0, 0, 0)),
+    ("3x3_same_32_48", 2, 35, 35, 32, 48, 3, 3, 1, (1, 1, 1, 1)),
+    ("3x3_valid_s2_stem", 2, 31, 31, 8, 32, 3, 3, 2, (0, 0, 0, 0)),
+    ("3x3_valid_80_192", 1, 21, 21, 80, 192, 3, 3, 1, (0, 0, 0, 0)),
+    ("1x7_128_160", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
+    ("7x1_160_192", 2, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)),
+    ("5x5_48_64", 1, 35, 35, 48, 64, 5, 5, 1, (2, 2, 2, 2)),
+    ("3x3_s2_same_asym", 4, 8, 8, 256, 256, 3, 3, 2, (0, 0, 1, 1)),
+    ("3x3_s2_valid_320_384", 2, 35, 35, 320, 384, 3, 3, 2, (0, 0, 0, 0)),
+    ("2x2_valid_128_96", 4, 4, 4, 128, 96, 2, 2, 1, (0, 0, 0, 0)),
+    ("1x3_192_224", 4, 8, 8, 192, 224, 1, 3, 1, (0, 1, 0, 1)),
+    ("1x1_2080_1536_m4096", 64, 8, 8, 2080, 1536, 1, 1, 1, (0, 0, 0, 0)),
+]
+
+
+def out_hw(H, W, R, S, stride, pads):
+    return (H + pads[0] + pads[2] - R) // stride + 1, (W + pads[1] + pads[3] - S) // stride + 1
+
+
+def make_case(torch, g, seed=0):
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    gen = torch.Generator().manual_seed(seed)
+    x = bf16_round(torch, torch.randn(N, H, W, Ci, generator=gen))
+    w = bf16_round(torch, torch.randn(Co, R, S, Ci, generator=gen) / (R * S * Ci) ** 0.5)
+    return x, w
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv_forward(T, g):
+    torch = T
+    from multibox_amd import ops
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    ref = ref_conv(torch, x, w, st, pads)
+    # input lives in a channel slice of a wider buffer; output too
+    xb = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb)
+    rows = ops.conv_stats_rows(d)
+    stats = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
+    d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=stats)
+    ops.conv(d)
+    torch.cuda.synchronize()
+    out = yb.tensor()
+    ok, msg = close(torch, out, ref)
+    assert ok, msg
+    # neighbours of the slice untouched
+    full = yb.buf.reshape(N, Ho, Wo, Co + 24)
+    assert float(full[..., :16].abs().max()) == 0 and float(full[..., 16 + Co:].abs().max()) == 0
+    # batch-norm statistics partials: sums of the STORED (bf16) values
+    st_sum = stats.sum(0).cpu()
+    o32 = out.float().cpu().reshape(-1, Co)
+    assert torch.allclose(st_sum[:, 0], o32.sum(0), rtol=1e-4, atol=1e-3 * float(o32.abs().sum(0).max()))
+    assert torch.allclose(st_sum[:, 1], (o32 * o32).sum(0), rtol=1e-4)
+
+
+def test_conv_epilogues(T):
+    torch = T
+    from multibox_amd import ops
+    g = ("e", 2, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0))
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=3)
+    gen = torch.Generator().manual_seed(4)
+    scale = torch.rand(Co, generator=gen) + 0.5
+    shift = torch.randn(Co, generator=gen)
+    skip = bf16_round(torch, torch.randn(N, H, W, Co, generator=gen))
+    ref = ref_conv(torch, x, w, st, pads)
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda()
+    sc, sh = scale.cuda(), shift.cuda()
+    # AFFINE + relu (frozen batch norm, detect.py:313-326)
+    y = ops.View.alloc(N, H, W, Co)
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, 0, 0, y, epilogue=ops.EPI_AFFINE, relu=1, scale=sc, shift=sh))
+    ok, msg = close(torch, y.tensor(), torch.relu(ref * scale + shift))
+    assert ok, "affine: " + msg
+    # RESIDUAL: relu(skip + 0.1*(acc + bias))  (model.py:39-43)
+    sk = ops.View.alloc(N, H, W, Co + 8).slice(8, Co)
+    sk.tensor().copy_(skip.to(torch.bfloat16))
+    for relu in (1, 0):
+        ops.conv(ops.make_desc(xb, wd, Co, R, S, st, 0, 0, y, epilogue=ops.EPI_RESIDUAL, relu=relu, shift=sh, skip=sk, rscale=0.1))
+        r = skip + 0.1 * (ref + shift)
+        ok, msg = close(torch, y.tensor(), torch.relu(r) if relu else r)
+        assert ok, "residual relu=%d: %s" % (relu, msg)
+    # accumulate (gradient summation into an existing bf16 buffer)
+    y.tensor().copy_(skip.to(torch.bfloat16))
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, 0, 0, y, accumulate=1))
+    ok, msg = close(torch, y.tensor(), skip + ref)
+    assert ok, "accumulate: " + msg
+
+
+def test_conv_f32_head_output(T):
+    """model.py:213-219: 1x1, no BN/bias/act, C_out = 5k = 25 (locations 4k + confidences k), fp32 out."""
+    torch = T
+    from multibox_amd import ops
+    g = ("h", 3, 6, 6, 96, 25, 1, 1, 1, (0, 0, 0, 0))
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=5)
+    ref = ref_conv(torch, x, w, st, pads)
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    y = ops.View.alloc(N, H, W, Co, ld=32, dtype=torch.float32, zero=True)
+    ops.conv(ops.make_desc(xb, w.to(torch.bfloat16).cuda(), Co, R, S, st, 0, 0, y, epilogue=ops.EPI_STORE_F32))
+    ok, msg = close(torch, y.tensor(), ref, f32=True)
+    assert ok, msg
+    assert float(y.buf.reshape(N, H, W, 32)[..., Co:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("g", GEOMS[:12], ids=[g[0] for g in GEOMS[:12]])
+def test_conv_dgrad_wgrad(T, g):
+    torch = T
+    from multibox_amd import ops
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=7)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    gen = torch.Generator().manual_seed(8)
+    dy = bf16_round(torch, torch.randn(N, Ho, Wo, Co, generator=gen))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref_conv(torch, xr, wr, st, pads).backward(dy)
+    dyb = ops.View.alloc(N, Ho, Wo, Co + 8).slice(8, Co)
+    dyb.buf.zero_()
+    dyb.tensor().copy_(dy.to(torch.bfloat16))
+    # ---- data gradient: transposed conv with the flipped, channel-transposed filter
+    wT = w.flip(1, 2).permute(3, 1, 2, 0).contiguous().to(torch.bfloat16).cuda()       # [Ci][R][S][Co]
+    dx = ops.View.alloc(N, H, W, Ci + 8, zero=True).slice(0, Ci)
+    ops.conv(ops.make_desc(dyb, wT, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], dx, transposed=1))
+    ok, msg = close(torch, dx.tensor(), xr.grad)
+    assert ok, "dgrad: " + msg
+    # ---- weight (+ bias) gradient
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
+    db = torch.zeros((Co,), dtype=torch.float32, device="cuda")
+    yv = ops.View.alloc(N, Ho, Wo, Co)
+    d = ops.make_desc(xb, None, Co, R, S, st, pads[0], pads[1], yv)
+    ops.conv_wgrad(d, dyb, dw, db)
+    ok, msg = close(torch, dw, wr.grad, f32=True)
+    assert ok, "wgrad: " + msg
+    ok, msg = close(torch, db, dy.reshape(-1, Co).sum(0), f32=True)
+    assert ok, "bias grad: " + msg
+
+
+def test_wgrad_odd_cout_padded_dy(T):
+    """Head output conv: C_out = 25 with dy padded to ld 32 (zeros beyond 25)."""
+    torch = T
+    from multibox_amd import ops
+    N, H, W, Ci, Co = 4, 6, 6, 96, 25
+    gen = torch.Generator().manual_seed(9)
+    x = bf16_round(torch, torch.randn(N, H, W, Ci, generator=gen))
+    dy = bf16_round(torch, torch.randn(N, H, W, Co, generator=gen))
+    ref = torch.einsum("nhwk,nhwc->kc", dy, x).reshape(Co, 1, 1, Ci)
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    dyb = ops.View.alloc(N, H, W, Co, ld=32, zero=True)
+    dyb.tensor().copy_(dy.to(torch.bfloat16))
+    dw = torch.zeros((Co, 1, 1, Ci), dtype=torch.float32, device="cuda")
+    d = ops.make_desc(xb, None, Co, 1, 1, 1, 0, 0, ops.View.alloc(N, H, W, 32))
+    d.C_out = Co
+    ops.conv_wgrad(d, dyb, dw)
+    ok, msg = close(torch, dw, ref, f32=True)
+    assert ok, msg
