@@ -154,6 +154,102 @@ int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
 int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const void* dy,
                    int64_t dy_img_stride, int32_t ld_dy, float* dw, float* db, mbx_stream_t stream);
 
+/* Scalars on the dgrad/wgrad path: mbx_conv multiplies the accumulator by `rscale` when
+ * epilogue == MBX_EPI_STORE and rscale != 0 (the residual branch scale of model.py:21 on the
+ * way back); mbx_conv_wgrad_scaled multiplies dw/db contributions by `scale`.             */
+int mbx_conv_wgrad_scaled(const mbx_conv_desc* desc, const void* dy, int64_t dy_img_stride,
+                          int32_t ld_dy, float scale, float* dw, float* db, mbx_stream_t stream);
+
+/* ----------------------------------------------------------------- batch norm (K8, A3)
+ * slim.batch_norm as the reference configures it (train.py:94-99): no gamma
+ * (scale=False), beta, epsilon 0.001, batch statistics over N*H*W when training, moving
+ * averages updated as moving -= (1-decay)*(moving - batch) (biased variance).
+ * Forward training = mbx_conv(stats_partial) -> mbx_bn_finalize -> mbx_bn_apply.          */
+int mbx_bn_finalize(const float* stats_partial /*[rows,C,2]*/, int rows, int C, int64_t count,
+                    float eps, float decay, float* mean /*[C]*/, float* rstd /*[C]*/,
+                    float* moving_mean /*[C] or NULL*/, float* moving_var /*[C] or NULL*/,
+                    mbx_stream_t stream);
+/* a = relu?((y - mean) * rstd + beta): y bf16 [M,C] contiguous -> a bf16 view (ld_a).     */
+int mbx_bn_apply(const void* y, int64_t M, int C, const float* mean, const float* rstd,
+                 const float* beta, int relu, void* a, int ld_a, mbx_stream_t stream);
+/* Frozen BN folded into the conv epilogue (detect.py:313-326, train.py:124-131):
+ * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
+int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,
+                int C, float* scale, float* shift, mbx_stream_t stream);
+/* Backward through relu + batch norm.  g = da * (a > 0) (relu) ; xhat = (y-mean)*rstd;
+ * pass 1 writes partial sums {sum g, sum g*xhat} [rows,C,2]; mbx_bn_bwd_finalize reduces them,
+ * ACCUMULATES dbeta += sum g and stores m1 = sum g / M, m2 = sum g*xhat / M;
+ * pass 2: dy = rstd * (g - m1 - xhat*m2)  (bf16 [M,C]).                                     */
+int mbx_bn_bwd_rows(int64_t M, int C);
+int mbx_bn_bwd_reduce(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y,
+                      int64_t M, int C, const float* mean, const float* rstd,
+                      float* partial /*[mbx_bn_bwd_rows,C,2]*/, mbx_stream_t stream);
+int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_t M, float* dbeta /*[C] +=*/,
+                        float* m12 /*[2,C]*/, mbx_stream_t stream);
+int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y,
+                     int64_t M, int C, const float* mean, const float* rstd, const float* m12,
+                     void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
+
+/* ---------------------------------------------------------------------- pooling (K9)
+ * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap
+ * index, first maximum) is kept for the backward pass.  avg: k x k stride 1, pad `pad`
+ * on every side, divisor = number of valid taps (TF SAME semantics, model.py:134; VALID
+ * 8x8 of model.py:285 with pad 0).  Backward passes gather, `accumulate` adds to dx.      */
+int mbx_maxpool_fwd(const void* x, int64_t x_img_stride, int ldx, int N, int H, int W, int C,
+                    int k, int stride, void* y, int64_t y_img_stride, int ldy, int Ho, int Wo,
+                    uint8_t* argmax /*[N,Ho,Wo,C] or NULL*/, mbx_stream_t stream);
+int mbx_maxpool_bwd(const void* dy, int64_t dy_img_stride, int ld_dy, const uint8_t* argmax,
+                    int N, int H, int W, int C, int k, int stride, int Ho, int Wo, void* dx,
+                    int64_t dx_img_stride, int ld_dx, int accumulate, mbx_stream_t stream);
+int mbx_avgpool_fwd(const void* x, int64_t x_img_stride, int ldx, int N, int H, int W, int C,
+                    int k, int pad, void* y, int64_t y_img_stride, int ldy, int Ho, int Wo,
+                    mbx_stream_t stream);
+int mbx_avgpool_bwd(const void* dy, int64_t dy_img_stride, int ld_dy, int N, int H, int W, int C,
+                    int k, int pad, int Ho, int Wo, void* dx, int64_t dx_img_stride, int ld_dx,
+                    int accumulate, mbx_stream_t stream);
+
+/* ------------------------------------------------------------------- small glue kernels
+ * relu backward in place: g *= (a > 0)   (model.py:22-23 on the way back).                 */
+int mbx_relu_mask(void* g, int ld_g, const void* a, int ld_a, int64_t M, int C, mbx_stream_t stream);
+/* images float32 [N,H,W,3] -> bf16 [N,H,W,8] (channels 3..7 zero) for the stem conv.       */
+int mbx_pack_input(const float* img, int64_t pixels, void* out, mbx_stream_t stream);
+/* Detection heads (model.py:295-322): one head's float32 conv output h [N*cells, ld_h]
+ * (channels [0,4k) locations, [4k,5k) confidence logits) <-> locations [N,P,4],
+ * logits [N,P] at prior offset `off` (flatten order of model.py:296-319).
+ * scatter writes the bf16 gradient [N*cells, ld_g] (zero beyond 5k) from d_locs/d_logits.  */
+int mbx_head_gather(const float* h, int ld_h, int N, int cells, int k, int P, int off,
+                    float* locs, float* logits, mbx_stream_t stream);
+int mbx_head_scatter(const float* d_locs, const float* d_logits, int N, int cells, int k, int P,
+                     int off, void* g, int ld_g, mbx_stream_t stream);
+
+/* ---------------------------------------------------------- parameters (A8, K16-K18)
+ * Filters live as float32 masters in one flat buffer (KRSC each); the bf16 copies the
+ * kernels read are refreshed once per step.  mbx_filter_prepare writes, for every table
+ * entry, the flipped channel-transposed dgrad copy [C][R][S][Kpad] from the bf16 KRSC copy. */
+typedef struct {
+  int64_t src_off;  /* element offset of the KRSC filter in the bf16 flat buffer           */
+  int64_t dst_off;  /* element offset of the [C][R][S][Kpad] copy in the dgrad buffer       */
+  int32_t K, R, S, C, Kpad;
+  int32_t first_block; /* prefix sum of ceil(C*R*S*Kpad / 2048) over the entries            */
+} mbx_filter_entry;
+int mbx_filter_prepare(const void* w_bf16, void* w_dgrad, const mbx_filter_entry* table /*DEVICE*/,
+                       int n_entries, int total_blocks, mbx_stream_t stream);
+
+/* RMSProp (tf.train.RMSPropOptimizer, train.py:207-212) + L2 regulariser gradient
+ * (train.py:104-105: g += wd*w) + EMA of the variables (train.py:253-259) + refresh of the
+ * bf16 copy, one pass over a flat parameter range:
+ *   ema -= (1-ema_decay)*(ema - w)   [value before this step's update]
+ *   g' = g + wd*w ; ms = decay*ms + (1-decay)*g'^2 ; mom = momentum*mom + lr*g'/sqrt(ms+eps)
+ *   w -= mom ; w_bf16 = bf16(w)
+ * reg_loss (float32 scalar, may be NULL) += wd/2 * sum w^2 (the value before the update:
+ * slim's regularization loss in total_loss, train.py:246).  `trainable` = 0 skips the
+ * update (frozen variables still get EMA, regulariser and bf16 refresh).                   */
+int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* mom /*NULL if momentum==0*/,
+                         float* ema /*or NULL*/, void* w_bf16 /*or NULL*/, int64_t n, float lr,
+                         float decay, float momentum, float eps, float wd, float ema_decay,
+                         int trainable, float* reg_loss, mbx_stream_t stream);
+int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, mbx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,25 @@ _SIGS = {
     "mbx_conv_stats_rows": (I, [P]),
     "mbx_conv": (I, [P, P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
+    "mbx_conv_wgrad_scaled": (I, [P, P, C.c_int64, I, F, P, P, P]),
+    "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
+    "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
+    "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
+    "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
+    "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P]),
+    "mbx_bn_bwd_finalize": (I, [P, I, I, C.c_int64, P, P, P]),
+    "mbx_bn_bwd_apply": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P]),
+    "mbx_maxpool_fwd": (I, [P, C.c_int64, I, I, I, I, I, I, I, P, C.c_int64, I, I, I, P, P]),
+    "mbx_maxpool_bwd": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, I, I, P, C.c_int64, I, I, P]),
+    "mbx_avgpool_fwd": (I, [P, C.c_int64, I, I, I, I, I, I, I, P, C.c_int64, I, I, I, P]),
+    "mbx_avgpool_bwd": (I, [P, C.c_int64, I, I, I, I, I, I, I, I, I, P, C.c_int64, I, I, P]),
+    "mbx_relu_mask": (I, [P, I, P, I, C.c_int64, I, P]),
+    "mbx_pack_input": (I, [P, C.c_int64, P, P]),
+    "mbx_head_gather": (I, [P, I, I, I, I, I, I, P, P, P]),
+    "mbx_head_scatter": (I, [P, P, I, I, I, I, I, P, I, P]),
+    "mbx_filter_prepare": (I, [P, P, P, I, I, P]),
+    "mbx_rmsprop_ema_step": (I, [P, P, P, P, P, P, C.c_int64, F, F, F, F, F, F, I, P, P]),
+    "mbx_ema_update": (I, [P, P, C.c_int64, F, P]),
 }
 
 _lib = None
@@ -47,6 +66,12 @@ _lib = None
 
 class MbxError(RuntimeError):
     pass
+
+
+class FilterEntry(C.Structure):
+    """mbx_filter_entry (include/mbx.h)."""
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
+                ("C", C.c_int32), ("Kpad", C.c_int32), ("first_block", C.c_int32)]
 
 
 def lib():

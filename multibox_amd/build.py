@@ -21,6 +21,7 @@ SOURCES = {
     "priors.cpp": ["-ffp-contract=off"],
     "postproc.hip": ["-ffp-contract=off"],
     "conv.hip": ["-munsafe-fp-atomics"],
+    "nnops.hip": ["-munsafe-fp-atomics"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 

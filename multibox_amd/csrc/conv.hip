@@ -207,7 +207,13 @@ conv_igemm_kernel(const ConvK p) {
         v[1] = k1 + p.rscale * (v[1] + sh[1]);
         v[2] = k2 + p.rscale * (v[2] + sh[2]);
         v[3] = k3 + p.rscale * (v[3] + sh[3]);
-      } else if (p.accumulate) {
+      } else {
+        if (p.rscale != 0.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
+        }
+      }
+      if (p.epi == MBX_EPI_STORE && p.accumulate) {
         const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
         v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
         v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
@@ -265,7 +271,7 @@ struct WgradK {
   const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
   const unsigned short* dy; int dy_img_stride, ld_dy;
   int C_out, S, Ktot, stride, pad_t, pad_l, W_out, HW_out, M;
-  float* dw; float* db;
+  float* dw; float* db; float scale;
   int tiles_n, tiles_k, m_per_split;
 };
 
@@ -388,10 +394,10 @@ conv_wgrad_kernel(const WgradK p) {
       if (kc >= p.Ktot) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r]);
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
     }
   }
-  if (do_bias) atomicAdd(p.db + n0 + tid, bsum);
+  if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -486,8 +492,8 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   }
 }
 
-extern "C" int mbx_conv_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
-                              float* dw, float* db, mbx_stream_t stream) {
+extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
+                                     float scale, float* dw, float* db, mbx_stream_t stream) {
   int st = check_desc(d);
   if (st != MBX_OK) return st;
   if (!dy || !dw || d->transposed) return MBX_ERR_INVALID_ARG;
@@ -501,7 +507,7 @@ extern "C" int mbx_conv_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy
   k.C_out = d->C_out; k.S = d->S; k.Ktot = d->R * d->S * d->C_in;
   k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
   k.M = d->N * k.HW_out;
-  k.dw = dw; k.db = db;
+  k.dw = dw; k.db = db; k.scale = scale;
   k.tiles_n = (k.C_out + 127) / 128;
   k.tiles_k = (k.Ktot + 127) / 128;
   const int tiles = k.tiles_n * k.tiles_k;
@@ -517,4 +523,9 @@ extern "C" int mbx_conv_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(kThreads), 0, mbx_s(stream), k);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
+}
+
+extern "C" int mbx_conv_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
+                              float* dw, float* db, mbx_stream_t stream) {
+  return mbx_conv_wgrad_scaled(d, dy, dy_img_stride, ld_dy, 1.0f, dw, db, stream);
 }

@@ -1,0 +1,671 @@
+// libmbx: batch norm (fwd/bwd), pooling, relu mask, head gather/scatter, input packing,
+// filter preparation and the fused RMSProp+L2+EMA step.  All HBM-bound: 16-byte (8 x bf16)
+// accesses per lane along the NHWC channel axis, grid-stride loops capped at 2048 blocks.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+constexpr int kT = 256;
+
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ unsigned f2bf(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+  f[0] = bf2f(v.x & 0xffffu); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffffu); f[3] = bf2f(v.y >> 16);
+  f[4] = bf2f(v.z & 0xffffu); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffffu); f[7] = bf2f(v.w >> 16);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+  v.x = f2bf(f[0]) | (f2bf(f[1]) << 16); v.y = f2bf(f[2]) | (f2bf(f[3]) << 16);
+  v.z = f2bf(f[4]) | (f2bf(f[5]) << 16); v.w = f2bf(f[6]) | (f2bf(f[7]) << 16);
+  return v;
+}
+__device__ __forceinline__ u32x4 ld8(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st8(unsigned short* p, const u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+inline int grid_for(long long work_items) {
+  long long b = (work_items + kT - 1) / kT;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ batch norm: finalize
+__global__ void __launch_bounds__(kT)
+bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_count, float eps, float decay,
+                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ mmean,
+                   float* __restrict__ mvar) {
+  __shared__ double red[16][16][2];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
+      s1 += v.x; s2 += v.y;
+    }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int r = 1; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    const double m = s1 * inv_count;
+    double var = s2 * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mmean) mmean[c] -= (1.0f - decay) * (mmean[c] - (float)m);        // assign_moving_average
+    if (mvar) mvar[c] -= (1.0f - decay) * (mvar[c] - (float)var);
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+bn_fold_kernel(const float* mm, const float* mv, const float* beta, float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c < C) {
+    const float s = 1.0f / sqrtf(mv[c] + eps);
+    scale[c] = s;
+    shift[c] = (beta ? beta[c] : 0.f) - mm[c] * s;
+  }
+}
+
+// ------------------------------------------------------------------ batch norm: apply
+__global__ void __launch_bounds__(kT)
+bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ mean,
+                const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
+                unsigned short* __restrict__ a, int ld_a) {
+  const int C8 = C >> 3;
+  const long long total = M * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8) << 3;
+    float f[8];
+    unpack8(ld8(y + m * C + c), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = (f[j] - mean[c + j]) * rstd[c + j] + beta[c + j];
+      f[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+    st8(a + m * ld_a + c, pack8(f));
+  }
+}
+
+// ---------------------------------------------------------------- batch norm: backward
+struct BnBwdGeom { int C8, rows_per_iter, rpb, rows; };
+inline BnBwdGeom bn_bwd_geom(long long M, int C) {
+  BnBwdGeom g;
+  g.C8 = C / 8;
+  g.rows_per_iter = kT / g.C8;
+  if (g.rows_per_iter < 1) g.rows_per_iter = 1;
+  long long rpb = (M + 511) / 512;
+  if (rpb < 4LL * g.rows_per_iter) rpb = 4LL * g.rows_per_iter;
+  rpb = ((rpb + g.rows_per_iter - 1) / g.rows_per_iter) * g.rows_per_iter;
+  g.rpb = (int)rpb;
+  g.rows = (int)((M + rpb - 1) / rpb);
+  return g;
+}
+
+__global__ void __launch_bounds__(kT)
+bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
+                     int relu, const unsigned short* __restrict__ y, long long M, int C,
+                     const float* __restrict__ mean, const float* __restrict__ rstd, int rpi, int rpb,
+                     float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16]
+  const int C8 = C >> 3;
+  const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+  const bool active = rr < rpi;
+  const int c = vc << 3;
+  float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
+  const long long r0 = (long long)blockIdx.x * rpb;
+  long long r1 = r0 + rpb;
+  if (r1 > M) r1 = M;
+  if (active)
+    for (long long m = r0 + rr; m < r1; m += rpi) {
+      float g[8], yy[8], aa[8];
+      unpack8(ld8(da + m * ld_da + c), g);
+      unpack8(ld8(y + m * C + c), yy);
+      if (relu) unpack8(ld8(a + m * ld_a + c), aa);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+        s1[j] += gj;
+        s2[j] += gj * ((yy[j] - mu[j]) * rs[j]);
+      }
+    }
+  if (active) {
+    float* o = sred + ((size_t)rr * C8 + vc) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = s1[j]; o[8 + j] = s2[j]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int r = 0; r < rpi; ++r) {
+      const float* o = sred + ((size_t)r * C8 + threadIdx.x) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+    }
+    float* p = partial + ((size_t)blockIdx.x * C + (threadIdx.x << 3)) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[2 * j] = s1[j]; p[2 * j + 1] = s2[j]; }
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_M, float* __restrict__ dbeta,
+                       float* __restrict__ m12) {
+  __shared__ double red[16][16][2];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
+      s1 += v.x; s2 += v.y;
+    }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int r = 1; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    if (dbeta) dbeta[c] += (float)s1;
+    m12[c] = (float)(s1 * inv_M);
+    m12[C + c] = (float)(s2 * inv_M);
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+bn_bwd_apply_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
+                    int relu, const unsigned short* __restrict__ y, long long M, int C,
+                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m12,
+                    unsigned short* __restrict__ dy) {
+  const int C8 = C >> 3;
+  const long long total = M * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8) << 3;
+    float g[8], yy[8], aa[8], o[8];
+    unpack8(ld8(da + m * ld_da + c), g);
+    unpack8(ld8(y + m * C + c), yy);
+    if (relu) unpack8(ld8(a + m * ld_a + c), aa);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+      const float rs = rstd[c + j];
+      const float xh = (yy[j] - mean[c + j]) * rs;
+      o[j] = rs * (gj - m12[c + j] - xh * m12[C + c + j]);
+    }
+    st8(dy + m * C + c, pack8(o));
+  }
+}
+
+// ------------------------------------------------------------------------------- pooling
+__global__ void __launch_bounds__(kT)
+maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
+                   int stride, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo,
+                   unsigned char* __restrict__ argmax) {
+  const int C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const int c = (int)(i % C8) << 3;
+    long long t = i / C8;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best[8];
+    unsigned arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+    for (int r = 0; r < k; ++r)
+      for (int s = 0; s < k; ++s) {
+        const int h = oh * stride + r, w = ow * stride + s;
+        if (h >= H || w >= W) continue;
+        float f[8];
+        unpack8(ld8(x + n * xs + ((long long)h * W + w) * ldx + c), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > best[j]) { best[j] = f[j]; arg[j] = r * k + s; }
+      }
+    st8(y + n * ys + ((long long)oh * Wo + ow) * ldy + c, pack8(best));
+    if (argmax) {
+      u32x2 av;
+      av.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+      av.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+      *reinterpret_cast<u32x2*>(argmax + (((long long)n * Ho + oh) * Wo + ow) * C + c) = av;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+maxpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_dy,
+                   const unsigned char* __restrict__ argmax, int N, int H, int W, int C, int k, int stride, int Ho,
+                   int Wo, unsigned short* __restrict__ dx, long long dxs, int ld_dx, int accumulate) {
+  const int C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const int c = (int)(i % C8) << 3;
+    long long t = i / C8;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+    unsigned short* dst = dx + n * dxs + ((long long)h * W + w) * ld_dx + c;
+    if (accumulate) unpack8(ld8(dst), acc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    int oh0 = (h - k + stride) / stride;          // ceil((h-k+1)/stride) for h-k+1 > -stride
+    if (h - k + 1 <= 0) oh0 = 0;
+    int ow0 = (w - k + stride) / stride;
+    if (w - k + 1 <= 0) ow0 = 0;
+    const int oh1 = min(h / stride, Ho - 1), ow1 = min(w / stride, Wo - 1);
+    for (int oh = oh0; oh <= oh1; ++oh)
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        const unsigned tap = (h - oh * stride) * k + (w - ow * stride);
+        const long long o = ((long long)n * Ho + oh) * Wo + ow;
+        const u32x2 av = *reinterpret_cast<const u32x2*>(argmax + o * C + c);
+        float g[8];
+        unpack8(ld8(dy + n * dys + ((long long)oh * Wo + ow) * ld_dy + c), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned aj = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xffu;
+          if (aj == tap) acc[j] += g[j];
+        }
+      }
+    st8(dst, pack8(acc));
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+avgpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
+                   int pad, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const int c = (int)(i % C8) << 3;
+    long long t = i / C8;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    int cnt = 0;
+    for (int r = 0; r < k; ++r)
+      for (int s = 0; s < k; ++s) {
+        const int h = oh - pad + r, w = ow - pad + s;
+        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+        float f[8];
+        unpack8(ld8(x + n * xs + ((long long)h * W + w) * ldx + c), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        ++cnt;
+      }
+    const float inv = 1.0f / (float)cnt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= inv;
+    st8(y + n * ys + ((long long)oh * Wo + ow) * ldy + c, pack8(acc));
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+avgpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_dy, int N, int H, int W, int C, int k,
+                   int pad, int Ho, int Wo, unsigned short* __restrict__ dx, long long dxs, int ld_dx,
+                   int accumulate) {
+  const int C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const int c = (int)(i % C8) << 3;
+    long long t = i / C8;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+    unsigned short* dst = dx + n * dxs + ((long long)h * W + w) * ld_dx + c;
+    if (accumulate) unpack8(ld8(dst), acc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    const int oh0 = max(h + pad - k + 1, 0), oh1 = min(h + pad, Ho - 1);
+    const int ow0 = max(w + pad - k + 1, 0), ow1 = min(w + pad, Wo - 1);
+    for (int oh = oh0; oh <= oh1; ++oh) {
+      const int nh = min(oh - pad + k, H) - max(oh - pad, 0);
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        const int nw = min(ow - pad + k, W) - max(ow - pad, 0);
+        const float inv = 1.0f / (float)(nh * nw);
+        float g[8];
+        unpack8(ld8(dy + n * dys + ((long long)oh * Wo + ow) * ld_dy + c), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g[j] * inv;
+      }
+    }
+    st8(dst, pack8(acc));
+  }
+}
+
+// ------------------------------------------------------------------------- glue kernels
+__global__ void __launch_bounds__(kT)
+relu_mask_kernel(unsigned short* __restrict__ g, int ld_g, const unsigned short* __restrict__ a, int ld_a,
+                 long long M, int C) {
+  const int C8 = C >> 3;
+  const long long total = M * C8;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8) << 3;
+    float gg[8], aa[8];
+    unpack8(ld8(g + m * ld_g + c), gg);
+    unpack8(ld8(a + m * ld_a + c), aa);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!(aa[j] > 0.f)) gg[j] = 0.f;
+    st8(g + m * ld_g + c, pack8(gg));
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+pack_input_kernel(const float* __restrict__ img, long long pixels, unsigned short* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < pixels; i += (long long)gridDim.x * kT) {
+    float f[8] = {img[3 * i], img[3 * i + 1], img[3 * i + 2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    st8(out + 8 * i, pack8(f));
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+head_gather_kernel(const float* __restrict__ h, int ld_h, int N, int cells, int k, int P, int off,
+                   float* __restrict__ locs, float* __restrict__ logits) {
+  const int total = N * cells * k;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    const int a = i % k, t = i / k, cell = t % cells, n = t / cells;
+    const float* row = h + (size_t)(n * cells + cell) * ld_h;
+    const size_t p = (size_t)n * P + off + cell * k + a;
+    *reinterpret_cast<float4*>(locs + p * 4) = make_float4(row[a * 4], row[a * 4 + 1], row[a * 4 + 2], row[a * 4 + 3]);
+    logits[p] = row[4 * k + a];
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+head_scatter_kernel(const float* __restrict__ d_locs, const float* __restrict__ d_logits, int N, int cells, int k,
+                    int P, int off, unsigned short* __restrict__ g, int ld_g) {
+  const int total = N * cells * ld_g;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    const int ch = i % ld_g, t = i / ld_g, cell = t % cells, n = t / cells;
+    const size_t p = (size_t)n * P + off + cell * k;
+    float v = 0.f;
+    if (ch < 4 * k) v = d_locs[(p + ch / 4) * 4 + (ch & 3)];
+    else if (ch < 5 * k) v = d_logits[p + (ch - 4 * k)];
+    g[i] = (unsigned short)f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------------- filter prepare
+__global__ void __launch_bounds__(kT)
+filter_prepare_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wd,
+                      const mbx_filter_entry* __restrict__ table, int n_entries) {
+  // binary search: last entry with first_block <= blockIdx.x
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const mbx_filter_entry e = table[lo];
+  const long long n = (long long)e.C * e.R * e.S * e.Kpad;
+  const long long base = (long long)(blockIdx.x - e.first_block) * 2048;
+  const unsigned short* src = w + e.src_off;
+  unsigned short* dst = wd + e.dst_off;
+  for (int j = 0; j < 8; ++j) {
+    const long long i = base + j * kT + threadIdx.x;
+    if (i >= n) break;
+    const int kq = (int)(i % e.Kpad);
+    long long t = i / e.Kpad;
+    const int s = (int)(t % e.S); t /= e.S;
+    const int r = (int)(t % e.R);
+    const int c = (int)(t / e.R);
+    unsigned short v = 0;
+    if (kq < e.K) v = src[(((long long)kq * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.C + c];
+    dst[i] = v;
+  }
+}
+
+// --------------------------------------------------------------------------- optimizer
+__global__ void __launch_bounds__(kT)
+rmsprop_ema_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms, float* __restrict__ mom,
+                   float* __restrict__ ema, unsigned short* __restrict__ wb, long long n, float lr, float decay,
+                   float momentum, float eps, float wd, float ema_decay, int trainable, float* __restrict__ reg_loss) {
+  float sq = 0.f;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    float wi = w[i];
+    sq += wi * wi;
+    if (ema) { const float e = ema[i]; ema[i] = e - (1.0f - ema_decay) * (e - wi); }
+    if (trainable) {
+      const float gi = g[i] + wd * wi;
+      const float m = decay * ms[i] + (1.0f - decay) * gi * gi;
+      ms[i] = m;
+      float step = lr * gi / sqrtf(m + eps);
+      if (mom) { step = momentum * mom[i] + step; mom[i] = step; }
+      wi -= step;
+      w[i] = wi;
+    }
+    if (wb) wb[i] = (unsigned short)f2bf(wi);
+  }
+  if (reg_loss && wd != 0.f) {
+    sq = wave_sum(sq);
+    __shared__ float red[kT / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < kT / 64; ++i) t += red[i];
+      atomicAdd(reg_loss, 0.5f * wd * t);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+ema_update_kernel(float* __restrict__ ema, const float* __restrict__ v, long long n, float d) {
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    const float e = ema[i];
+    ema[i] = e - (1.0f - d) * (e - v[i]);
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+typedef const unsigned short* cus;
+typedef unsigned short* us;
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" int mbx_bn_finalize(const float* part, int rows, int C, int64_t count, float eps, float decay, float* mean,
+                               float* rstd, float* mmean, float* mvar, mbx_stream_t stream) {
+  if (!part || !mean || !rstd || rows <= 0 || C <= 0 || count <= 0) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, mbx_s(stream), part, rows, C,
+                     1.0 / (double)count, eps, decay, mean, rstd, mmean, mvar);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_fold(const float* mm, const float* mv, const float* beta, float eps, int C, float* scale,
+                           float* shift, mbx_stream_t stream) {
+  if (!mm || !mv || !scale || !shift || C <= 0) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + kT - 1) / kT), dim3(kT), 0, mbx_s(stream), mm, mv, beta, eps, C, scale, shift);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_apply(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
+                            int relu, void* a, int ld_a, mbx_stream_t stream) {
+  if (!y || !a || !mean || !rstd || !beta || M <= 0 || C <= 0 || C % 8 || ld_a % 8 || !al16(y) || !al16(a))
+    return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)y, (long long)M, C,
+                     mean, rstd, beta, relu, (us)a, ld_a);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_rows(int64_t M, int C) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048) return MBX_ERR_INVALID_ARG;
+  return bn_bwd_geom(M, C).rows;
+}
+
+extern "C" int mbx_bn_bwd_reduce(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
+                                 int C, const float* mean, const float* rstd, float* partial, mbx_stream_t stream) {
+  if (!da || !y || !mean || !rstd || !partial || (relu && !a) || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || (relu && ld_a % 8))
+    return MBX_ERR_INVALID_ARG;
+  if (C > 2048) return MBX_ERR_UNSUPPORTED;
+  if (!al16(da) || !al16(y) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
+  const BnBwdGeom g = bn_bwd_geom(M, C);
+  MBX_ENTER();
+  const size_t lds = (size_t)g.rows_per_iter * g.C8 * 16 * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.rows), dim3(kT), lds, mbx_s(stream), (cus)da, ld_da, (cus)a, ld_a, relu,
+                     (cus)y, (long long)M, C, mean, rstd, g.rows_per_iter, g.rpb, partial);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_t M, float* dbeta, float* m12,
+                                   mbx_stream_t stream) {
+  if (!partial || !m12 || rows <= 0 || C <= 0 || M <= 0) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, mbx_s(stream), partial, rows, C,
+                     1.0 / (double)M, dbeta, m12);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
+                                int C, const float* mean, const float* rstd, const float* m12, void* dy,
+                                mbx_stream_t stream) {
+  if (!da || !y || !mean || !rstd || !m12 || !dy || (relu && !a) || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || (relu && ld_a % 8))
+    return MBX_ERR_INVALID_ARG;
+  if (!al16(da) || !al16(y) || !al16(dy) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)da, ld_da, (cus)a,
+                     ld_a, relu, (cus)y, (long long)M, C, mean, rstd, m12, (us)dy);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+static int pool_args_ok(const void* x, int ldx, const void* y, int ldy, int N, int H, int W, int C, int k, int Ho, int Wo) {
+  return x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && k > 0 && k < 16 &&
+         Ho > 0 && Wo > 0 && al16(x) && al16(y);
+}
+
+extern "C" int mbx_maxpool_fwd(const void* x, int64_t xs, int ldx, int N, int H, int W, int C, int k, int stride, void* y,
+                               int64_t ys, int ldy, int Ho, int Wo, uint8_t* argmax, mbx_stream_t stream) {
+  if (!pool_args_ok(x, ldx, y, ldy, N, H, W, C, k, Ho, Wo) || stride < 1) return MBX_ERR_INVALID_ARG;
+  if ((Ho - 1) * stride + k > H || (Wo - 1) * stride + k > W) return MBX_ERR_INVALID_ARG;   // VALID only
+  MBX_ENTER();
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                     (cus)x, (long long)xs, ldx, N, H, W, C, k, stride, (us)y, (long long)ys, ldy, Ho, Wo, argmax);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_maxpool_bwd(const void* dy, int64_t dys, int ld_dy, const uint8_t* argmax, int N, int H, int W, int C,
+                               int k, int stride, int Ho, int Wo, void* dx, int64_t dxs, int ld_dx, int accumulate,
+                               mbx_stream_t stream) {
+  if (!pool_args_ok(dy, ld_dy, dx, ld_dx, N, H, W, C, k, Ho, Wo) || !argmax || stride < 1) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                     (cus)dy, (long long)dys, ld_dy, argmax, N, H, W, C, k, stride, Ho, Wo, (us)dx, (long long)dxs, ld_dx,
+                     accumulate);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_avgpool_fwd(const void* x, int64_t xs, int ldx, int N, int H, int W, int C, int k, int pad, void* y,
+                               int64_t ys, int ldy, int Ho, int Wo, mbx_stream_t stream) {
+  if (!pool_args_ok(x, ldx, y, ldy, N, H, W, C, k, Ho, Wo) || pad < 0 || pad >= k) return MBX_ERR_INVALID_ARG;
+  if (Ho != H + 2 * pad - k + 1 || Wo != W + 2 * pad - k + 1) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                     (cus)x, (long long)xs, ldx, N, H, W, C, k, pad, (us)y, (long long)ys, ldy, Ho, Wo);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_avgpool_bwd(const void* dy, int64_t dys, int ld_dy, int N, int H, int W, int C, int k, int pad, int Ho,
+                               int Wo, void* dx, int64_t dxs, int ld_dx, int accumulate, mbx_stream_t stream) {
+  if (!pool_args_ok(dy, ld_dy, dx, ld_dx, N, H, W, C, k, Ho, Wo) || pad < 0 || pad >= k) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                     (cus)dy, (long long)dys, ld_dy, N, H, W, C, k, pad, Ho, Wo, (us)dx, (long long)dxs, ld_dx, accumulate);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_relu_mask(void* g, int ld_g, const void* a, int ld_a, int64_t M, int C, mbx_stream_t stream) {
+  if (!g || !a || M <= 0 || C <= 0 || C % 8 || ld_g % 8 || ld_a % 8 || !al16(g) || !al16(a)) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (us)g, ld_g, (cus)a, ld_a,
+                     (long long)M, C);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_pack_input(const float* img, int64_t pixels, void* out, mbx_stream_t stream) {
+  if (!img || !out || pixels <= 0 || !al16(out)) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(pixels)), dim3(kT), 0, mbx_s(stream), img, (long long)pixels, (us)out);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_head_gather(const float* h, int ld_h, int N, int cells, int k, int P, int off, float* locs,
+                               float* logits, mbx_stream_t stream) {
+  if (!h || !locs || !logits || N <= 0 || cells <= 0 || k <= 0 || ld_h < 5 * k || off < 0 || off + cells * k > P)
+    return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(head_gather_kernel, dim3(grid_for((long long)N * cells * k)), dim3(kT), 0, mbx_s(stream), h, ld_h, N,
+                     cells, k, P, off, locs, logits);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_head_scatter(const float* d_locs, const float* d_logits, int N, int cells, int k, int P, int off, void* g,
+                                int ld_g, mbx_stream_t stream) {
+  if (!d_locs || !d_logits || !g || N <= 0 || cells <= 0 || k <= 0 || ld_g < 5 * k || off < 0 || off + cells * k > P)
+    return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(head_scatter_kernel, dim3(grid_for((long long)N * cells * ld_g)), dim3(kT), 0, mbx_s(stream), d_locs,
+                     d_logits, N, cells, k, P, off, (us)g, ld_g);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_filter_prepare(const void* w_bf16, void* w_dgrad, const mbx_filter_entry* table, int n_entries,
+                                  int total_blocks, mbx_stream_t stream) {
+  if (!w_bf16 || !w_dgrad || !table || n_entries <= 0 || total_blocks <= 0) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(filter_prepare_kernel, dim3(total_blocks), dim3(kT), 0, mbx_s(stream), (cus)w_bf16, (us)w_dgrad, table,
+                     n_entries);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* mom, float* ema, void* w_bf16, int64_t n,
+                                    float lr, float decay, float momentum, float eps, float wd, float ema_decay,
+                                    int trainable, float* reg_loss, mbx_stream_t stream) {
+  if (!w || n <= 0 || (trainable && (!g || !ms))) return MBX_ERR_INVALID_ARG;
+  if (trainable && momentum != 0.f && !mom) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(rmsprop_ema_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), w, g, ms, momentum != 0.f ? mom : nullptr,
+                     ema, (us)w_bf16, (long long)n, lr, decay, momentum, eps, wd, ema_decay, trainable, reg_loss);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, mbx_stream_t stream) {
+  if (!ema || !value || n <= 0) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), ema, value, (long long)n, ema_decay);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}

@@ -1,0 +1,651 @@
+"""The Multibox network on libmbx: Inception-ResNet-v2 backbone + detection heads
+(reference model.py:6-337) as a static schedule of HIP kernel launches.
+
+Design (MI355X-first, not a tracing compiler):
+  * the graph is built ONCE into two Python lists of pre-bound launches (forward, backward);
+    a step replays them on the current HIP stream, so the whole step can be captured into a
+    hipGraph (torch.cuda.graph) -- no allocation, no host sync inside;
+  * activations are NHWC bf16 channel-slice views of a few wide buffers: every tf.concat of
+    model.py is free, sibling 1x1 convs that read the same tensor run as ONE GEMM
+    (block35: N = 96, block17: 320, block8: 384, Mixed_5b: 208, Mixed_7a: 768);
+  * parameters live in flat fp32 buffers (weights+biases | betas | moving stats) so the
+    optimizer/EMA step is one launch per range and the data-parallel gradient all-reduce is a
+    handful of contiguous buckets.
+
+Variable names follow the slim scopes of the reference (model.py:87,142,202,207) so that a
+TF checkpoint can be mapped later.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .ops import View
+
+BN_EPS = 0.001           # train.py:96
+WEIGHT_DECAY = 0.00004   # train.py:104-105
+
+
+def _same_pad(n, k, s):
+    """TF 'SAME': out = ceil(n/s); extra padding goes to the bottom/right."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def _valid(n, k, s):
+    return (n - k) // s + 1, 0
+
+
+class ParamSpec:
+    """One reference variable group: conv weights (KRSC) [+ bias] [+ BN beta / moving stats]."""
+
+    def __init__(self, scope, K, R, S, Cin, bn, bias):
+        self.scope, self.K, self.R, self.S, self.Cin, self.bn, self.bias = scope, K, R, S, Cin, bn, bias
+
+
+class ConvOp:
+    """A (possibly fused) convolution with its normalisation/activation, forward and backward."""
+
+    def __init__(self, net, members, x: View, out: View, R, S, stride, pad_t, pad_l, kind, relu=True, skip=None,
+                 rscale=0.0, trainable=True, need_dx=True, head=None):
+        self.net, self.members, self.x, self.out = net, members, x, out
+        self.R, self.S, self.stride, self.pad_t, self.pad_l = R, S, stride, pad_t, pad_l
+        self.kind, self.relu, self.skip, self.rscale = kind, relu, skip, rscale       # kind: bn | frozen | residual | head
+        self.trainable, self.need_dx, self.head = trainable, need_dx, head
+        self.K = sum(m.K for m in members)
+        self.Cin = x.C
+        self.M = out.M
+        self.name = members[0].scope if len(members) == 1 else "+".join(m.scope for m in members)
+
+    # offsets into the flat parameter buffers are assigned by Net.finalize()
+    w_off = b_off = beta_off = dw_off = -1
+
+
+class Net:
+    def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
+                 bn_decay=0.9997):
+        assert mode in ("train", "infer")
+        self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
+        self.bn_decay = bn_decay
+        self.convs, self.fwd, self.bwd = [], [], []
+        self.grad_alias = {}       # id(activation buffer) -> gradient buffer
+        self.written = set()       # gradient regions already written in the backward pass (build time)
+        self.heads = []
+        self._bufs = []
+        self._build()
+        self._finalize(seed)
+
+    # ------------------------------------------------------------------ buffers
+    def alloc(self, H, W, Cc, dtype=torch.bfloat16, zero=False):
+        v = View.alloc(self.B, H, W, Cc, dtype=dtype, device=self.dev, zero=zero)
+        self._bufs.append(v.buf)
+        return v
+
+    def grad_of(self, v: View) -> View:
+        """Gradient view mirroring an activation view (same ld / channel offset)."""
+        key = id(v.buf)
+        if key not in self.grad_alias:
+            g = torch.zeros_like(v.buf)
+            self._bufs.append(g)
+            self.grad_alias[key] = g
+        return View(self.grad_alias[key], v.N, v.H, v.W, v.C, v.ld, v.ch_off, v.elem_size)
+
+    def share_grad(self, v: View, like: View):
+        """Make v's buffer use the same gradient buffer as `like`'s (identical shapes)."""
+        self.grad_alias[id(v.buf)] = self.grad_of(like).buf
+
+    # --------------------------------------------------------------- graph building
+    def _training_bn(self, is_head):
+        if self.mode == "infer":
+            return False
+        return is_head if self.fine_tune else True
+
+    def conv(self, members, x, out, kh, kw, stride=1, padding="SAME", kind=None, relu=True, skip=None, rscale=0.0,
+             is_head=False, need_dx=True, head=None):
+        """members: list of (scope, K).  Creates a ConvOp writing into `out`."""
+        fh = _same_pad if padding == "SAME" else _valid
+        Ho, pt = fh(x.H, kh, stride)
+        Wo, pl = fh(x.W, kw, stride)
+        assert (Ho, Wo) == (out.H, out.W), (members, Ho, Wo, out.H, out.W)
+        if kind is None:
+            kind = "bn" if self._training_bn(is_head) else "frozen"
+        trainable = self.mode == "train" and (is_head or not self.fine_tune)
+        specs = [ParamSpec(s, K, kh, kw, x.C, bn=kind in ("bn", "frozen"), bias=kind == "residual") for s, K in members]
+        op = ConvOp(self, specs, x, out, kh, kw, stride, pt, pl, kind, relu, skip, rscale, trainable,
+                    need_dx and trainable, head)
+        op.is_head = is_head
+        assert op.K == out.C or kind == "head", (op.name, op.K, out.C)
+        self.convs.append(op)
+        self.fwd.append(op)
+        return op
+
+    def _build(self):
+        B, S, k = self.B, self.S, self.k
+        P = "InceptionResnetV2/"
+        self.images = self.alloc(S, S, 8)                      # packed bf16 input (3 real channels)
+        s1, _ = _valid(S, 3, 2)
+        a1 = self.alloc(s1, s1, 32)
+        self.conv([(P + "Conv2d_1a_3x3", 32)], self.images, a1, 3, 3, 2, "VALID", need_dx=False)
+        s2 = s1 - 2
+        a2 = self.alloc(s2, s2, 32)
+        self.conv([(P + "Conv2d_2a_3x3", 32)], a1, a2, 3, 3, 1, "VALID")
+        a3 = self.alloc(s2, s2, 64)
+        self.conv([(P + "Conv2d_2b_3x3", 64)], a2, a3, 3, 3, 1, "SAME")
+        s3, _ = _valid(s2, 3, 2)
+        p3 = self.alloc(s3, s3, 64)
+        self.pool("max", a3, p3, 3, 2)
+        a4 = self.alloc(s3, s3, 80)
+        self.conv([(P + "Conv2d_3b_1x1", 80)], p3, a4, 1, 1, 1, "VALID")
+        s4 = s3 - 2
+        a5 = self.alloc(s4, s4, 192)
+        self.conv([(P + "Conv2d_4a_3x3", 192)], a4, a5, 3, 3, 1, "VALID")
+        s5, _ = _valid(s4, 3, 2)
+        t5 = self.alloc(s5, s5, 192)
+        self.pool("max", a5, t5, 3, 2)
+
+        # ---- Mixed_5b (model.py:120-141): [t1 48 | t2 64 | b0 96 | b1 64 | b2 96 | b3 64 | t2b 96]
+        Q = P + "Mixed_5b/"
+        z = self.alloc(s5, s5, 528)
+        self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 48), (Q + "Branch_2/Conv2d_0a_1x1", 64), (Q + "Branch_0/Conv2d_1x1", 96)],
+                  t5, z.slice(0, 208), 1, 1)
+        self.conv([(Q + "Branch_1/Conv2d_0b_5x5", 64)], z.slice(0, 48), z.slice(208, 64), 5, 5)
+        self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 96)], z.slice(48, 64), z.slice(432, 96), 3, 3)
+        self.conv([(Q + "Branch_2/Conv2d_0c_3x3", 96)], z.slice(432, 96), z.slice(272, 96), 3, 3)
+        p5 = self.alloc(s5, s5, 192)
+        self.pool("avg", t5, p5, 3, 1, pad=1)
+        self.conv([(Q + "Branch_3/Conv2d_0b_1x1", 64)], p5, z.slice(368, 64), 1, 1)
+        net = z.slice(112, 320)
+
+        # ---- 10 x block35 (model.py:6-24), scale 0.17
+        trunk0 = net
+        zg = None
+        for i in range(1, 11):
+            Q = P + "Repeat/block35_%d/" % i
+            z = self.alloc(s5, s5, 240)     # [t1 32 | t2 32 | b0 32 | b1 32 | b2 64 | b2a 48]
+            if zg is None:
+                zg = z
+            else:
+                self.share_grad(z, zg)
+            self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 32), (Q + "Branch_2/Conv2d_0a_1x1", 32), (Q + "Branch_0/Conv2d_1x1", 32)],
+                      net, z.slice(0, 96), 1, 1)
+            self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 32)], z.slice(0, 32), z.slice(96, 32), 3, 3)
+            self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 48)], z.slice(32, 32), z.slice(192, 48), 3, 3)
+            self.conv([(Q + "Branch_2/Conv2d_0c_3x3", 64)], z.slice(192, 48), z.slice(128, 64), 3, 3)
+            out = self.alloc(s5, s5, 320)
+            self.residual(Q + "Conv2d_1x1", z.slice(64, 128), net, out, 0.17, True, trunk0)
+            net = out
+
+        # ---- Mixed_6a (model.py:145-161): [b0 384 | b1 384 | pool 320]
+        Q = P + "Mixed_6a/"
+        s6, _ = _valid(s5, 3, 2)
+        o6 = self.alloc(s6, s6, 1088)
+        self.conv([(Q + "Branch_0/Conv2d_1a_3x3", 384)], net, o6.slice(0, 384), 3, 3, 2, "VALID")
+        t6a = self.alloc(s5, s5, 256)
+        self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 256)], net, t6a, 1, 1)
+        t6b = self.alloc(s5, s5, 256)
+        self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 256)], t6a, t6b, 3, 3)
+        self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 384)], t6b, o6.slice(384, 384), 3, 3, 2, "VALID")
+        self.pool("max", net, o6.slice(768, 320), 3, 2)
+        net = o6
+
+        # ---- 20 x block17 (model.py:27-44), scale 0.10
+        trunk0, zg = net, None
+        for i in range(1, 21):
+            Q = P + "Repeat_1/block17_%d/" % i
+            z = self.alloc(s6, s6, 672)     # [t1 128 | b0 192 | b1_2 192 | b1_1 160]
+            if zg is None:
+                zg = z
+            else:
+                self.share_grad(z, zg)
+            self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 128), (Q + "Branch_0/Conv2d_1x1", 192)], net, z.slice(0, 320), 1, 1)
+            self.conv([(Q + "Branch_1/Conv2d_0b_1x7", 160)], z.slice(0, 128), z.slice(512, 160), 1, 7)
+            self.conv([(Q + "Branch_1/Conv2d_0c_7x1", 192)], z.slice(512, 160), z.slice(320, 192), 7, 1)
+            out = self.alloc(s6, s6, 1088)
+            self.residual(Q + "Conv2d_1x1", z.slice(128, 384), net, out, 0.10, True, trunk0)
+            net = out
+
+        # ---- Mixed_7a (model.py:164-185): [b0 384 | b1 288 | b2 320 | pool 1088]
+        Q = P + "Mixed_7a/"
+        s7, _ = _valid(s6, 3, 2)
+        o7 = self.alloc(s7, s7, 2080)
+        t7 = self.alloc(s6, s6, 1056)       # [t0 256 | t1 256 | t2 256 | t2b 288]
+        self.conv([(Q + "Branch_0/Conv2d_0a_1x1", 256), (Q + "Branch_1/Conv2d_0a_1x1", 256), (Q + "Branch_2/Conv2d_0a_1x1", 256)],
+                  net, t7.slice(0, 768), 1, 1)
+        self.conv([(Q + "Branch_0/Conv2d_1a_3x3", 384)], t7.slice(0, 256), o7.slice(0, 384), 3, 3, 2, "VALID")
+        self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 288)], t7.slice(256, 256), o7.slice(384, 288), 3, 3, 2, "VALID")
+        self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 288)], t7.slice(512, 256), t7.slice(768, 288), 3, 3)
+        self.conv([(Q + "Branch_2/Conv2d_1a_3x3", 320)], t7.slice(768, 288), o7.slice(672, 320), 3, 3, 2, "VALID")
+        self.pool("max", net, o7.slice(992, 1088), 3, 2)
+        net = o7
+
+        # ---- 9 x block8 (scale 0.20) + Block8 without relu at scale 1.0 (model.py:187-188)
+        trunk0, zg = net, None
+        for i in range(1, 11):
+            Q = P + ("Repeat_2/block8_%d/" % i if i < 10 else "Block8/")
+            z = self.alloc(s7, s7, 864)     # [t1 192 | b0 192 | b1_2 256 | b1_1 224]
+            if zg is None:
+                zg = z
+            else:
+                self.share_grad(z, zg)
+            self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 192), (Q + "Branch_0/Conv2d_1x1", 192)], net, z.slice(0, 384), 1, 1)
+            self.conv([(Q + "Branch_1/Conv2d_0b_1x3", 224)], z.slice(0, 192), z.slice(640, 224), 1, 3)
+            self.conv([(Q + "Branch_1/Conv2d_0c_3x1", 256)], z.slice(640, 224), z.slice(384, 256), 3, 1)
+            out = self.alloc(s7, s7, 2080)
+            self.residual(Q + "Conv2d_1x1", z.slice(192, 448), net, out, 0.20 if i < 10 else 1.0, i < 10, trunk0)
+            net = out
+        feat = self.alloc(s7, s7, 1536)
+        self.conv([(P + "Conv2d_7b_1x1", 1536)], net, feat, 1, 1)
+        self.features = feat
+
+        # ------------------------------------------------------- detection heads (model.py:198-324)
+        H = "Multibox/"
+        f = s7
+        grids = []
+        h8 = self.alloc(f, f, 192)
+        self.conv([(H + "8x8/Conv", 96)], feat, h8.slice(0, 96), 1, 1, is_head=True, need_dx=not self.fine_tune)
+        self.conv([(H + "8x8/Conv_1", 96)], h8.slice(0, 96), h8.slice(96, 96), 3, 3, is_head=True)
+        grids.append((H + "8x8/", h8.slice(96, 96), f, k))
+        h6a = self.alloc(f, f, 96)
+        self.conv([(H + "6x6/Conv", 96)], feat, h6a, 3, 3, is_head=True, need_dx=not self.fine_tune)
+        h6b = self.alloc(f - 2, f - 2, 96)
+        self.conv([(H + "6x6/Conv_1", 96)], h6a, h6b, 3, 3, 1, "VALID", is_head=True)
+        grids.append((H + "6x6/", h6b, f - 2, k))
+        f4 = -(-f // 2)
+        n4 = self.alloc(f4, f4, 256)
+        self.conv([(H + "Conv", 256)], feat, n4, 3, 3, 2, "SAME", is_head=True, need_dx=not self.fine_tune)
+        h4 = self.alloc(f4, f4, 128)
+        self.conv([(H + "4x4/Conv", 128)], n4, h4, 3, 3, is_head=True)
+        grids.append((H + "4x4/", h4, f4, k))
+        h32 = self.alloc(f4, f4, 256)
+        self.conv([(H + "3x3/Conv", 128), (H + "2x2/Conv", 128)], n4, h32, 1, 1, is_head=True)
+        h3 = self.alloc(f4 - 1, f4 - 1, 96)
+        self.conv([(H + "3x3/Conv_1", 96)], h32.slice(0, 128), h3, 2, 2, 1, "VALID", is_head=True)
+        grids.append((H + "3x3/", h3, f4 - 1, k))
+        h2 = self.alloc(f4 - 2, f4 - 2, 96)
+        self.conv([(H + "2x2/Conv_1", 96)], h32.slice(128, 128), h2, 3, 3, 1, "VALID", is_head=True)
+        grids.append((H + "2x2/", h2, f4 - 2, k))
+        f1 = f - 7
+        g1 = self.alloc(f1, f1, 1536)
+        self.pool("avg", feat, g1, 8, 1, pad=0)
+        grids.append((H + "1x1/", g1, f1, 1))
+        # prediction index: off_g + (i*g + j)*k + a  (model.py:296-319)
+        self.P = sum(g * g * kk for _, _, g, kk in grids)
+        self.grid_sizes = [g for _, _, g, _ in grids]
+        self.locs = torch.zeros((B, self.P, 4), dtype=torch.float32, device=self.dev)
+        self.logits = torch.zeros((B, self.P), dtype=torch.float32, device=self.dev)
+        self.d_locs = torch.zeros_like(self.locs)
+        self.d_logits = torch.zeros_like(self.logits)
+        off = 0
+        for scope, src, g, kk in grids:
+            o = self.alloc(g, g, 32, dtype=torch.float32, zero=True)        # [M_g, 32] f32: 4k locs | k logits
+            if scope.endswith("1x1/"):
+                names = [(scope + "Conv", 4), (scope + "Conv_1", 1)]
+            elif scope.endswith("4x4/"):
+                names = [(scope + "Conv_1", 4 * kk), (scope + "Conv_2", kk)]
+            else:
+                names = [(scope + "Conv_2", 4 * kk), (scope + "Conv_3", kk)]
+            op = self.conv(names, src, o, 1, 1, kind="head", relu=False, is_head=True, head=(g * g, kk, off),
+                           need_dx=not (self.fine_tune and src.buf is feat.buf))
+            self.heads.append(op)
+            off += g * g * kk
+
+    def residual(self, scope, mixed, skip, out, scale, relu, trunk0):
+        op = self.conv([(scope, out.C)], mixed, out, 1, 1, kind="residual", relu=relu, skip=skip, rscale=scale)
+        # the gradient of every trunk tensor of a residual stage lives in ONE buffer, updated in place
+        op.trunk0 = trunk0
+        return op
+
+    def pool(self, kind, x, out, ksz, stride, pad=0):
+        self.fwd.append(PoolOp(self, kind, x, out, ksz, stride, pad))
+
+    # ------------------------------------------------------------- parameters
+    def _finalize(self, seed):
+        dev = self.dev
+        # resolve trunk gradient aliases (all trunk tensors of a stage share trunk0's gradient view)
+        self.trunk_grad = {}
+        for op in self.convs:
+            if op.kind == "residual":
+                for v in (op.skip, op.out):
+                    if v.buf is not op.trunk0.buf:
+                        self.trunk_grad[id(v.buf)] = op.trunk0
+
+        # flat parameter layout: W = all filters (+ biases), 8-element aligned; Bt = betas; stats
+        w_off = bt_off = 0
+        self.param_index = {}
+        for op in self.convs:
+            op.w_off = w_off
+            ktot = op.R * op.S * op.Cin
+            row = 0
+            for m in op.members:
+                # the stem filter is stored with C_in padded 3 -> 8 (zeros); the variable is [K,R,S,3]
+                real_c = 3 if op.x is self.images else m.Cin
+                self.param_index[m.scope + "/weights"] = ("W", w_off + row * ktot, (m.K, m.R, m.S, real_c), m.Cin)
+                row += m.K
+            w_off += op.K * ktot
+            w_off = (w_off + 7) // 8 * 8
+            if op.kind == "residual":
+                op.b_off = w_off
+                self.param_index[op.members[0].scope + "/biases"] = ("W", w_off, (op.K,), None)
+                w_off += (op.K + 7) // 8 * 8
+            if op.kind in ("bn", "frozen"):
+                op.beta_off = bt_off
+                ch = 0
+                for m in op.members:
+                    self.param_index[m.scope + "/BatchNorm/beta"] = ("Bt", bt_off + ch, (m.K,), None)
+                    self.param_index[m.scope + "/BatchNorm/moving_mean"] = ("MM", bt_off + ch, (m.K,), None)
+                    self.param_index[m.scope + "/BatchNorm/moving_variance"] = ("MV", bt_off + ch, (m.K,), None)
+                    ch += m.K
+                bt_off += (op.K + 7) // 8 * 8
+        self.nW, self.nBt = w_off, bt_off
+        first_head = next(op for op in self.convs if op.is_head)
+        self.head_w_start, self.head_bt_start = first_head.w_off, first_head.beta_off
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.W = torch.zeros(self.nW, **f32)
+        self.Wb = torch.zeros(self.nW, dtype=torch.bfloat16, device=dev)
+        self.Bt = torch.zeros(self.nBt, **f32)
+        self.MM = torch.zeros(self.nBt, **f32)
+        self.MV = torch.ones(self.nBt, **f32)
+        self.bn_mean = torch.zeros(self.nBt, **f32)
+        self.bn_rstd = torch.ones(self.nBt, **f32)
+        self.bn_scale = torch.ones(self.nBt, **f32)     # folded (frozen) BN
+        self.bn_shift = torch.zeros(self.nBt, **f32)
+        self.init_weights(seed)
+        if self.mode == "train":
+            self.Wg = torch.zeros(self.nW, **f32)
+            self.Btg = torch.zeros(self.nBt, **f32)
+        self._alloc_scratch()
+        self._build_backward()
+
+    def init_weights(self, seed):
+        """slim defaults (un-vendored): Xavier-uniform filters, zero biases/betas, moving mean 0 / variance 1."""
+        gen = torch.Generator().manual_seed(seed)
+        W = torch.zeros(self.nW, dtype=torch.float32)
+        for name, (buf, off, shape, cpad) in self.param_index.items():
+            if buf == "W" and name.endswith("/weights"):
+                K, R, S_, Cc = shape
+                lim = math.sqrt(6.0 / (R * S_ * Cc + R * S_ * K))
+                n = K * R * S_ * Cc
+                v = ((torch.rand(n, generator=gen) * 2 - 1) * lim).reshape(shape)
+                W[off:off + K * R * S_ * cpad].reshape(K, R, S_, cpad)[..., :Cc] = v
+        self.W.copy_(W)
+        self.Wb.copy_(self.W.to(torch.bfloat16))
+
+    def get_param(self, name, kind="value"):
+        """View of a reference variable inside the flat buffers (kind: value | grad)."""
+        buf, off, shape, cpad = self.param_index[name]
+        t = {"W": self.W, "Bt": self.Bt, "MM": self.MM, "MV": self.MV}[buf] if kind == "value" else \
+            {"W": self.Wg, "Bt": self.Btg}[buf]
+        if cpad is not None and cpad != shape[-1]:
+            K, R, S_, Cc = shape
+            return t[off:off + K * R * S_ * cpad].reshape(K, R, S_, cpad)[..., :Cc]
+        n = int(np.prod(shape))
+        return t[off:off + n].reshape(shape)
+
+    def set_param(self, name, value):
+        self.get_param(name).copy_(torch.as_tensor(value, dtype=torch.float32).reshape(self.get_param(name).shape))
+
+    def refresh_bf16(self):
+        self.Wb.copy_(self.W.to(torch.bfloat16))
+
+    def _alloc_scratch(self):
+        dev = self.dev
+        max_y = max_stats = max_bwd = 0
+        self.y_tmp = {}
+        l = _lib.lib()
+        for op in self.convs:
+            if op.kind == "bn":
+                op.y = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)      # pre-BN output, kept for backward
+                self._bufs.append(op.y)
+                d = self._desc(op, View(op.y, op.out.N, op.out.H, op.out.W, op.K))
+                max_stats = max(max_stats, ops.conv_stats_rows(d) * op.K * 2)
+                if op.trainable:
+                    max_y = max(max_y, op.M * op.K)
+                    max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, op.K) * op.K * 2)
+        self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
+        self.dy_scratch = torch.zeros(max(max_y, 8), dtype=torch.bfloat16, device=dev)
+        self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
+        self.m12 = torch.zeros(2 * 2048, dtype=torch.float32, device=dev)
+        self.reg_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ descriptors
+    def _w(self, op):
+        return self.Wb[op.w_off:]
+
+    def _desc(self, op, y: View, **kw):
+        return ops.make_desc(op.x, self._w(op), op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, y, **kw)
+
+    def _sl(self, t, off, n):
+        return t[off:off + n]
+
+    def _build_forward_launches(self):
+        """Pre-bind every forward launch; returns a list of zero-argument callables."""
+        L = []
+        l = _lib.lib()
+        st = lambda: torch.cuda.current_stream().cuda_stream
+        for op in self.fwd:
+            if isinstance(op, PoolOp):
+                L.append(op.forward)
+                continue
+            if op.kind == "bn":
+                yv = View(op.y, op.out.N, op.out.H, op.out.W, op.K)
+                d = self._desc(op, yv, stats=self.stats_scratch)
+                rows = ops.conv_stats_rows(d)
+                mean, rstd = self._sl(self.bn_mean, op.beta_off, op.K), self._sl(self.bn_rstd, op.beta_off, op.K)
+                mm, mv = self._sl(self.MM, op.beta_off, op.K), self._sl(self.MV, op.beta_off, op.K)
+                beta = self._sl(self.Bt, op.beta_off, op.K)
+                out = op.out
+
+                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out):
+                    s = st()
+                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, self.bn_decay,
+                                                 mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_finalize")
+                    _lib.check(l.mbx_bn_apply(op.y.data_ptr(), op.M, op.K, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                                              int(op.relu), out.ptr, out.ld, s), "bn_apply")
+                L.append(run)
+            elif op.kind == "frozen":
+                d = self._desc(op, op.out, epilogue=ops.EPI_AFFINE, relu=op.relu,
+                               scale=self._sl(self.bn_scale, op.beta_off, op.K), shift=self._sl(self.bn_shift, op.beta_off, op.K))
+                L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
+            elif op.kind == "residual":
+                d = self._desc(op, op.out, epilogue=ops.EPI_RESIDUAL, relu=op.relu, shift=self._sl(self.W, op.b_off, op.K),
+                               skip=op.skip, rscale=op.rscale)
+                L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
+            elif op.kind == "head":
+                d = self._desc(op, op.out, epilogue=ops.EPI_STORE_F32)
+                cells, kk, off = op.head
+
+                def run(d=d, op=op, cells=cells, kk=kk, off=off):
+                    s = st()
+                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    _lib.check(l.mbx_head_gather(op.out.buf.data_ptr(), 32, self.B, cells, kk, self.P, off,
+                                                 self.locs.data_ptr(), self.logits.data_ptr(), s), "head_gather")
+                L.append(run)
+        return L
+
+    # ------------------------------------------------------------------- backward
+    def _gview(self, v: View) -> View:
+        """Gradient view for an activation view (trunk tensors of a residual stage share one)."""
+        t0 = self.trunk_grad.get(id(v.buf))
+        if t0 is not None:
+            g = self.grad_of(t0)
+            return View(g.buf, v.N, v.H, v.W, v.C, g.ld, g.ch_off + v.ch_off, 2)
+        return self.grad_of(v)
+
+    def _claim(self, g: View):
+        """Build-time bookkeeping: returns accumulate flag for a write into gradient region g."""
+        key = (id(g.buf), g.ch_off, g.C)
+        acc = key in self.written
+        self.written.add(key)
+        return int(acc)
+
+    def _build_backward(self):
+        if self.mode != "train":
+            self.fwd_launches = self._build_forward_launches()
+            self.bwd_launches = []
+            return
+        l = _lib.lib()
+        st = lambda: torch.cuda.current_stream().cuda_stream
+        # dgrad filter copies ([C][R][S][Kpad], flipped): table for mbx_filter_prepare
+        entries, d_off, blocks = [], 0, 0
+        for op in self.convs:
+            if op.need_dx:
+                kpad = (op.K + 7) // 8 * 8
+                e = _lib.FilterEntry(op.w_off, d_off, op.K, op.R, op.S, op.Cin, kpad, blocks)
+                op.dgrad_off, op.kpad = d_off, kpad
+                n = op.Cin * op.R * op.S * kpad
+                d_off += (n + 7) // 8 * 8
+                blocks += (n + 2047) // 2048
+                entries.append(e)
+        self.Wd = torch.zeros(max(d_off, 8), dtype=torch.bfloat16, device=self.dev)
+        arr = (_lib.FilterEntry * len(entries))(*entries)
+        raw = np.frombuffer(C.string_at(C.addressof(arr), C.sizeof(arr)), dtype=np.uint8).copy()
+        self.filter_table = torch.from_numpy(raw).to(self.dev)
+        self.filter_blocks, self.filter_entries = blocks, len(entries)
+
+        L = []
+        for op in reversed(self.fwd):
+            if isinstance(op, PoolOp):
+                if op.needs_backward():
+                    gx = self._gview(op.x)
+                    acc = self._claim(gx)
+                    L.append(op.make_backward(self._gview(op.out), gx, acc))
+                continue
+            if not op.trainable:
+                continue
+            K, M = op.K, op.M
+            dw = self._sl(self.Wg, op.w_off, K * op.R * op.S * op.Cin)
+            wdesc = ops.make_desc(op.x, None, K, op.R, op.S, op.stride, op.pad_t, op.pad_l, View(self.dy_scratch, op.out.N, op.out.H, op.out.W, 8))
+            wdesc.C_out = K
+            if op.kind == "head":
+                cells, kk, off = op.head
+                g = View(torch.zeros((M, 32), dtype=torch.bfloat16, device=self.dev), op.out.N, op.out.H, op.out.W, 32)
+                self._bufs.append(g.buf)
+                dyv, scale, db = g, 1.0, None
+                pre = lambda s, g=g, cells=cells, kk=kk, off=off: _lib.check(
+                    l.mbx_head_scatter(self.d_locs.data_ptr(), self.d_logits.data_ptr(), self.B, cells, kk, self.P, off,
+                                       g.buf.data_ptr(), 32, s), "head_scatter")
+                dy_C = op.kpad if op.need_dx else 32
+            elif op.kind == "residual":
+                gout = self._gview(op.out)          # == gradient of skip (same trunk buffer, in place)
+                self._claim(self._gview(op.skip))
+                zb = id(self.grad_of(op.x).buf)     # per-stage branch gradient buffer is reused by every block
+                self.written = {k for k in self.written if k[0] != zb}
+                dyv, scale, db = gout, op.rscale, self._sl(self.Wg, op.b_off, K)
+                if op.relu:
+                    pre = lambda s, gout=gout, op=op: _lib.check(
+                        l.mbx_relu_mask(gout.ptr, gout.ld, op.out.ptr, op.out.ld, op.M, op.K, s), "relu_mask")
+                else:
+                    pre = None
+                dy_C = K
+            else:   # bn
+                da = self._gview(op.out)
+                dyv = View(self.dy_scratch, op.out.N, op.out.H, op.out.W, K)
+                mean, rstd = self._sl(self.bn_mean, op.beta_off, K), self._sl(self.bn_rstd, op.beta_off, K)
+                dbeta = self._sl(self.Btg, op.beta_off, K)
+                rows = l.mbx_bn_bwd_rows(M, K)
+                scale, db, dy_C = 1.0, None, K
+
+                def pre(s, op=op, da=da, mean=mean, rstd=rstd, dbeta=dbeta, rows=rows, K=K, M=M):
+                    a = op.out
+                    _lib.check(l.mbx_bn_bwd_reduce(da.ptr, da.ld, a.ptr, a.ld, int(op.relu), op.y.data_ptr(), M, K,
+                                                   mean.data_ptr(), rstd.data_ptr(), self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce")
+                    _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, K, M, dbeta.data_ptr(),
+                                                     self.m12.data_ptr(), s), "bn_bwd_finalize")
+                    _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, a.ptr, a.ld, int(op.relu), op.y.data_ptr(), M, K,
+                                                  mean.data_ptr(), rstd.data_ptr(), self.m12.data_ptr(),
+                                                  self.dy_scratch.data_ptr(), s), "bn_bwd_apply")
+            ddesc = None
+            if op.need_dx:
+                gx = self._gview(op.x)
+                acc = self._claim(gx)
+                dyin = View(dyv.buf, dyv.N, dyv.H, dyv.W, op.kpad, dyv.ld, dyv.ch_off, 2)
+                ddesc = ops.make_desc(dyin, self.Wd[op.dgrad_off:], op.Cin, op.R, op.S, op.stride,
+                                      op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
+                                      rscale=(scale if scale != 1.0 else 0.0))
+
+            def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
+                s = st()
+                if pre is not None:
+                    pre(s)
+                _lib.check(l.mbx_conv_wgrad_scaled(C.byref(wdesc), dyv.ptr, dyv.img_stride, dyv.ld, float(scale),
+                                                   dw.data_ptr(), None if db is None else db.data_ptr(), s), "wgrad " + op.name)
+                if ddesc is not None:
+                    _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
+            L.append(run)
+        self.bwd_launches = L
+        self.fwd_launches = self._build_forward_launches()
+
+    # --------------------------------------------------------------------- running
+    def prepare_filters(self):
+        """Refresh the dgrad filter copies from the bf16 filters (once per step, after the update)."""
+        if self.mode == "train" and self.filter_entries:
+            _lib.check(_lib.lib().mbx_filter_prepare(self.Wb.data_ptr(), self.Wd.data_ptr(), self.filter_table.data_ptr(),
+                                                     self.filter_entries, self.filter_blocks,
+                                                     torch.cuda.current_stream().cuda_stream), "filter_prepare")
+
+    def fold_bn(self):
+        """Frozen BN -> per-channel scale/shift for the conv epilogue (detect.py:313-326)."""
+        _lib.check(_lib.lib().mbx_bn_fold(self.MM.data_ptr(), self.MV.data_ptr(), self.Bt.data_ptr(), BN_EPS, self.nBt,
+                                          self.bn_scale.data_ptr(), self.bn_shift.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "bn_fold")
+
+    def set_input(self, images_f32):
+        """images [B,S,S,3] float32 in [-1,1] (inputs.py:350-351) -> packed bf16 NHWC8."""
+        assert images_f32.shape == (self.B, self.S, self.S, 3) and images_f32.dtype == torch.float32
+        _lib.check(_lib.lib().mbx_pack_input(images_f32.contiguous().data_ptr(), self.B * self.S * self.S,
+                                             self.images.buf.data_ptr(), torch.cuda.current_stream().cuda_stream), "pack_input")
+
+    def forward(self):
+        for f in self.fwd_launches:
+            f()
+        return self.locs, self.logits
+
+    def zero_grads(self):
+        self.Wg.zero_()
+        self.Btg.zero_()
+
+    def backward(self):
+        """d_locs / d_logits must hold the loss gradients; fills Wg / Btg."""
+        for f in self.bwd_launches:
+            f()
+
+
+class PoolOp:
+    def __init__(self, net, kind, x: View, out: View, k, stride, pad):
+        self.net, self.kind, self.x, self.out, self.k, self.stride, self.pad = net, kind, x, out, k, stride, pad
+        self.argmax = None
+        if kind == "max" and net.mode == "train" and not net.fine_tune:
+            self.argmax = torch.zeros((out.N, out.H, out.W, out.C), dtype=torch.uint8, device=net.dev)
+
+    def needs_backward(self):
+        return self.net.mode == "train" and not self.net.fine_tune
+
+    def forward(self):
+        l, x, y = _lib.lib(), self.x, self.out
+        s = torch.cuda.current_stream().cuda_stream
+        if self.kind == "max":
+            _lib.check(l.mbx_maxpool_fwd(x.ptr, x.img_stride, x.ld, x.N, x.H, x.W, x.C, self.k, self.stride, y.ptr,
+                                         y.img_stride, y.ld, y.H, y.W, None if self.argmax is None else self.argmax.data_ptr(), s),
+                       "maxpool_fwd")
+        else:
+            _lib.check(l.mbx_avgpool_fwd(x.ptr, x.img_stride, x.ld, x.N, x.H, x.W, x.C, self.k, self.pad, y.ptr,
+                                         y.img_stride, y.ld, y.H, y.W, s), "avgpool_fwd")
+
+    def make_backward(self, gy: View, gx: View, acc):
+        l, x, y = _lib.lib(), self.x, self.out
+
+        def run():
+            s = torch.cuda.current_stream().cuda_stream
+            if self.kind == "max":
+                _lib.check(l.mbx_maxpool_bwd(gy.ptr, gy.img_stride, gy.ld, self.argmax.data_ptr(), x.N, x.H, x.W, x.C, self.k,
+                                             self.stride, y.H, y.W, gx.ptr, gx.img_stride, gx.ld, acc, s), "maxpool_bwd")
+            else:
+                _lib.check(l.mbx_avgpool_bwd(gy.ptr, gy.img_stride, gy.ld, x.N, x.H, x.W, x.C, self.k, self.pad, y.H, y.W,
+                                             gx.ptr, gx.img_stride, gx.ld, acc, s), "avgpool_bwd")
+        return run

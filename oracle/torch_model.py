@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU float32 restatement of the reference network.
+
+Follows /root/reference/model.py:6-337 layer by layer (block35/17/8, inception_resnet_v2,
+build_detection_heads) with the slim/TF-0.11 semantics the reference relies on but does not
+vendor: 'SAME' padding puts the odd pixel at the bottom/right, avg_pool SAME divides by the
+number of valid taps, batch_norm has beta only (scale=False), epsilon 0.001, biased batch
+variance (train.py:94-99).  "parity unpinned" against TF itself (TF 0.11 cannot run here);
+pinned structurally: 646/904 predictions, parameter counts, head flatten order.
+
+Parameters come in a dict keyed by the slim variable names (".../weights" KRSC float32,
+".../biases", ".../BatchNorm/beta|moving_mean|moving_variance").  ``q`` optionally rounds
+tensors where the HIP engine stores bf16, so the two can be compared tightly.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 0.001
+
+
+def q_bf16(t):
+    """Round to bf16 with a straight-through gradient."""
+    return t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+
+
+def _same(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+class Model:
+    def __init__(self, params, k=5, bn_training=True, heads_bn_training=None, q=None, bn_decay=0.9997):
+        self.P, self.k, self.q = params, k, (q or (lambda t: t))
+        self.bn_training = bn_training
+        self.heads_bn_training = bn_training if heads_bn_training is None else heads_bn_training
+        self.bn_decay = bn_decay
+        self.new_moving = {}
+        self.endpoints = {}
+        self._in_heads = False
+
+    # slim.conv2d (+ batch_norm + relu)
+    def conv(self, x, scope, ksize, stride=1, padding="SAME", bn=True, relu=True, bias=False):
+        w = self.P[scope + "/weights"]                       # [K,R,S,C]
+        kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+        assert w.shape[1:3] == (kh, kw), (scope, w.shape)
+        if padding == "SAME":
+            pt, pb = _same(x.shape[2], kh, stride)
+            pl, pr = _same(x.shape[3], kw, stride)
+            x = F.pad(x, (pl, pr, pt, pb))
+        y = F.conv2d(x, w.permute(0, 3, 1, 2), stride=stride)
+        if bias:
+            y = y + self.P[scope + "/biases"].view(1, -1, 1, 1)
+        if bn:
+            y = self.q(y)
+            beta = self.P[scope + "/BatchNorm/beta"].view(1, -1, 1, 1)
+            training = self.heads_bn_training if self._in_heads else self.bn_training
+            if training:
+                mean = y.mean((0, 2, 3))
+                var = y.var((0, 2, 3), unbiased=False)
+                mm, mv = self.P[scope + "/BatchNorm/moving_mean"], self.P[scope + "/BatchNorm/moving_variance"]
+                self.new_moving[scope] = ((mm - (1 - self.bn_decay) * (mm - mean)).detach(),
+                                          (mv - (1 - self.bn_decay) * (mv - var)).detach())
+            else:
+                mean, var = self.P[scope + "/BatchNorm/moving_mean"], self.P[scope + "/BatchNorm/moving_variance"]
+            y = (y - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + BN_EPS) + beta
+        if relu:
+            y = torch.relu(y)
+        if bn:
+            y = self.q(y)
+        return y
+
+    def block(self, net, s, scale, relu, kind):
+        """model.py:6-63."""
+        c = self.conv
+        if kind == 35:
+            b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
+            b1 = c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_3x3", 3)
+            b2 = c(c(c(net, s + "Branch_2/Conv2d_0a_1x1", 1), s + "Branch_2/Conv2d_0b_3x3", 3), s + "Branch_2/Conv2d_0c_3x3", 3)
+            mixed = torch.cat([b0, b1, b2], 1)
+        elif kind == 17:
+            b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
+            b1 = c(c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_1x7", (1, 7)), s + "Branch_1/Conv2d_0c_7x1", (7, 1))
+            mixed = torch.cat([b0, b1], 1)
+        else:
+            b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
+            b1 = c(c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_1x3", (1, 3)), s + "Branch_1/Conv2d_0c_3x1", (3, 1))
+            mixed = torch.cat([b0, b1], 1)
+        up = c(mixed, s + "Conv2d_1x1", 1, bn=False, relu=False, bias=True)
+        net = net + scale * up
+        if relu:
+            net = torch.relu(net)
+        return self.q(net)
+
+    @staticmethod
+    def avg_pool_same3(x):
+        """slim.avg_pool2d(3, stride 1, SAME): divisor = valid taps (model.py:134)."""
+        s = F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
+        return s
+
+    def backbone(self, x):
+        """model.py:67-196.  x [B,3,S,S]."""
+        c, P = self.conv, "InceptionResnetV2/"
+        net = c(x, P + "Conv2d_1a_3x3", 3, 2, "VALID")
+        net = c(net, P + "Conv2d_2a_3x3", 3, 1, "VALID")
+        net = c(net, P + "Conv2d_2b_3x3", 3)
+        net = F.max_pool2d(net, 3, 2)
+        net = c(net, P + "Conv2d_3b_1x1", 1, 1, "VALID")
+        net = c(net, P + "Conv2d_4a_3x3", 3, 1, "VALID")
+        net = F.max_pool2d(net, 3, 2)
+        self.endpoints["MaxPool_5a_3x3"] = net
+        Q = P + "Mixed_5b/"
+        b0 = c(net, Q + "Branch_0/Conv2d_1x1", 1)
+        b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_5x5", 5)
+        b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_0c_3x3", 3)
+        b3 = c(self.q(self.avg_pool_same3(net)), Q + "Branch_3/Conv2d_0b_1x1", 1)
+        net = torch.cat([b0, b1, b2, b3], 1)
+        self.endpoints["Mixed_5b"] = net
+        for i in range(1, 11):
+            net = self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)
+        self.endpoints["block35_10"] = net
+        Q = P + "Mixed_6a/"
+        b0 = c(net, Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
+        b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
+        net = torch.cat([b0, b1, F.max_pool2d(net, 3, 2)], 1)
+        self.endpoints["Mixed_6a"] = net
+        for i in range(1, 21):
+            net = self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)
+        self.endpoints["block17_20"] = net
+        Q = P + "Mixed_7a/"
+        b0 = c(c(net, Q + "Branch_0/Conv2d_0a_1x1", 1), Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
+        b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
+        b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_1a_3x3", 3, 2, "VALID")
+        net = torch.cat([b0, b1, b2, F.max_pool2d(net, 3, 2)], 1)
+        self.endpoints["Mixed_7a"] = net
+        for i in range(1, 10):
+            net = self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)
+        net = self.block(net, P + "Block8/", 1.0, False, 8)          # model.py:188
+        net = c(net, P + "Conv2d_7b_1x1", 1)
+        self.endpoints["Conv2d_7b_1x1"] = net
+        return net
+
+    def heads(self, feat):
+        """model.py:198-324.  Returns raw locations [B,P,4] and confidence LOGITS [B,P]."""
+        self._in_heads = True
+        c, H, k = self.conv, "Multibox/", self.k
+        out = lambda x, s, n: c(x, s, 1, bn=False, relu=False)
+        nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
+        locs, confs = [], []
+        b = c(c(feat, H + "8x8/Conv", 1), H + "8x8/Conv_1", 3)
+        locs.append(nhwc(out(b, H + "8x8/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "8x8/Conv_3", k)))
+        b = c(c(feat, H + "6x6/Conv", 3), H + "6x6/Conv_1", 3, 1, "VALID")
+        locs.append(nhwc(out(b, H + "6x6/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "6x6/Conv_3", k)))
+        net = c(feat, H + "Conv", 3, 2)
+        b = c(net, H + "4x4/Conv", 3)
+        locs.append(nhwc(out(b, H + "4x4/Conv_1", 4 * k))); confs.append(nhwc(out(b, H + "4x4/Conv_2", k)))
+        b = c(c(net, H + "3x3/Conv", 1), H + "3x3/Conv_1", 2, 1, "VALID")
+        locs.append(nhwc(out(b, H + "3x3/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "3x3/Conv_3", k)))
+        b = c(c(net, H + "2x2/Conv", 1), H + "2x2/Conv_1", 3, 1, "VALID")
+        locs.append(nhwc(out(b, H + "2x2/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "2x2/Conv_3", k)))
+        b = self.q(F.avg_pool2d(feat, 8, 1))
+        locs.append(nhwc(out(b, H + "1x1/Conv", 4))); confs.append(nhwc(out(b, H + "1x1/Conv_1", 1)))
+        self._in_heads = False
+        B = feat.shape[0]
+        return torch.cat(locs, 1).reshape(B, -1, 4), torch.cat(confs, 1)
+
+    def build(self, images_nhwc):
+        """model.py:326-337: images [B,S,S,3] in [-1,1] -> (locations, logits); confidences = sigmoid(logits)."""
+        x = self.q(images_nhwc).permute(0, 3, 1, 2)
+        return self.heads(self.backbone(x))
+
+
+def multibox_loss(locs, logits, priors, gt, match, alpha):
+    """loss.py:67-101 in torch given the (constant) matching; returns (loc_loss, conf_loss)."""
+    B, P = logits.shape
+    dec = locs + priors.unsqueeze(0)
+    c = torch.sigmoid(logits) + 1e-10
+    m = torch.as_tensor(match, dtype=torch.long)
+    pos = m >= 0
+    gsel = torch.gather(gt, 1, m.clamp(min=0).unsqueeze(-1).expand(B, P, 4))
+    loc = alpha * 0.5 * (((dec - gsel) ** 2) * pos.unsqueeze(-1)).sum()
+    conf = -(torch.log(c) * pos).sum() - (torch.log((1.0 - c) + 1e-10) * (~pos)).sum()
+    return loc, conf

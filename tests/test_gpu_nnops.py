@@ -1,0 +1,260 @@
+"""GPU parity of the HBM-bound kernels (batch norm, pooling, glue, optimizer) vs torch-CPU float32.
+
+Tolerance: bf16 outputs within 1 bf16 ulp of the float32 reference computed from the same
+bf16-rounded inputs (2^-7 relative + 2e-3 of max|ref|); float32 outputs rtol 1e-5.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+    return torch
+
+
+def bfr(torch, t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def close_bf16(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    mx = float(ref.abs().max()) + 1e-20
+    bad = (out - ref).abs() > (2.0 ** -7) * ref.abs() + 2e-3 * mx
+    return int(bad.sum()) == 0, "%d/%d bad, max err %.3g, max|ref| %.3g" % (int(bad.sum()), bad.numel(), float((out - ref).abs().max()), mx)
+
+
+def S():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("M,Cc,relu", [(2 * 35 * 35, 96, 1), (3 * 17 * 17, 320, 1), (64, 1536, 0), (5000, 32, 1)])
+def test_bn_forward_backward(T, M, Cc, relu):
+    torch = T
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(M + Cc)
+    y = bfr(torch, torch.randn(M, Cc, generator=gen) * 2 + 0.5)
+    beta = torch.randn(Cc, generator=gen) * 0.3
+    da = bfr(torch, torch.randn(M, Cc, generator=gen))
+    # reference (train.py:94-99 semantics: no gamma, eps .001, biased variance)
+    yr = y.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    mean, var = yr.mean(0), yr.var(0, unbiased=False)
+    a_ref = (yr - mean) * torch.rsqrt(var + 0.001) + br
+    if relu:
+        a_ref = torch.relu(a_ref)
+    a_q = bfr(torch, a_ref.detach())
+    # stats via partial sums exactly as the conv epilogue would write them (2 partial rows)
+    h = M // 2
+    part = torch.stack([torch.stack([y[:h].sum(0), (y[:h] ** 2).sum(0)], 1), torch.stack([y[h:].sum(0), (y[h:] ** 2).sum(0)], 1)]).cuda().contiguous()
+    dm, dr = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    mm, mv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    _lib.check(l.mbx_bn_finalize(part.data_ptr(), 2, Cc, M, 0.001, 0.9, dm.data_ptr(), dr.data_ptr(), mm.data_ptr(), mv.data_ptr(), S()))
+    assert torch.allclose(dm.cpu(), mean.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(dr.cpu(), torch.rsqrt(var.detach() + 0.001), rtol=1e-4)
+    assert torch.allclose(mm.cpu(), 0.1 * mean.detach(), rtol=1e-4, atol=1e-6)           # moving -= (1-d)(moving - batch)
+    assert torch.allclose(mv.cpu(), 0.9 + 0.1 * var.detach(), rtol=1e-4)
+    yd = y.to(torch.bfloat16).cuda()
+    av = ops.View.alloc(1, 1, M, Cc + 8, zero=True).slice(8, Cc)
+    bd = beta.cuda()
+    _lib.check(l.mbx_bn_apply(yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), bd.data_ptr(), relu, av.ptr, av.ld, S()))
+    ok, msg = close_bf16(av.tensor().reshape(M, Cc), a_ref.detach())
+    assert ok, "bn_apply: " + msg
+    # backward
+    a_ref.backward(da)
+    dav = ops.View.alloc(1, 1, M, Cc + 16, zero=True).slice(16, Cc)
+    dav.tensor().reshape(M, Cc).copy_(da.to(torch.bfloat16))
+    rows = l.mbx_bn_bwd_rows(M, Cc)
+    partial = torch.zeros((rows, Cc, 2), device="cuda")
+    dbeta = torch.ones(Cc, device="cuda")                   # accumulates on top of existing content
+    m12 = torch.zeros(2 * Cc, device="cuda")
+    dy = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_bn_bwd_reduce(dav.ptr, dav.ld, av.ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), partial.data_ptr(), S()))
+    _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta.data_ptr(), m12.data_ptr(), S()))
+    _lib.check(l.mbx_bn_bwd_apply(dav.ptr, dav.ld, av.ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), m12.data_ptr(), dy.data_ptr(), S()))
+    # the kernel masks with the STORED activation (bf16 a > 0); the reference with the float one: identical sets
+    # except where rounding flips a tiny positive to 0 -- tolerate through the tolerance on dbeta / dy.
+    assert torch.allclose(dbeta.cpu() - 1.0, br.grad, rtol=2e-3, atol=2e-2 * float(br.grad.abs().max()))
+    ok, msg = close_bf16(dy, yr.grad)
+    assert ok or float((dy.float().cpu() - yr.grad).abs().max()) < 2e-2 * float(yr.grad.abs().max()), "bn_bwd: " + msg
+
+
+def test_bn_fold(T):
+    torch = T
+    from multibox_amd import _lib
+    l = _lib.lib()
+    Cc = 100
+    mm, mv, beta = torch.randn(Cc), torch.rand(Cc) + 0.1, torch.randn(Cc)
+    sc, sh = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    _lib.check(l.mbx_bn_fold(mm.cuda().data_ptr(), mv.cuda().data_ptr(), beta.cuda().data_ptr(), 0.001, Cc, sc.data_ptr(), sh.data_ptr(), S()))
+    s = torch.rsqrt(mv + 0.001)
+    assert torch.allclose(sc.cpu(), s, rtol=1e-5) and torch.allclose(sh.cpu(), beta - mm * s, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,H,W,Cc", [(2, 35, 35, 64), (1, 17, 17, 1088), (3, 9, 9, 8)])
+def test_maxpool(T, N, H, W, Cc):
+    torch = T
+    import torch.nn.functional as F
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(H)
+    x = bfr(torch, torch.relu(torch.randn(N, H, W, Cc, generator=gen)))      # many exact ties at 0
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr, idx = F.max_pool2d(xr, 3, 2, return_indices=True)
+    xv = ops.View.alloc(N, H, W, Cc + 8, zero=True).slice(0, Cc)
+    xv.tensor().copy_(x.to(torch.bfloat16))
+    yv = ops.View.alloc(N, Ho, Wo, Cc + 8, zero=True).slice(8, Cc)
+    am = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device="cuda")
+    _lib.check(l.mbx_maxpool_fwd(xv.ptr, xv.img_stride, xv.ld, N, H, W, Cc, 3, 2, yv.ptr, yv.img_stride, yv.ld, Ho, Wo, am.data_ptr(), S()))
+    assert torch.equal(yv.tensor().float().cpu(), yr.detach().permute(0, 2, 3, 1))
+    dy = bfr(torch, torch.randn(N, Ho, Wo, Cc, generator=gen))
+    yr.backward(dy.permute(0, 3, 1, 2))
+    dyv = ops.View.alloc(N, Ho, Wo, Cc)
+    dyv.tensor().copy_(dy.to(torch.bfloat16))
+    dxv = ops.View.alloc(N, H, W, Cc, zero=True)
+    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, 3, 2, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 0, S()))
+    ok, msg = close_bf16(dxv.tensor(), xr.grad.permute(0, 2, 3, 1))      # first-maximum routing, like torch/TF
+    assert ok, msg
+    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, 3, 2, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 1, S()))
+    ok, msg = close_bf16(dxv.tensor(), 2 * xr.grad.permute(0, 2, 3, 1))
+    assert ok, "accumulate: " + msg
+
+
+@pytest.mark.parametrize("N,H,W,Cc,k,pad", [(2, 35, 35, 192, 3, 1), (4, 8, 8, 1536, 8, 0), (1, 14, 14, 64, 8, 0)])
+def test_avgpool(T, N, H, W, Cc, k, pad):
+    torch = T
+    import torch.nn.functional as F
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(k)
+    x = bfr(torch, torch.randn(N, H, W, Cc, generator=gen))
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, k, 1, pad, count_include_pad=False)              # TF SAME: divide by valid taps
+    xv = ops.View.alloc(N, H, W, Cc)
+    xv.tensor().copy_(x.to(torch.bfloat16))
+    yv = ops.View.alloc(N, Ho, Wo, Cc)
+    _lib.check(l.mbx_avgpool_fwd(xv.ptr, xv.img_stride, xv.ld, N, H, W, Cc, k, pad, yv.ptr, yv.img_stride, yv.ld, Ho, Wo, S()))
+    ok, msg = close_bf16(yv.tensor(), yr.detach().permute(0, 2, 3, 1))
+    assert ok, msg
+    dy = bfr(torch, torch.randn(N, Ho, Wo, Cc, generator=gen))
+    yr.backward(dy.permute(0, 3, 1, 2))
+    dyv = ops.View.alloc(N, Ho, Wo, Cc)
+    dyv.tensor().copy_(dy.to(torch.bfloat16))
+    dxv = ops.View.alloc(N, H, W, Cc, zero=True)
+    _lib.check(l.mbx_avgpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, N, H, W, Cc, k, pad, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 0, S()))
+    ok, msg = close_bf16(dxv.tensor(), xr.grad.permute(0, 2, 3, 1))
+    assert ok, msg
+
+
+def test_glue_kernels(T):
+    torch = T
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(1)
+    # relu mask
+    M, Cc = 777, 40
+    g = bfr(torch, torch.randn(M, Cc, generator=gen))
+    a = bfr(torch, torch.relu(torch.randn(M, Cc, generator=gen)))
+    gv = ops.View.alloc(1, 1, M, Cc + 8, zero=True).slice(8, Cc)
+    gv.tensor().reshape(M, Cc).copy_(g.to(torch.bfloat16))
+    av = ops.View.alloc(1, 1, M, Cc)
+    av.tensor().reshape(M, Cc).copy_(a.to(torch.bfloat16))
+    _lib.check(l.mbx_relu_mask(gv.ptr, gv.ld, av.ptr, av.ld, M, Cc, S()))
+    assert torch.equal(gv.tensor().reshape(M, Cc).float().cpu(), g * (a > 0))
+    # pack input
+    img = torch.rand(2, 5, 7, 3, generator=gen) * 2 - 1
+    out = torch.zeros((2, 5, 7, 8), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_pack_input(img.cuda().data_ptr(), 2 * 5 * 7, out.data_ptr(), S()))
+    assert torch.equal(out[..., :3].float().cpu(), bfr(torch, img)) and float(out[..., 3:].float().abs().max()) == 0
+    # head gather / scatter (model.py:295-322 flatten order)
+    N, g_, k, P, off = 3, 6, 5, 646, 320
+    cells = g_ * g_
+    h = torch.randn(N * cells, 32, generator=gen)
+    locs, logits = torch.zeros((N, P, 4), device="cuda"), torch.zeros((N, P), device="cuda")
+    _lib.check(l.mbx_head_gather(h.cuda().data_ptr(), 32, N, cells, k, P, off, locs.data_ptr(), logits.data_ptr(), S()))
+    ref_l = h[:, :4 * k].reshape(N, cells * k, 4)
+    ref_c = h[:, 4 * k:5 * k].reshape(N, cells * k)
+    assert torch.equal(locs[:, off:off + cells * k].cpu(), ref_l) and torch.equal(logits[:, off:off + cells * k].cpu(), ref_c)
+    assert float(locs[:, :off].abs().max()) == 0
+    dl, dz = torch.randn(N, P, 4, generator=gen), torch.randn(N, P, generator=gen)
+    gb = torch.ones((N * cells, 32), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_head_scatter(dl.cuda().data_ptr(), dz.cuda().data_ptr(), N, cells, k, P, off, gb.data_ptr(), 32, S()))
+    gb = gb.float().cpu()
+    assert torch.equal(gb[:, :4 * k], bfr(torch, dl[:, off:off + cells * k].reshape(N * cells, 4 * k)))
+    assert torch.equal(gb[:, 4 * k:5 * k], bfr(torch, dz[:, off:off + cells * k].reshape(N * cells, k)))
+    assert float(gb[:, 5 * k:].abs().max()) == 0
+
+
+def test_filter_prepare(T):
+    torch = T
+    from multibox_amd import _lib
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(2)
+    shapes = [(32, 3, 3, 8), (25, 1, 1, 96), (160, 1, 7, 128), (96, 2, 2, 128)]
+    ws = [bfr(torch, torch.randn(*s, generator=gen)) for s in shapes]
+    src_off, dst_off, blocks, entries, refs = 0, 0, 0, [], []
+    flat = []
+    for w, (K, R, S_, Cc) in zip(ws, shapes):
+        kpad = (K + 7) // 8 * 8
+        entries.append(_lib.FilterEntry(src_off, dst_off, K, R, S_, Cc, kpad, blocks))
+        flat.append(w.reshape(-1))
+        ref = torch.zeros(Cc, R, S_, kpad)
+        ref[..., :K] = w.flip(1, 2).permute(3, 1, 2, 0)
+        refs.append((dst_off, ref))
+        n = Cc * R * S_ * kpad
+        src_off += w.numel()
+        dst_off += (n + 7) // 8 * 8
+        blocks += (n + 2047) // 2048
+    wsrc = torch.cat(flat).to(torch.bfloat16).cuda()
+    wdst = torch.zeros(dst_off, dtype=torch.bfloat16, device="cuda")
+    arr = (_lib.FilterEntry * len(entries))(*entries)
+    raw = np.frombuffer(C.string_at(C.addressof(arr), C.sizeof(arr)), dtype=np.uint8).copy()
+    table = torch.from_numpy(raw).cuda()
+    _lib.check(l.mbx_filter_prepare(wsrc.data_ptr(), wdst.data_ptr(), table.data_ptr(), len(entries), blocks, S()))
+    for off, ref in refs:
+        assert torch.equal(wdst[off:off + ref.numel()].float().cpu(), ref.reshape(-1))
+
+
+def test_rmsprop_ema_step(T):
+    """train.py:190-263 on a flat range vs the numpy restatement (oracle/ref_numpy.py)."""
+    torch = T
+    from multibox_amd import _lib
+    from oracle import ref_numpy as R
+    l = _lib.lib()
+    rng = np.random.RandomState(0)
+    n = 100003
+    w, g = rng.randn(n).astype(np.float32), (rng.randn(n) * 10).astype(np.float32)
+    ms, ema = np.ones(n, np.float32), w.copy()
+    lr, decay, eps, wd, d = 0.0094, 0.9, 1.0, 4e-5, R.ema_decay(0.9999, 3)
+    dw, dg, dms, dema = [torch.from_numpy(a.copy()).cuda() for a in (w, g, ms, ema)]
+    wb = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    reg = torch.zeros(1, device="cuda")
+    for _ in range(2):
+        _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), dg.data_ptr(), dms.data_ptr(), None, dema.data_ptr(), wb.data_ptr(), n,
+                                          lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), S()))
+    reg_ref = 0.0
+    for _ in range(2):
+        reg_ref += 0.5 * wd * float((w.astype(np.float64) ** 2).sum())
+        ema -= np.float32(1 - d) * (ema - w)
+        gg = g + np.float32(wd) * w
+        R.rmsprop_step(w, gg, ms, np.zeros_like(w), lr, decay, 0.0, eps)
+    assert np.allclose(dw.cpu().numpy(), w, rtol=1e-5, atol=1e-6)
+    assert np.allclose(dms.cpu().numpy(), ms, rtol=1e-5)
+    assert np.allclose(dema.cpu().numpy(), ema, rtol=1e-5, atol=1e-6)
+    assert np.isclose(float(reg), reg_ref, rtol=1e-4)
+    assert torch.equal(wb.float().cpu(), dw.to(torch.bfloat16).float().cpu())
+    # frozen range: no update, EMA + bf16 refresh only
+    w0 = dw.clone()
+    _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), None, None, None, dema.data_ptr(), wb.data_ptr(), n, lr, decay, 0.0, eps, wd, d, 0, None, S()))
+    assert torch.equal(dw, w0)
