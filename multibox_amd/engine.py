@@ -160,6 +160,7 @@ class Net:
         self.pool("avg", t5, p5, 3, 1, pad=1)
         self.conv([(Q + "Branch_3/Conv2d_0b_1x1", 64)], p5, z.slice(368, 64), 1, 1)
         net = z.slice(112, 320)
+        self.endpoints = {"MaxPool_5a_3x3": t5, "Mixed_5b": net}
 
         # ---- 10 x block35 (model.py:6-24), scale 0.17
         trunk0 = net
@@ -191,7 +192,9 @@ class Net:
         self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 256)], t6a, t6b, 3, 3)
         self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 384)], t6b, o6.slice(384, 384), 3, 3, 2, "VALID")
         self.pool("max", net, o6.slice(768, 320), 3, 2)
+        self.endpoints["block35_10"] = net
         net = o6
+        self.endpoints["Mixed_6a"] = net
 
         # ---- 20 x block17 (model.py:27-44), scale 0.10
         trunk0, zg = net, None
@@ -221,7 +224,9 @@ class Net:
         self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 288)], t7.slice(512, 256), t7.slice(768, 288), 3, 3)
         self.conv([(Q + "Branch_2/Conv2d_1a_3x3", 320)], t7.slice(768, 288), o7.slice(672, 320), 3, 3, 2, "VALID")
         self.pool("max", net, o7.slice(992, 1088), 3, 2)
+        self.endpoints["block17_20"] = net
         net = o7
+        self.endpoints["Mixed_7a"] = net
 
         # ---- 9 x block8 (scale 0.20) + Block8 without relu at scale 1.0 (model.py:187-188)
         trunk0, zg = net, None
@@ -241,6 +246,7 @@ class Net:
         feat = self.alloc(s7, s7, 1536)
         self.conv([(P + "Conv2d_7b_1x1", 1536)], net, feat, 1, 1)
         self.features = feat
+        self.endpoints["Conv2d_7b_1x1"] = feat
 
         # ------------------------------------------------------- detection heads (model.py:198-324)
         H = "Multibox/"
@@ -360,6 +366,8 @@ class Net:
             self.Btg = torch.zeros(self.nBt, **f32)
         self._alloc_scratch()
         self._build_backward()
+        if torch.device(self.dev).type == "cuda":
+            self.prepare_filters()
 
     def init_weights(self, seed):
         """slim defaults (un-vendored): Xavier-uniform filters, zero biases/betas, moving mean 0 / variance 1."""
@@ -390,7 +398,9 @@ class Net:
         self.get_param(name).copy_(torch.as_tensor(value, dtype=torch.float32).reshape(self.get_param(name).shape))
 
     def refresh_bf16(self):
+        """Call after editing W directly (set_param, checkpoint load)."""
         self.Wb.copy_(self.W.to(torch.bfloat16))
+        self.prepare_filters()
 
     def _alloc_scratch(self):
         dev = self.dev

@@ -6,6 +6,7 @@ pixel stride is ``ld`` -- how tf.concat(3, ...) of model.py is made free.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -66,7 +67,10 @@ class View:
     def alloc(N, H, W, C, ld=None, dtype=torch.bfloat16, device="cuda", zero=False):
         ld = C if ld is None else ld
         f = torch.zeros if zero else torch.empty
-        return View(f((N, H, W, ld), dtype=dtype, device=device), N, H, W, C, ld, 0, torch.empty((), dtype=dtype).element_size())
+        buf = f((N, H, W, ld), dtype=dtype, device=device)
+        if not zero and os.environ.get("MBX_POISON"):      # debugging: make any read-before-write visible as NaN
+            buf.fill_(float("nan"))
+        return View(buf, N, H, W, C, ld, 0, torch.empty((), dtype=dtype).element_size())
 
 
 def _stream():

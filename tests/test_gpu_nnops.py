@@ -95,7 +95,8 @@ def test_bn_fold(T):
     Cc = 100
     mm, mv, beta = torch.randn(Cc), torch.rand(Cc) + 0.1, torch.randn(Cc)
     sc, sh = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
-    _lib.check(l.mbx_bn_fold(mm.cuda().data_ptr(), mv.cuda().data_ptr(), beta.cuda().data_ptr(), 0.001, Cc, sc.data_ptr(), sh.data_ptr(), S()))
+    dmm, dmv, dbeta = mm.cuda(), mv.cuda(), beta.cuda()      # keep the device tensors alive across the call
+    _lib.check(l.mbx_bn_fold(dmm.data_ptr(), dmv.data_ptr(), dbeta.data_ptr(), 0.001, Cc, sc.data_ptr(), sh.data_ptr(), S()))
     s = torch.rsqrt(mv + 0.001)
     assert torch.allclose(sc.cpu(), s, rtol=1e-5) and torch.allclose(sh.cpu(), beta - mm * s, rtol=1e-5, atol=1e-6)
 
@@ -175,21 +176,24 @@ def test_glue_kernels(T):
     # pack input
     img = torch.rand(2, 5, 7, 3, generator=gen) * 2 - 1
     out = torch.zeros((2, 5, 7, 8), dtype=torch.bfloat16, device="cuda")
-    _lib.check(l.mbx_pack_input(img.cuda().data_ptr(), 2 * 5 * 7, out.data_ptr(), S()))
+    dimg = img.cuda()
+    _lib.check(l.mbx_pack_input(dimg.data_ptr(), 2 * 5 * 7, out.data_ptr(), S()))
     assert torch.equal(out[..., :3].float().cpu(), bfr(torch, img)) and float(out[..., 3:].float().abs().max()) == 0
     # head gather / scatter (model.py:295-322 flatten order)
     N, g_, k, P, off = 3, 6, 5, 646, 320
     cells = g_ * g_
     h = torch.randn(N * cells, 32, generator=gen)
     locs, logits = torch.zeros((N, P, 4), device="cuda"), torch.zeros((N, P), device="cuda")
-    _lib.check(l.mbx_head_gather(h.cuda().data_ptr(), 32, N, cells, k, P, off, locs.data_ptr(), logits.data_ptr(), S()))
+    dh = h.cuda()
+    _lib.check(l.mbx_head_gather(dh.data_ptr(), 32, N, cells, k, P, off, locs.data_ptr(), logits.data_ptr(), S()))
     ref_l = h[:, :4 * k].reshape(N, cells * k, 4)
     ref_c = h[:, 4 * k:5 * k].reshape(N, cells * k)
     assert torch.equal(locs[:, off:off + cells * k].cpu(), ref_l) and torch.equal(logits[:, off:off + cells * k].cpu(), ref_c)
     assert float(locs[:, :off].abs().max()) == 0
     dl, dz = torch.randn(N, P, 4, generator=gen), torch.randn(N, P, generator=gen)
     gb = torch.ones((N * cells, 32), dtype=torch.bfloat16, device="cuda")
-    _lib.check(l.mbx_head_scatter(dl.cuda().data_ptr(), dz.cuda().data_ptr(), N, cells, k, P, off, gb.data_ptr(), 32, S()))
+    ddl, ddz = dl.cuda(), dz.cuda()
+    _lib.check(l.mbx_head_scatter(ddl.data_ptr(), ddz.data_ptr(), N, cells, k, P, off, gb.data_ptr(), 32, S()))
     gb = gb.float().cpu()
     assert torch.equal(gb[:, :4 * k], bfr(torch, dl[:, off:off + cells * k].reshape(N * cells, 4 * k)))
     assert torch.equal(gb[:, 4 * k:5 * k], bfr(torch, dz[:, off:off + cells * k].reshape(N * cells, k)))
