@@ -164,6 +164,13 @@ class Trainer:
         self._optimizer()
         self.global_step += 1
 
+    def run_eager_once(self):
+        """forward + loss + backward launched eagerly (profiling aid; no optimizer, no all-reduce)."""
+        self._front()
+        for fns, _, _ in self._segments:
+            for f in fns:
+                f()
+
     def _optimizer(self):
         net, l = self.net, _lib.lib()
         s = torch.cuda.current_stream().cuda_stream
