@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's detect.py (detect.py:462-524): same flags and results JSON
+(`results-dense-<global_step>.json`, detect.py:438-460).  Forward pass + decode/clip/filter/
+top-K/convert all run on the GPU (libmbx); NO NMS, exactly like the reference.
+
+Not yet wired: --tfrecords multi-crop input; `--synthetic N` feeds N seeded
+synthetic patches with whole-image metadata instead."""
+import argparse
+import json
+import os
+import pprint
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="Detect objects using a pretrained Multibox model")
+    p.add_argument("--tfrecords", dest="tfrecords", type=str, nargs="+", required=False, default=None)
+    p.add_argument("--priors", dest="priors", type=str, required=True)
+    p.add_argument("--checkpoint_path", dest="checkpoint_path", type=str, required=True)
+    p.add_argument("--config", dest="config_file", type=str, required=True)
+    p.add_argument("--max_iterations", dest="max_iterations", type=int, default=0)
+    p.add_argument("--max_detections", dest="max_detections", type=int, default=100,
+                   help="accepted for compatibility; unused by the reference too (detect.py:294)")
+    p.add_argument("--save_dir", dest="save_dir", type=str, required=True)
+    p.add_argument("--synthetic", type=int, default=0, help="[new] number of synthetic images instead of --tfrecords")
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    from multibox_amd.config import parse_config_file, with_defaults
+    from multibox_amd import priors as PR, checkpoint as CK, detect as D, _lib
+    from multibox_amd.engine import Net
+    import __graft_entry__ as g
+    print("Command line arguments:")
+    pprint.pprint(vars(args))
+    cfg = with_defaults(parse_config_file(args.config_file))
+    if args.tfrecords and not args.synthetic:
+        raise SystemExit("--tfrecords input is not wired yet (SURVEY 8f F3); run with --synthetic N")
+    g.build()
+    bbox_priors = PR.load_priors(args.priors)
+    ckpt = CK.latest_checkpoint(args.checkpoint_path)
+    if ckpt is None:
+        print("ERROR: No checkpoint file found.")
+        return
+    B = cfg.BATCH_SIZE
+    net = Net(batch=B, input_size=cfg.INPUT_SIZE, k=cfg.NUM_BBOXES_PER_CELL, mode="infer")
+    global_step = CK.restore_for_inference(ckpt, net)
+    print("Found model for global step: %d" % global_step)
+    det = cfg.get("DETECTION", {})
+    max_keep = int(det.get("ORIGINAL_IMAGE_MAX_TO_KEEP", 200))
+    pp = D.DetectPostprocess(bbox_priors, B, k_max=max(max_keep, 1))
+    conf = torch.empty((B, net.P), dtype=torch.float32, device="cuda")
+    results, step = [], 0
+    n_images = args.synthetic
+    S = cfg.INPUT_SIZE
+    for start in range(0, n_images - n_images % B if n_images >= B else 0, B):
+        rng = np.random.RandomState(start)
+        images = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+        ids = np.arange(start, start + B)
+        meta = D.make_patch_meta(np.zeros((B, 2), np.int32), np.tile([[S, S]], (B, 1)), np.zeros((B, 1), np.int32),
+                                 np.tile([[0., 0., 1., 1.]], (B, 1)), np.full((B, 1), max_keep), np.tile([[S, S]], (B, 1)))
+        t = time.time()
+        net.set_input(torch.from_numpy(images).cuda())
+        locs, logits = net.forward()
+        _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "sigmoid")
+        torch.cuda.synchronize()
+        dt = time.time() - t
+        t2 = time.time()
+        boxes, scores, _, count = pp(locs, conf, meta)
+        torch.cuda.synchronize()
+        dt2 = time.time() - t2
+        results += D.results_to_json_records(boxes, scores, count, ids)
+        step += 1
+        print("Step: %d, Time/image (ms): %.1f, Post-process/image (ms): %.3f" % (step, dt / B * 1000, dt2 / B * 1000))
+        if args.max_iterations > 0 and step == args.max_iterations:
+            break
+    os.makedirs(args.save_dir, exist_ok=True)
+    save_path = os.path.join(args.save_dir, "results-dense-%d.json" % global_step)
+    with open(save_path, "w") as f:
+        json.dump(results, f)
+    print("wrote", save_path, len(results), "detections")
+
+
+if __name__ == "__main__":
+    main()

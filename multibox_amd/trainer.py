@@ -18,6 +18,7 @@ import torch
 from . import _lib
 from .engine import Net, WEIGHT_DECAY
 from .loss import MultiboxLoss
+from .dist import BucketReducer
 
 
 def decay_steps(num_train_examples, batch_size, num_epochs_per_decay):
@@ -46,7 +47,7 @@ class Trainer:
         self.lr0, self.dsteps, self.lr_factor, self.staircase = initial_learning_rate, decay_steps_, learning_rate_decay_factor, staircase
         self.rms_decay, self.momentum, self.eps, self.ema_decay = rmsprop_decay, rmsprop_momentum, rmsprop_epsilon, moving_average_decay
         self.global_step = 0
-        self.pg = process_group
+        self.reducer = BucketReducer(process_group)
         f32 = dict(dtype=torch.float32, device=net.dev)
         # trainable ranges of the flat buffers (heads are last in forward order)
         self.w_lo = net.head_w_start if net.fine_tune else 0
@@ -140,27 +141,22 @@ class Trainer:
     def step(self):
         """One optimisation step on the batch set by set_batch().  Returns nothing; read
         self.loss.loss2 / self.total_loss() when needed (no host sync here)."""
-        net = self.net
-        works = []
+        net, red = self.net, self.reducer
         if self.use_graph:
             if self.graphs is None:
                 self._capture()
             self.graphs[0].replay()
             for g, (_, lo, hi) in zip(self.graphs[1:], self._segments):
                 g.replay()
-                if self.pg is not None:
-                    works.append(torch.distributed.all_reduce(net.Wg[lo:hi], group=self.pg, async_op=True))
+                red.reduce_async(net.Wg, lo, hi)
         else:
             self._front()
             for fns, lo, hi in self._segments:
                 for f in fns:
                     f()
-                if self.pg is not None:
-                    works.append(torch.distributed.all_reduce(net.Wg[lo:hi], group=self.pg, async_op=True))
-        if self.pg is not None:
-            works.append(torch.distributed.all_reduce(net.Btg[self.bt_lo:], group=self.pg, async_op=True))
-            for w in works:
-                w.wait()
+                red.reduce_async(net.Wg, lo, hi)
+        red.reduce_async(net.Btg, self.bt_lo, net.nBt)
+        red.wait()
         self._optimizer()
         self.global_step += 1
 

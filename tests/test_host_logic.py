@@ -1,0 +1,101 @@
+"""Host-side logic that needs no GPU: config keys, CLI flags, LR schedule, DP segments, patches."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+EXAMPLE = """
+RANDOM_SEED : 1.0
+SESSION_CONFIG : {
+  PER_PROCESS_GPU_MEMORY_FRACTION : 0.95
+}
+NUM_BBOXES_PER_CELL : 7
+MAX_NUM_BBOXES : 13
+LOCATION_LOSS_ALPHA : 1000.0
+BATCH_SIZE : 32
+INPUT_SIZE : 299
+DETECTION :
+  USE_ORIGINAL_IMAGE : true
+  ORIGINAL_IMAGE_MAX_TO_KEEP : 200
+  CROPS :
+    - HEIGHT : 299
+      WIDTH : 299
+      HEIGHT_STRIDE : 113
+      WIDTH_STRIDE : 113
+      FLIP : false
+      MAX_TO_KEEP : 50
+NUM_TRAIN_EXAMPLES : 56945
+INITIAL_LEARNING_RATE : 0.01
+NUM_EPOCHS_PER_DELAY : 4
+LEARNING_RATE_DECAY_FACTOR : 0.94
+LEARNING_RATE_STAIRCASE : true
+RMSPROP_EPSILON : 1.0
+"""
+
+
+def test_config_keys(tmp_path):
+    from multibox_amd.config import parse_config_file, with_defaults
+    f = tmp_path / "config.yaml"
+    f.write_text(EXAMPLE)
+    cfg = with_defaults(parse_config_file(str(f)))
+    assert cfg.NUM_BBOXES_PER_CELL == 7 and cfg.RANDOM_SEED == 1.0          # config.yaml.example:1 is a float
+    assert cfg.DETECTION.CROPS[0].MAX_TO_KEEP == 50 and cfg.SESSION_CONFIG.PER_PROCESS_GPU_MEMORY_FRACTION == 0.95
+    assert cfg.MOVING_AVERAGE_DECAY == 0.9999                               # default filled in
+    cfg.BATCH_SIZE = 8                                                      # train.py:362-366 overrides
+    assert cfg["BATCH_SIZE"] == 8
+
+
+@pytest.mark.parametrize("script,flags", [
+    ("train.py", ["--tfrecords", "--priors", "--logdir", "--config", "--pretrained_model", "--fine_tune",
+                  "--trainable_scopes", "--use_moving_averages", "--restore_moving_averages", "--max_number_of_steps", "--batch_size"]),
+    ("detect.py", ["--tfrecords", "--priors", "--checkpoint_path", "--config", "--max_iterations", "--max_detections", "--save_dir"]),
+])
+def test_cli_flags_match_reference(script, flags):
+    """train.py:304-346 / detect.py:466-492."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for f in flags:
+        assert f in out.stdout, f
+
+
+def test_schedule_matches_oracle():
+    from multibox_amd import trainer as T
+    from oracle import ref_numpy as R
+    assert T.decay_steps(56945, 32, 4) == R.decay_steps(56945, 32, 4) == 7116
+    for step in (0, 1, 7115, 7116, 20000):
+        assert np.isclose(T.learning_rate(step, 0.01, 7116, 0.94), float(R.learning_rate(step, 0.01, 7116, 0.94)), rtol=1e-6)
+
+
+def test_extract_patches_matches_oracle():
+    from multibox_amd import detect as D
+    from oracle import ref_numpy as R
+    img = np.random.RandomState(0).rand(480, 640, 3).astype(np.float32)
+    patches, offs, res, n = D.extract_patches(img, (299, 299), (113, 113))
+    ro, rr = R.extract_patch_offsets((480, 640), (299, 299), (113, 113))
+    assert n == 8 and np.array_equal(offs, ro) and np.array_equal(res, rr)
+    assert np.array_equal(patches[5], img[113:412, 113:412])
+    p2, o2, r2, n2 = D.extract_patches(np.zeros((100, 100, 3), np.float32), (299, 299), (113, 113))
+    assert n2 == 0 and p2.shape == (0, 299, 299, 3)                          # detect.py:64-70
+
+
+def test_backward_segments_cover_gradient_buffer():
+    """The data-parallel buckets (one per backward segment) tile the trainable range of Wg exactly."""
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    for fine_tune in (False, True):
+        net = Net(batch=1, input_size=299, k=5, mode="train", fine_tune=fine_tune, device="cpu")
+        tr = Trainer.__new__(Trainer)
+        tr.net, tr.w_lo = net, (net.head_w_start if fine_tune else 0)
+        segs = tr._make_segments(4)
+        assert sum(len(s[0]) for s in segs) == len(net.bwd_launches)
+        hi = net.nW
+        for fns, lo, h in segs:
+            assert h == hi and lo < h
+            hi = lo
+        assert hi == tr.w_lo

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's train.py (train.py:300-385): same flags, same config.yaml keys,
+same priors.pkl; the step runs on libmbx (one process per GPU; launch with torch.distributed.run
+for data parallelism).
+
+Not yet wired: --tfrecords input (F1: TFRecord/JPEG/augmentation pipeline) and
+--pretrained_model import of TF checkpoints (F2).  Until then `--synthetic` feeds seeded
+synthetic batches of the reference's input contract (inputs.py:340-351)."""
+import argparse
+import json
+import os
+import pprint
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="Train the multibox detection system")
+    p.add_argument("--tfrecords", dest="tfrecords", type=str, nargs="+", required=False, default=None,
+                   help="paths to tfrecords files that contain the training data")
+    p.add_argument("--priors", dest="priors", type=str, required=True, help="path to the bounding box priors pickle file")
+    p.add_argument("--logdir", dest="logdir", type=str, required=True, help="path to directory to store summary files and checkpoint files")
+    p.add_argument("--config", dest="config_file", type=str, required=True, help="Path to the configuration file")
+    p.add_argument("--pretrained_model", dest="pretrained_model", type=str, default=None)
+    p.add_argument("--fine_tune", dest="fine_tune", action="store_true", default=False,
+                   help="only the variables in the detection heads will be trained")
+    p.add_argument("--trainable_scopes", dest="trainable_scopes", type=str, nargs="+", default=None)
+    p.add_argument("--use_moving_averages", dest="use_moving_averages", action="store_true", default=False)
+    p.add_argument("--restore_moving_averages", dest="restore_moving_averages", action="store_true", default=False)
+    p.add_argument("--max_number_of_steps", dest="max_number_of_steps", type=int, default=None)
+    p.add_argument("--batch_size", dest="batch_size", type=int, default=None)
+    p.add_argument("--synthetic", action="store_true", help="[new] synthetic input instead of --tfrecords")
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    from multibox_amd.config import parse_config_file, with_defaults
+    from multibox_amd import priors as PR, checkpoint as CK
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer, decay_steps
+    from multibox_amd.synth import synthetic_batch
+    import __graft_entry__ as g
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        print("Command line arguments:")
+        pprint.pprint(vars(args))
+    cfg = with_defaults(parse_config_file(args.config_file))
+    if args.max_number_of_steps is not None:      # train.py:362-366
+        cfg.NUM_TRAIN_ITERATIONS = args.max_number_of_steps
+    if args.batch_size is not None:
+        cfg.BATCH_SIZE = args.batch_size
+    if args.tfrecords and not args.synthetic:
+        raise SystemExit("--tfrecords input is not wired yet (SURVEY 8f F1); run with --synthetic")
+    if args.pretrained_model and not os.path.exists(args.pretrained_model):
+        raise SystemExit("pretrained model not found: %s" % args.pretrained_model)
+    if args.trainable_scopes:
+        raise SystemExit("--trainable_scopes is not supported yet (train.py:152-171)")
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg = torch.distributed.group.WORLD
+    if rank == 0:
+        g.build()
+    if world > 1:
+        torch.distributed.barrier()
+    bbox_priors = PR.load_priors(args.priors)                     # train.py:368-370
+    net = Net(batch=cfg.BATCH_SIZE, input_size=cfg.INPUT_SIZE, k=cfg.NUM_BBOXES_PER_CELL, mode="train",
+              fine_tune=args.fine_tune, bn_decay=cfg.BATCHNORM_MOVING_AVERAGE_DECAY)
+    tr = Trainer(net, bbox_priors, max_num_bboxes=cfg.MAX_NUM_BBOXES, location_loss_alpha=cfg.LOCATION_LOSS_ALPHA,
+                 initial_learning_rate=cfg.INITIAL_LEARNING_RATE,
+                 decay_steps_=decay_steps(cfg.NUM_TRAIN_EXAMPLES, cfg.BATCH_SIZE, cfg.NUM_EPOCHS_PER_DELAY),
+                 learning_rate_decay_factor=cfg.LEARNING_RATE_DECAY_FACTOR, staircase=cfg.LEARNING_RATE_STAIRCASE,
+                 rmsprop_decay=cfg.RMSPROP_DECAY, rmsprop_momentum=float(cfg.RMSPROP_MOMENTUM), rmsprop_epsilon=cfg.RMSPROP_EPSILON,
+                 moving_average_decay=cfg.MOVING_AVERAGE_DECAY, process_group=pg)
+    latest = CK.latest_checkpoint(args.logdir)                    # slim.learning.train resumes from logdir
+    if latest:
+        CK.restore_for_training(latest, tr)
+        if rank == 0:
+            print("Resumed from %s (step %d)" % (latest, tr.global_step))
+    elif args.pretrained_model:
+        CK.restore_for_training(CK.latest_checkpoint(args.pretrained_model), tr)
+        tr.global_step = 0
+    t_save = t_log = time.time()
+    log = open(os.path.join(args.logdir, "train_log.jsonl"), "a") if rank == 0 and (os.makedirs(args.logdir, exist_ok=True) or True) else None
+    step0 = tr.global_step
+    while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
+        images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
+        tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+        tr.step()
+        if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
+            loc, conf, reg, total = tr.losses()
+            if int(tr.match_status().max()) != 0:
+                raise RuntimeError("bipartite matching failed (non-finite predictions)")     # py_func error -> abort, loss.py:82
+            now = time.time()
+            ips = cfg.BATCH_SIZE * world * (tr.global_step - step0) / (now - t_log) if now > t_log else 0.0
+            rec = dict(global_step=tr.global_step, total_loss=total, location_loss=loc, confidence_loss=conf,
+                       learning_rate=tr.lr, images_per_sec=ips)          # train.py:266-271 summaries
+            print("global step %d: loss = %.4f (loc %.4f conf %.4f) lr %.6f %.1f img/s" % (tr.global_step, total, loc, conf, tr.lr, ips))
+            log.write(json.dumps(rec) + "\n")
+            log.flush()
+            step0, t_log = tr.global_step, now
+        if rank == 0 and time.time() - t_save > cfg.SAVE_INTERVAL_SECS:
+            CK.save(args.logdir, tr, cfg.MAX_TO_KEEP)
+            t_save = time.time()
+    if rank == 0:
+        print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
