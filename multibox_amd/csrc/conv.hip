@@ -11,6 +11,7 @@
 // (chunk ^ (row & 7)) so the ds_read_b128 fragment reads are bank-conflict free; two buffers,
 // one barrier per 64-deep K step, next tile's global loads in flight during the MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,7 +26,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_c
 
 struct ConvK {
   const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
-  const unsigned short* w; int C_out, S, Ktot;
+  const unsigned short* w; int C_out, R, S, Ktot;
+  unsigned x_bytes, w_bytes;
   int mul, shift, pad_t, pad_l, W_out, HW_out, M;
   void* y; int y_img_stride, ldy;
   int epi, relu, accumulate;
@@ -33,9 +35,25 @@ struct ConvK {
   const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
   float* stats;
   int tiles_m, tiles_n;
+  unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
+  int pw;                              // pointwise: R = S = 1, no padding, unit stride, not transposed
 };
 
 constexpr int kThreads = 256;
+// exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
+__device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
+  return (unsigned)(((unsigned long long)m * magic) >> shift);
+}
+constexpr unsigned kOOB = 0x80000000u;      // byte offset beyond every tensor: buffer loads return 0 there
+
+// Buffer loads: 32-bit byte offsets off an SGPR descriptor; an out-of-range offset yields zeros,
+// so zero padding / tile edges need no branch and no exec masking.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
 
 // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each
 // XCD a contiguous run of logical tiles so that tiles sharing a pixel panel share an L2.
@@ -61,30 +79,28 @@ conv_igemm_kernel(const ConvK p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- loader state: thread owns 16-B chunk `chunk` of rows lrow + 32*i
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
   const int chunk = tid & 7, lrow = tid >> 3;
-  int hb[PI], wb[PI], xb[PI];
-  bool mv[PI];
+  int hb[PI], wb[PI], ro[PI];          // first-tap input coordinates and byte offset of each pixel row
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
     const int m = m0 + lrow + 32 * i;
-    mv[i] = m < p.M;
-    const int mm = mv[i] ? m : 0;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
     const int img = mm / p.HW_out, rem = mm - img * p.HW_out;
     const int oh = rem / p.W_out, ow = rem - oh * p.W_out;
-    hb[i] = oh * p.mul - p.pad_t;
+    hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);       // rows past M fail every bounds check
     wb[i] = ow * p.mul - p.pad_l;
-    xb[i] = img * p.x_img_stride;
+    ro[i] = p.shift ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
   }
   int wo[WI];
-  bool wv[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int n = n0 + lrow + 32 * i;
-    wv[i] = n < p.C_out;
-    wo[i] = (wv[i] ? n : 0) * p.Ktot;
+    wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;
   }
   u32x4 rp[PI], rw[WI];
-  const u32x4 zero = {0u, 0u, 0u, 0u};
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -95,26 +111,36 @@ conv_igemm_kernel(const ConvK p) {
   const int frow = lane & 15, fch = lane >> 4;
   const int sw_st = chunk ^ (lrow & 7);
   const int nk = (p.Ktot + 63) >> 6;
+  // this thread's chunk of the K axis as (tap row r, tap col s, channel c); advanced by 64 per step
+  int kc = chunk * 8, kr = 0, ks = 0;
+  while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
+  const int ldx2 = p.ldx * 2;
   // One code instance of load / compute / store: iteration kt = -1 only stages tile 0.
   for (int kt = -1; kt < nk; ++kt) {
     const bool stage = kt + 1 < nk;
-    if (stage) {                                     // global -> registers, tile kt+1
-      const int k = (kt + 1) * 64 + chunk * 8;
-      const bool kv = k < p.Ktot;
-      const int kk = kv ? k : 0;
-      const int tap = kk / p.C_in, c = kk - tap * p.C_in;
-      const int r = tap / p.S, s = tap - r * p.S;
+    if (stage) {                                     // global -> registers, tile kt+1 (branch-free)
+      const bool kv = kr < p.R;
+      if (!p.shift) {
+        const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;
 #pragma unroll
-      for (int i = 0; i < PI; ++i) {
-        int hn = hb[i] + r, wn_ = wb[i] + s;
-        bool ok = mv[i] && kv;
-        if (p.shift) { ok = ok && (((hn | wn_) & 1) == 0); hn >>= 1; wn_ >>= 1; }
-        ok = ok && ((unsigned)hn < (unsigned)p.H_in) && ((unsigned)wn_ < (unsigned)p.W_in);
-        rp[i] = ok ? *reinterpret_cast<const u32x4*>(p.x + xb[i] + (hn * p.W_in + wn_) * p.ldx + c) : zero;
+        for (int i = 0; i < PI; ++i) {
+          const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) && ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);
+          rp[i] = buf_load16(xr, ok ? (unsigned)(ro[i] + toff) : kOOB);
+        }
+      } else {                                       // transposed, stride 2: input dilated by 2
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+          const int hn = hb[i] + kr, wn_ = wb[i] + ks;
+          const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&
+                          ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);
+          rp[i] = buf_load16(xr, ok ? (unsigned)(ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : kOOB);
+        }
       }
+      const int kb = ((kt + 1) * 64 + chunk * 8) * 2;
 #pragma unroll
-      for (int i = 0; i < WI; ++i)
-        rw[i] = (wv[i] && kv) ? *reinterpret_cast<const u32x4*>(p.w + wo[i] + k) : zero;
+      for (int i = 0; i < WI; ++i) rw[i] = buf_load16(wr, (kv && wo[i] >= 0) ? (unsigned)(wo[i] + kb) : kOOB);
+      kc += 64;
+      while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
     }
     if (kt >= 0) {                                   // MFMA on tile kt
       const u32x4* cW = sW + (kt & 1) * BN * 8;
@@ -262,6 +288,254 @@ conv_igemm_kernel(const ConvK p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v2: the same GEMM, staged by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip) into a
+// 3-deep ring of 64-deep K tiles: tile t+2 is in flight while tile t is multiplied, so two tiles of
+// global latency are covered per block.  The LDS image is the XOR-swizzled [row][8 chunks] layout of
+// v1; because an LDS-DMA wave-instruction writes 64 consecutive 16-B slots (8 rows x 8 chunks), the
+// swizzle is applied to the SOURCE chunk each lane fetches (chunk = slot ^ (row & 7)).
+// Counted s_waitcnt vmcnt + raw s_barrier: nothing in the loop drains the DMA queue.
+// LDS-DMA: 16 B per lane from buffer offset `off` to lds_dst + lane (lds_dst wave-uniform); offsets
+// past the buffer write zeros.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, u32x4* lds_dst, int off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
+}
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WNW, int WMW>
+__global__ void __launch_bounds__(kThreads)
+conv_igemm3_kernel(const ConvK p) {
+  static_assert(WNW * WMW == 4, "four waves");
+  constexpr int TN = BN / WNW, TM = BM / WMW, NI = TN / 16, MI = TM / 16;
+  constexpr int PI = BM / 32, WI = BN / 32, NL = PI + WI;
+  constexpr int STAGE = (BM + BN) * 8;                 // 16-B slots per stage
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wn = wave % WNW, wm = wave / WNW;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ (lrow & 7);            // source chunk of this lane's LDS slot
+  int hb[PI], wb[PI], ro[PI];
+#pragma unroll
+  for (int i = 0; i < PI; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    const bool mv = m < p.M;
+    const unsigned mm = mv ? (unsigned)m : 0u;
+    const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), rem = (int)mm - img * p.HW_out;
+    const int oh = (int)fast_div((unsigned)rem, p.mg_w, p.sh_w), ow = rem - oh * p.W_out;
+    hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);
+    wb[i] = ow * p.mul - p.pad_l;
+    ro[i] = p.shift ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
+    if (p.pw && !mv) ro[i] = (int)kOOB;
+  }
+  int wo[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int n = n0 + lrow + 32 * i;
+    wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;
+  }
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  // fragment read offsets (16-B slots): row*8 + ((kk*4 + fch) ^ (row & 7)); row & 7 == frow & 7
+  const int fr0 = frow * 8 + (fch ^ (frow & 7));
+  const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
+  const int nk = (p.Ktot + 63) >> 6;
+  int kc = chunk * 8, kr = 0, ks = 0;
+  while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
+  const int ldx2 = p.ldx * 2;
+  int st_issue = 0, st_comp = 0;                        // ring positions
+  for (int it = -2; it < nk; ++it) {
+    const int lt = it + 2;
+    if (lt < nk) {                                      // LDS-DMA of tile lt into ring slot st_issue
+      u32x4* sp = smem + st_issue * STAGE + wave * 64;
+      const bool kv = kr < p.R;
+      if (p.pw) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+          const unsigned off = (kv && ro[i] >= 0) ? (unsigned)(ro[i] + kc * 2) : kOOB;
+          glds16(xr, sp + i * 256, (int)off);
+        }
+      } else if (!p.shift) {
+        const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+          const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) && ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);
+          glds16(xr, sp + i * 256, ok ? (ro[i] + toff) : (int)kOOB);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+          const int hn = hb[i] + kr, wn_ = wb[i] + ks;
+          const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&
+                          ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);
+          glds16(xr, sp + i * 256, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB);
+        }
+      }
+      const int kb = (lt * 64 + chunk * 8) * 2;
+      u32x4* sw = sp + BM * 8;
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        glds16(wr, sw + i * 256, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);
+      kc += 64;
+      while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
+      st_issue = st_issue == 2 ? 0 : st_issue + 1;
+    }
+    if (it >= 0) {                                      // MFMA on tile `it` (ring slot st_comp)
+      const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
+      const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int fr = kk ? fr1 : fr0;
+        bf16x8 wf[NI], pf[MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[a * 128 + fr]);
+#pragma unroll
+        for (int b = 0; b < MI; ++b) pf[b] = __builtin_bit_cast(bf16x8, cP[b * 128 + fr]);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+      }
+      st_comp = st_comp == 2 ? 0 : st_comp + 1;
+    }
+    if (it >= -1) {                                     // tile it+1 landed (own DMAs), then everyone's
+      if (lt < nk) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+      raw_barrier();
+    }
+  }
+  wait_vmcnt<0>();
+  // ---------------------------------------------------------------- epilogue
+  // lane: pixel = tile col (lane & 15), channels = (lane >> 4) * 4 + {0..3}
+  int yo[MI], so[MI];
+  bool mok[MI];
+#pragma unroll
+  for (int b = 0; b < MI; ++b) {
+    const int m = m0 + wm * TM + b * 16 + frow;
+    mok[b] = m < p.M;
+    const unsigned mm = mok[b] ? (unsigned)m : 0u;
+    const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), pix = (int)mm - img * p.HW_out;
+    yo[b] = img * p.y_img_stride + pix * p.ldy;
+    so[b] = img * p.skip_img_stride + pix * p.ld_skip;
+  }
+  float s1[NI][4], s2[NI][4];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    const int c0 = n0 + wn * TN + a * 16 + fch * 4;
+    if (c0 >= p.C_out) continue;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.epi == MBX_EPI_AFFINE || p.epi == MBX_EPI_RESIDUAL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (c0 + r < p.C_out) {
+          if (p.scale) sc[r] = p.scale[c0 + r];
+          if (p.shiftv) sh[r] = p.shiftv[c0 + r];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      if (!mok[b]) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if (p.epi == MBX_EPI_STORE_F32) {
+        float* yp = reinterpret_cast<float*>(p.y) + yo[b] + c0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r < p.C_out) yp[r] = v[r];
+        continue;
+      }
+      unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
+      if (p.epi == MBX_EPI_AFFINE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      } else if (p.epi == MBX_EPI_RESIDUAL) {
+        const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
+        const float k0 = bf2f(sk.x & 0xffffu), k1 = bf2f(sk.x >> 16), k2 = bf2f(sk.y & 0xffffu), k3 = bf2f(sk.y >> 16);
+        v[0] = k0 + p.rscale * (v[0] + sh[0]);
+        v[1] = k1 + p.rscale * (v[1] + sh[1]);
+        v[2] = k2 + p.rscale * (v[2] + sh[2]);
+        v[3] = k3 + p.rscale * (v[3] + sh[3]);
+      } else {
+        if (p.rscale != 0.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
+        }
+      }
+      if (p.epi == MBX_EPI_STORE && p.accumulate) {
+        const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
+        v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
+        v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      unsigned short q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
+      *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
+      if (p.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
+      }
+    }
+  }
+
+  if (p.stats) {
+    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes,
+    // then over the WMW pixel-waves through LDS (free after the K loop's last barrier).
+    float* red = reinterpret_cast<float*>(smem);   // [WMW][BN][2]
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x1 = s1[a][r], x2 = s2[a][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        if (frow == 0) {
+          const int cl = wn * TN + a * 16 + fch * 4 + r;
+          red[(wm * BN + cl) * 2 + 0] = x1;
+          red[(wm * BN + cl) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.C_out) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+      float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
+      o[0] = x1;
+      o[1] = x2;
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------- weight gradient
 // dW[n][kc] += sum_m dY[m][n] * P[m][kc]; GEMM whose reduction runs over PIXELS, the slow NHWC
 // dimension of both operands: tiles are staged [pixel][channel] exactly as they lie in HBM and
@@ -272,6 +546,9 @@ struct WgradK {
   const unsigned short* dy; int dy_img_stride, ld_dy;
   int C_out, S, Ktot, stride, pad_t, pad_l, W_out, HW_out, M;
   float* dw; float* db; float scale;
+  unsigned x_bytes, dy_bytes;
+  unsigned mg_hw, sh_hw, mg_w, sh_w;     // magic-number division by HW_out and W_out
+  int H_out;
   int tiles_n, tiles_k, m_per_split;
 };
 
@@ -299,28 +576,33 @@ conv_wgrad_kernel(const WgradK p) {
   __shared__ __attribute__((aligned(16))) unsigned short sX[2][64 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_k = blockIdx.x / p.tiles_n;
+  // 1-D grid, XCD-aware: all (n, k) tiles of one pixel split run on one XCD, so the split's dy / x
+  // panels are fetched into that L2 once instead of once per XCD.
+  const int ntiles = p.tiles_n * p.tiles_k;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles, split = lid / ntiles;
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
-  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
 
   const int lrow = tid >> 2, cq = tid & 3;           // row 0..63, chunks cq + 4*i
   // fixed per-thread k-column decode (chunk of 8 input channels at one tap)
-  int tr_[4], ts_[4], tc_[4];
-  bool kv[4], nv[4];
+  int tr_[4], ts_[4], toff[4], yoff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = k0 + (cq + 4 * i) * 8;
-    kv[i] = k < p.Ktot;
-    const int kk = kv[i] ? k : 0;
-    const int tap = kk / p.C_in;
-    tc_[i] = kk - tap * p.C_in;
-    tr_[i] = tap / p.S;
-    ts_[i] = tap - tr_[i] * p.S;
-    nv[i] = n0 + (cq + 4 * i) * 8 < p.C_out;
+    const bool kv = k < p.Ktot;
+    const int kk = kv ? k : 0;
+    const int tap = kk / p.C_in, tc = kk - tap * p.C_in;
+    tr_[i] = kv ? tap / p.S : (1 << 24);              // invalid columns fail the bounds check
+    ts_[i] = tap - (tap / p.S) * p.S;
+    toff[i] = ((tr_[i] * p.W_in + ts_[i]) * p.ldx + tc) * 2;
+    yoff[i] = (n0 + (cq + 4 * i) * 8 < p.C_out) ? (n0 + (cq + 4 * i) * 8) * 2 : -1;
   }
   u32x4 ry[4], rx[4];
-  const u32x4 zero = {0u, 0u, 0u, 0u};
   f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -337,18 +619,17 @@ conv_wgrad_kernel(const WgradK p) {
     if (stage) {
       const int m = ms + 64 + lrow;
       const bool mv = m < m_end;
-      const int mm = mv ? m : 0;
-      const int img = mm / p.HW_out, pix = mm - img * p.HW_out;
-      const int oh = pix / p.W_out, ow = pix - oh * p.W_out;
-      const int hb = oh * p.stride - p.pad_t, wb = ow * p.stride - p.pad_l;
-      const unsigned short* yrow = p.dy + img * p.dy_img_stride + pix * p.ld_dy + n0;
-      const unsigned short* ximg = p.x + img * p.x_img_stride;
+      const unsigned mm = mv ? (unsigned)m : 0u;
+      const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), pix = (int)mm - img * p.HW_out;
+      const int oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w), ow = pix - oh * p.W_out;
+      const int hb = mv ? oh * p.stride - p.pad_t : -(1 << 25), wb = ow * p.stride - p.pad_l;
+      const int xrow = (img * p.x_img_stride + (hb * p.W_in + wb) * p.ldx) * 2;
+      const int yrow = (img * p.dy_img_stride + pix * p.ld_dy) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ry[i] = (mv && nv[i]) ? *reinterpret_cast<const u32x4*>(yrow + (cq + 4 * i) * 8) : zero;
-        const int h = hb + tr_[i], w = wb + ts_[i];
-        const bool ok = mv && kv[i] && ((unsigned)h < (unsigned)p.H_in) && ((unsigned)w < (unsigned)p.W_in);
-        rx[i] = ok ? *reinterpret_cast<const u32x4*>(ximg + (h * p.W_in + w) * p.ldx + tc_[i]) : zero;
+        ry[i] = buf_load16(yr, (mv && yoff[i] >= 0) ? (unsigned)(yrow + yoff[i]) : kOOB);
+        const bool ok = ((unsigned)(hb + tr_[i]) < (unsigned)p.H_in) && ((unsigned)(wb + ts_[i]) < (unsigned)p.W_in);
+        rx[i] = buf_load16(xr, ok ? (unsigned)(xrow + toff[i]) : kOOB);
       }
     }
     if (it >= 0) {
@@ -400,6 +681,164 @@ conv_wgrad_kernel(const WgradK p) {
   if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad v2: same tiling and transpose-read MFMA loop, tiles staged by LDS-DMA into an NST-deep ring.
+// One DMA wave-instruction fills 4 rows x 16 chunks; the swizzle moves to the source chunk
+// (chunk = slot ^ swz(row), constant per lane because row & 3 and row bit 3 are lane constants).
+// Pixel rows advance by 16 per instruction: decoded once, then stepped incrementally; 1x1 convs
+// (contiguous pixel rows) take a two-instruction address path.  Fragment addresses are per-lane
+// constants + immediates.
+struct WgradK2 {
+  WgradK b;
+  int pw;            // x rows contiguous: offset = m * ldx (1x1, stride 1, no padding, dense images)
+  int ydense;        // dy rows contiguous: offset = m * ld_dy
+};
+
+template <int NST>
+__global__ void __launch_bounds__(kThreads)
+conv_wgrad2_kernel(const WgradK2 q) {
+  const WgradK& p = q.b;
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];     // [NST][Y 64x16 | X 64x16] slots
+  constexpr int STAGE = 2 * 64 * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int wn = wave & 1, wk = wave >> 1;
+  const int ntiles = p.tiles_n * p.tiles_k;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles, split = lid / ntiles;
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
+
+  // ---- DMA lane constants
+  const int r4 = lane >> 4;                                   // row within the 4-row piece
+  const int swz = ((r4 & 3) | (((wave >> 1) & 1) << 2)) << 1; // swz(row) for rows 16*i + 4*wave + r4
+  const int lc = (lane & 15) ^ swz;                           // logical chunk this lane fetches
+  const int kcol = k0 + lc * 8;
+  const bool kvalid = kcol < p.Ktot;
+  const int tap = (kvalid ? kcol : 0) / p.C_in, tc = (kvalid ? kcol : 0) - tap * p.C_in;
+  const int tr = kvalid ? tap / p.S : (1 << 24), ts = tap - (tap / p.S) * p.S;
+  const int toff = ((tr * p.W_in + ts) * p.ldx + tc) * 2;
+  const int ycol = (n0 + lc * 8 < p.C_out) ? (n0 + lc * 8) * 2 : -1;
+  const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
+  // running pixel = next row this lane will fetch (advances by 16 per DMA instruction)
+  int m_run = m_begin + wave * 4 + r4;
+  int img = 0, oh = 0, ow = 0;
+  {
+    const unsigned mm = (unsigned)min(m_run, p.M - 1);
+    img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+    const int pix = (int)mm - img * p.HW_out;
+    oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w);
+    ow = pix - oh * p.W_out;
+  }
+
+  // ---- fragment (transpose-read) lane constants, byte offsets inside a 16 KB tile
+  const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
+  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
+  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
+  int yo[4], xo[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    yo[a] = lb + (((2 * (wn * 4 + a) + (pp >> 1)) ^ sx) << 4);
+    xo[a] = lb + (((2 * (wk * 4 + a) + (pp >> 1)) ^ sx) << 4) + 64 * 256;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
+
+  const int nsteps = (m_end - m_begin + 63) >> 6;
+  int st_issue = 0, st_comp = 0;
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  for (int it = 1 - NST; it < nsteps; ++it) {
+    const int lt = it + NST - 1;
+    if (lt < nsteps) {                                  // DMA of pixel step lt into ring slot st_issue
+      u32x4* sp = smem + st_issue * STAGE + wave * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool mv = m_run < m_end;
+        int xoff, yoff;
+        if (q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;
+        else {
+          const int hb = oh * p.stride - p.pad_t + tr, wb = ow * p.stride - p.pad_l + ts;
+          const bool ok = mv && ((unsigned)hb < (unsigned)p.H_in) && ((unsigned)wb < (unsigned)p.W_in);
+          xoff = ok ? ((img * p.x_img_stride + ((oh * p.stride - p.pad_t) * p.W_in + ow * p.stride - p.pad_l) * p.ldx) * 2 + toff) : (int)kOOB;
+        }
+        if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;
+        else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB;
+        glds16(yr, sp + i * 256, yoff);
+        glds16(xr, sp + 1024 + i * 256, xoff);
+        m_run += 16;
+        if (!(q.pw && q.ydense)) {                      // step the pixel coordinates by 16
+          ow += 16;
+          while (ow >= p.W_out) { ow -= p.W_out; ++oh; }
+          while (oh >= p.H_out) { oh -= p.H_out; ++img; }
+        }
+      }
+      st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;
+    }
+    if (it >= 0) {
+      const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 yf[4], xf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192 + 1024));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          yf[a] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192 + 1024));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          xf[b] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+      }
+      if (do_bias) {
+        const unsigned short* cY = reinterpret_cast<const unsigned short*>(base);
+        const int ch = tid >> 3, e = tid & 7;
+        for (int r = 0; r < 64; ++r) bsum += bf2f(cY[r * 128 + ((ch ^ wg_swz(r)) << 3) + e]);
+      }
+      st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
+    }
+    if (it >= -1) {
+      if (NST == 3) { if (lt < nsteps) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+      else wait_vmcnt<0>();
+      raw_barrier();
+    }
+  }
+  wait_vmcnt<0>();
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
+      if (kc >= p.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+    }
+  }
+  if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
+}
+
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f}};
@@ -410,7 +849,7 @@ int pick_cfg(long M, int C_out) {
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
     const TileCfg& c = kCfgs[i];
     const long tiles = ((M + c.BM - 1) / c.BM) * ((C_out + c.BN - 1) / c.BN);
-    const long lds = 2L * (c.BM + c.BN) * 128;
+    const long lds = 3L * (c.BM + c.BN) * 128;
     long per_cu = (160 * 1024) / lds;
     if (per_cu > 2) per_cu = 2;
     const long rounds = (tiles + 256 * per_cu - 1) / (256 * per_cu);
@@ -420,20 +859,50 @@ int pick_cfg(long M, int C_out) {
   return best;
 }
 
+bool use_v1() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MBX_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+int choose_cfg(long M, int C_out) {
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
+  return force >= 0 ? force : pick_cfg(M, C_out);
+}
+
 template <int BM, int BN, int WNW, int WMW>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
-  const size_t lds = 2 * (size_t)(BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  if (use_v1()) {
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
+  } else {
+    const size_t lds = 3 * (size_t)(BM + BN) * 128;
+    static bool attr_set3 = false;
+    if (!attr_set3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set3 = true;
+    }
+    hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
+}
+
+void set_magic(unsigned d, unsigned& mg, unsigned& sh) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  sh = 31 + l;
+  mg = (unsigned)((1ull << sh) / d + 1);
 }
 
 int check_desc(const mbx_conv_desc* d) {
@@ -443,7 +912,7 @@ int check_desc(const mbx_conv_desc* d) {
   if (d->stride != 1 && d->stride != 2) return MBX_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(d->x) & 15)) return MBX_ERR_INVALID_ARG;
   const long long xe = (long long)d->N * d->x_img_stride;
-  if (xe >= (1LL << 31) || (long long)d->N * d->H_out * d->W_out >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  if (xe >= (1LL << 30) || (long long)d->N * d->H_out * d->W_out >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
   return MBX_OK;
 }
 
@@ -452,7 +921,7 @@ int check_desc(const mbx_conv_desc* d) {
 extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   if (!d) return MBX_ERR_INVALID_ARG;
   const long M = (long)d->N * d->H_out * d->W_out;
-  const TileCfg& c = kCfgs[pick_cfg(M, d->C_out)];
+  const TileCfg& c = kCfgs[choose_cfg(M, d->C_out)];
   return (int)((M + c.BM - 1) / c.BM);
 }
 
@@ -472,7 +941,9 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   k.x = reinterpret_cast<const unsigned short*>(d->x);
   k.x_img_stride = (int)d->x_img_stride; k.ldx = d->ldx; k.H_in = d->H_in; k.W_in = d->W_in; k.C_in = d->C_in;
   k.w = reinterpret_cast<const unsigned short*>(d->w);
-  k.C_out = d->C_out; k.S = d->S; k.Ktot = d->R * d->S * d->C_in;
+  k.C_out = d->C_out; k.R = d->R; k.S = d->S; k.Ktot = d->R * d->S * d->C_in;
+  k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
+  k.w_bytes = (unsigned)(2LL * d->C_out * k.Ktot);
   if (d->transposed) { k.mul = 1; k.shift = d->stride == 2 ? 1 : 0; } else { k.mul = d->stride; k.shift = 0; }
   k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
   k.M = d->N * k.HW_out;
@@ -482,8 +953,11 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   k.skip = reinterpret_cast<const unsigned short*>(d->skip);
   k.skip_img_stride = (int)d->skip_img_stride; k.ld_skip = d->ld_skip; k.rscale = d->rscale;
   k.stats = d->stats_partial;
+  set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
+  set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
+  k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
   hipStream_t s = mbx_s(stream);
-  switch (pick_cfg(k.M, k.C_out)) {
+  switch (choose_cfg(k.M, k.C_out)) {
     case 0: return launch_igemm<128, 128, 2, 2>(k, s);
     case 1: return launch_igemm<128, 64, 2, 2>(k, s);
     case 2: return launch_igemm<64, 128, 2, 2>(k, s);
@@ -498,7 +972,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   if (st != MBX_OK) return st;
   if (!dy || !dw || d->transposed) return MBX_ERR_INVALID_ARG;
   if (ld_dy % 8 || ld_dy < ((d->C_out + 7) / 8) * 8 || (reinterpret_cast<uintptr_t>(dy) & 15)) return MBX_ERR_INVALID_ARG;
-  if ((long long)d->N * dy_img_stride >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  if ((long long)d->N * dy_img_stride >= (1LL << 30)) return MBX_ERR_UNSUPPORTED;
   MBX_ENTER();
   WgradK k;
   k.x = reinterpret_cast<const unsigned short*>(d->x);
@@ -512,7 +986,9 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.tiles_k = (k.Ktot + 127) / 128;
   const int tiles = k.tiles_n * k.tiles_k;
   // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
-  int splits = (512 + tiles - 1) / tiles;
+  static int target = 0;
+  if (!target) { const char* e = getenv("MBX_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+  int splits = target / tiles;                 // floor: all blocks resident in one round (2 per CU)
   const int max_splits = (k.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -520,7 +996,39 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   mps = ((mps + 63) / 64) * 64;
   splits = (k.M + mps - 1) / mps;
   k.m_per_split = mps;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(kThreads), 0, mbx_s(stream), k);
+  auto magic = [](unsigned d, unsigned& mg, unsigned& sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    sh = 31 + l;
+    mg = (unsigned)((1ull << sh) / d + 1);
+  };
+  magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
+  magic((unsigned)k.W_out, k.mg_w, k.sh_w);
+  k.H_out = d->H_out;
+  k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
+  k.dy_bytes = (unsigned)(2 * ((long long)(d->N - 1) * dy_img_stride + ((long long)k.HW_out - 1) * ld_dy + ((d->C_out + 7) / 8) * 8));
+  static int v1 = -1, nst = 2;
+  if (v1 < 0) {
+    const char* e = getenv("MBX_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0;
+    const char* n = getenv("MBX_WGRAD_NST"); if (n) nst = atoi(n) == 3 ? 3 : 2;
+  }
+  if (v1) {
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(kThreads), 0, mbx_s(stream), k);
+  } else {
+    WgradK2 k2;
+    k2.b = k;
+    k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
+             d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
+    k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
+    static bool attr2 = false, attr3 = false;
+    if (nst == 3) {
+      if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768); attr3 = true; }
+      hipLaunchKernelGGL(conv_wgrad2_kernel<3>, dim3(tiles * splits), dim3(kThreads), 3 * 32768, mbx_s(stream), k2);
+    } else {
+      if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); attr2 = true; }
+      hipLaunchKernelGGL(conv_wgrad2_kernel<2>, dim3(tiles * splits), dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
+    }
+  }
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

@@ -32,23 +32,20 @@ inline int grid_for(long long work_items) {
 }
 
 // ------------------------------------------------------------------ batch norm: finalize
+// one wave per channel: 64 lanes stride over the partial rows, then a wave reduction.
 __global__ void __launch_bounds__(kT)
 bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_count, float eps, float decay,
                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ mmean,
                    float* __restrict__ mvar) {
-  __shared__ double red[16][16][2];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += 16) {
-      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
-      s1 += v.x; s2 += v.y;
-    }
-  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    for (int r = 1; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+  for (int r = lane; r < rows; r += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
+    s1 += v.x; s2 += v.y;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) {
     const double m = s1 * inv_count;
     double var = s2 * inv_count - m * m;
     if (var < 0.0) var = 0.0;
@@ -157,19 +154,15 @@ bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const uns
 __global__ void __launch_bounds__(kT)
 bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_M, float* __restrict__ dbeta,
                        float* __restrict__ m12) {
-  __shared__ double red[16][16][2];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += 16) {
-      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
-      s1 += v.x; s2 += v.y;
-    }
-  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    for (int r = 1; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+  for (int r = lane; r < rows; r += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
+    s1 += v.x; s2 += v.y;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) {
     if (dbeta) dbeta[c] += (float)s1;
     m12[c] = (float)(s1 * inv_M);
     m12[C + c] = (float)(s2 * inv_M);
@@ -483,7 +476,7 @@ extern "C" int mbx_bn_finalize(const float* part, int rows, int C, int64_t count
                                float* rstd, float* mmean, float* mvar, mbx_stream_t stream) {
   if (!part || !mean || !rstd || rows <= 0 || C <= 0 || count <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, mbx_s(stream), part, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, mbx_s(stream), part, rows, C,
                      1.0 / (double)count, eps, decay, mean, rstd, mmean, mvar);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
@@ -533,7 +526,7 @@ extern "C" int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_
                                    mbx_stream_t stream) {
   if (!partial || !m12 || rows <= 0 || C <= 0 || M <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, mbx_s(stream), partial, rows, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, mbx_s(stream), partial, rows, C,
                      1.0 / (double)M, dbeta, m12);
   MBX_LAUNCH_CHECK();
   return MBX_OK;

@@ -68,8 +68,11 @@ class ConvOp:
 
 class Net:
     def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
-                 bn_decay=0.9997):
+                 bn_decay=0.9997, repeats=(10, 20, 9)):
+        """repeats: number of block35 / block17 / block8 repetitions (model.py:142,162,187); anything
+        but the reference's (10, 20, 9) is a reduced-depth network for tests."""
         assert mode in ("train", "infer")
+        self.repeats = tuple(repeats)
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
         self.convs, self.fwd, self.bwd = [], [], []
@@ -165,7 +168,7 @@ class Net:
         # ---- 10 x block35 (model.py:6-24), scale 0.17
         trunk0 = net
         zg = None
-        for i in range(1, 11):
+        for i in range(1, self.repeats[0] + 1):
             Q = P + "Repeat/block35_%d/" % i
             z = self.alloc(s5, s5, 240)     # [t1 32 | t2 32 | b0 32 | b1 32 | b2 64 | b2a 48]
             if zg is None:
@@ -198,7 +201,7 @@ class Net:
 
         # ---- 20 x block17 (model.py:27-44), scale 0.10
         trunk0, zg = net, None
-        for i in range(1, 21):
+        for i in range(1, self.repeats[1] + 1):
             Q = P + "Repeat_1/block17_%d/" % i
             z = self.alloc(s6, s6, 672)     # [t1 128 | b0 192 | b1_2 192 | b1_1 160]
             if zg is None:
@@ -230,8 +233,9 @@ class Net:
 
         # ---- 9 x block8 (scale 0.20) + Block8 without relu at scale 1.0 (model.py:187-188)
         trunk0, zg = net, None
-        for i in range(1, 11):
-            Q = P + ("Repeat_2/block8_%d/" % i if i < 10 else "Block8/")
+        n8 = self.repeats[2] + 1
+        for i in range(1, n8 + 1):
+            Q = P + ("Repeat_2/block8_%d/" % i if i < n8 else "Block8/")
             z = self.alloc(s7, s7, 864)     # [t1 192 | b0 192 | b1_2 256 | b1_1 224]
             if zg is None:
                 zg = z
@@ -241,7 +245,7 @@ class Net:
             self.conv([(Q + "Branch_1/Conv2d_0b_1x3", 224)], z.slice(0, 192), z.slice(640, 224), 1, 3)
             self.conv([(Q + "Branch_1/Conv2d_0c_3x1", 256)], z.slice(640, 224), z.slice(384, 256), 3, 1)
             out = self.alloc(s7, s7, 2080)
-            self.residual(Q + "Conv2d_1x1", z.slice(192, 448), net, out, 0.20 if i < 10 else 1.0, i < 10, trunk0)
+            self.residual(Q + "Conv2d_1x1", z.slice(192, 448), net, out, 0.20 if i < n8 else 1.0, i < n8, trunk0)
             net = out
         feat = self.alloc(s7, s7, 1536)
         self.conv([(P + "Conv2d_7b_1x1", 1536)], net, feat, 1, 1)

@@ -31,8 +31,10 @@ def _same(n, k, s):
 
 
 class Model:
-    def __init__(self, params, k=5, bn_training=True, heads_bn_training=None, q=None, bn_decay=0.9997):
+    def __init__(self, params, k=5, bn_training=True, heads_bn_training=None, q=None, bn_decay=0.9997,
+                 repeats=(10, 20, 9)):
         self.P, self.k, self.q = params, k, (q or (lambda t: t))
+        self.repeats = repeats              # model.py:142,162,187 use (10, 20, 9); smaller = reduced-depth test net
         self.bn_training = bn_training
         self.heads_bn_training = bn_training if heads_bn_training is None else heads_bn_training
         self.bn_decay = bn_decay
@@ -117,7 +119,7 @@ class Model:
         b3 = c(self.q(self.avg_pool_same3(net)), Q + "Branch_3/Conv2d_0b_1x1", 1)
         net = torch.cat([b0, b1, b2, b3], 1)
         self.endpoints["Mixed_5b"] = net
-        for i in range(1, 11):
+        for i in range(1, self.repeats[0] + 1):
             net = self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)
         self.endpoints["block35_10"] = net
         Q = P + "Mixed_6a/"
@@ -125,7 +127,7 @@ class Model:
         b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
         net = torch.cat([b0, b1, F.max_pool2d(net, 3, 2)], 1)
         self.endpoints["Mixed_6a"] = net
-        for i in range(1, 21):
+        for i in range(1, self.repeats[1] + 1):
             net = self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)
         self.endpoints["block17_20"] = net
         Q = P + "Mixed_7a/"
@@ -134,7 +136,7 @@ class Model:
         b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_1a_3x3", 3, 2, "VALID")
         net = torch.cat([b0, b1, b2, F.max_pool2d(net, 3, 2)], 1)
         self.endpoints["Mixed_7a"] = net
-        for i in range(1, 10):
+        for i in range(1, self.repeats[2] + 1):
             net = self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)
         net = self.block(net, P + "Block8/", 1.0, False, 8)          # model.py:188
         net = c(net, P + "Conv2d_7b_1x1", 1)

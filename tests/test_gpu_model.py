@@ -112,22 +112,66 @@ def test_forward_backward_parity(env):
     assert torch.allclose(net.get_param(name + "/BatchNorm/moving_mean").cpu(), mm_new, rtol=2e-2, atol=1e-5)
     assert torch.allclose(net.get_param(name + "/BatchNorm/moving_variance").cpu(), mv_new, rtol=2e-2, atol=1e-5)
     assert not torch.equal(mm0, net.MM)
-    # ---- backward, full depth: no worse than the inherent bf16 sensitivity
+    # ---- backward, full depth: a 100-layer random-init BN net at batch 2 is chaotic (the two oracles
+    # themselves disagree at cos 0.6-0.85), so only sanity is asserted here; the tight end-to-end
+    # gradient check runs on the reduced-depth network below, per-kernel checks in test_gpu_conv/nnops.
     names = [n for n in net.param_index if n.endswith(("/weights", "/biases", "/beta"))]
     gq = {n: res["q"][0][n].grad for n in names}
-    gf = {n: res["f32"][0][n].grad for n in names}
     ge = {n: net.get_param(n, "grad").detach().float().cpu() for n in names}
-    big = [n for n in names if float(gq[n].norm()) > 1e-3 * np.median([float(gq[m_].norm()) for m_ in names])]
+    assert all(bool(torch.isfinite(ge[n]).all()) for n in names)
+    med = np.median([float(gq[m_].norm()) for m_ in names])
+    big = [n for n in names if float(gq[n].norm()) > 1e-3 * med]
     assert len(big) > 400
-    cat = lambda d: torch.cat([d[n].reshape(-1) for n in big])
-    assert rel_l2(cat(ge), cat(gq)) <= rel_l2(cat(gq), cat(gf)), "whole gradient"
-    c_eng = np.array([_cos(ge[n], gq[n]) for n in big])
-    c_inh = np.array([_cos(gq[n], gf[n]) for n in big])
-    assert np.median(c_eng) >= np.median(c_inh) and np.percentile(c_eng, 10) >= np.percentile(c_inh, 10), (np.median(c_eng), np.median(c_inh))
-    assert np.median(c_eng) > 0.7
-    # gradient magnitudes agree (a missing scale factor would show here)
     ratio = np.array([float(ge[n].norm() / gq[n].norm()) for n in big])
-    assert 0.7 < np.median(ratio) < 1.3, np.median(ratio)
+    assert 0.5 < np.median(ratio) < 2.0, np.median(ratio)              # a missing scale factor would show here
+    heads = [n for n in big if n.startswith("Multibox/")]
+    assert np.median([_cos(ge[n], gq[n]) for n in heads]) > 0.8
+
+
+def test_reduced_depth_gradients(env):
+    """Same graph builder, block repeats (2, 2, 1) instead of (10, 20, 9): every kind of op, slice,
+    accumulate flag and in-place trunk gradient is exercised, but the net is shallow enough for a tight
+    end-to-end gradient comparison: per tensor cos > 0.97 and rel L2 < 0.25, whole gradient rel L2 < 0.1."""
+    torch = env["torch"]
+    from multibox_amd.engine import Net
+    from multibox_amd.loss import MultiboxLoss
+    from oracle.torch_model import Model, q_bf16, multibox_loss
+    B, reps = 4, (2, 2, 1)
+    net = Net(batch=B, input_size=299, k=5, mode="train", seed=11, repeats=reps)
+    gen = torch.Generator().manual_seed(12)
+    net.Bt.copy_((torch.randn(net.nBt, generator=gen) * 0.1).cuda())
+    images = torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1
+    rng = np.random.RandomState(13)
+    n_gt = np.array([3, 1, 0, 5], np.int32)
+    gt = np.zeros((B, 13, 4), np.float32)
+    for b in range(B):
+        xy = rng.uniform(0, .7, (n_gt[b], 2)); wh = rng.uniform(.05, .3, (n_gt[b], 2))
+        gt[b, :n_gt[b], :2] = xy; gt[b, :n_gt[b], 2:] = xy + wh
+    P = {k_: v.requires_grad_(True) for k_, v in oracle_params(torch, net).items()}
+    net.set_input(images.cuda())
+    net.forward()
+    ml = MultiboxLoss(env["priors"], B, 13, 10.0)
+    ml.d_locs, ml.d_logits = net.d_locs, net.d_logits
+    ml.forward_backward(net.locs, net.logits, torch.from_numpy(gt).cuda(), torch.from_numpy(n_gt).cuda())
+    net.zero_grads()
+    net.backward()
+    torch.cuda.synchronize()
+    m = Model(P, k=5, bn_training=True, q=q_bf16, repeats=reps)
+    rl, rz = m.build(images)
+    for k_, v in net.endpoints.items():
+        assert rel_l2(v.tensor().float().cpu().permute(0, 3, 1, 2), m.endpoints[k_].detach()) < 2e-2, k_
+    loc, conf = multibox_loss(rl, rz, torch.from_numpy(env["priors"]), torch.from_numpy(gt), ml.match.cpu().numpy(), 10.0)
+    (loc + conf).backward()
+    names = [n for n in net.param_index if n.endswith(("/weights", "/biases", "/beta"))]
+    gq = {n: P[n].grad for n in names}
+    ge = {n: net.get_param(n, "grad").detach().float().cpu() for n in names}
+    med = np.median([float(gq[n].norm()) for n in names])
+    big = [n for n in names if float(gq[n].norm()) > 1e-2 * med]
+    assert len(big) > 0.9 * len(names) - 2
+    worst = sorted(((_cos(ge[n], gq[n]), rel_l2(ge[n], gq[n]), n) for n in big))[:6]
+    assert worst[0][0] > 0.97 and max(w[1] for w in worst) < 0.25, worst
+    cat = lambda d: torch.cat([d[n].reshape(-1) for n in big])
+    assert rel_l2(cat(ge), cat(gq)) < 0.1
 
 
 def test_head_gradients_tight(env):
