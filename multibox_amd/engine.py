@@ -523,12 +523,14 @@ class Net:
         self.filter_blocks, self.filter_entries = blocks, len(entries)
 
         L = []
+        self.bwd_ops = []          # the forward op each backward launch belongs to (same order as L)
         for op in reversed(self.fwd):
             if isinstance(op, PoolOp):
                 if op.needs_backward():
                     gx = self._gview(op.x)
                     acc = self._claim(gx)
                     L.append(op.make_backward(self._gview(op.out), gx, acc))
+                    self.bwd_ops.append(op)
                 continue
             if not op.trainable:
                 continue
@@ -592,6 +594,7 @@ class Net:
                 if ddesc is not None:
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
             L.append(run)
+            self.bwd_ops.append(op)
         self.bwd_launches = L
         self.fwd_launches = self._build_forward_launches()
 

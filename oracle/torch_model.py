@@ -101,8 +101,9 @@ class Model:
         s = F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
         return s
 
-    def backbone(self, x):
-        """model.py:67-196.  x [B,3,S,S]."""
+    # The backbone in four stages (each also callable on its own for stage-wise gradient tests).
+    def stem(self, x):
+        """model.py:92-117: images [B,3,S,S] -> MaxPool_5a_3x3."""
         c, P = self.conv, "InceptionResnetV2/"
         net = c(x, P + "Conv2d_1a_3x3", 3, 2, "VALID")
         net = c(net, P + "Conv2d_2a_3x3", 3, 1, "VALID")
@@ -110,8 +111,11 @@ class Model:
         net = F.max_pool2d(net, 3, 2)
         net = c(net, P + "Conv2d_3b_1x1", 1, 1, "VALID")
         net = c(net, P + "Conv2d_4a_3x3", 3, 1, "VALID")
-        net = F.max_pool2d(net, 3, 2)
-        self.endpoints["MaxPool_5a_3x3"] = net
+        return F.max_pool2d(net, 3, 2)
+
+    def stage35(self, net):
+        """model.py:120-142: Mixed_5b + block35 x repeats[0]."""
+        c, P = self.conv, "InceptionResnetV2/"
         Q = P + "Mixed_5b/"
         b0 = c(net, Q + "Branch_0/Conv2d_1x1", 1)
         b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_5x5", 5)
@@ -121,7 +125,11 @@ class Model:
         self.endpoints["Mixed_5b"] = net
         for i in range(1, self.repeats[0] + 1):
             net = self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)
-        self.endpoints["block35_10"] = net
+        return net
+
+    def stage17(self, net):
+        """model.py:145-162: Mixed_6a + block17 x repeats[1]."""
+        c, P = self.conv, "InceptionResnetV2/"
         Q = P + "Mixed_6a/"
         b0 = c(net, Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
         b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
@@ -129,7 +137,11 @@ class Model:
         self.endpoints["Mixed_6a"] = net
         for i in range(1, self.repeats[1] + 1):
             net = self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)
-        self.endpoints["block17_20"] = net
+        return net
+
+    def stage8(self, net):
+        """model.py:164-192: Mixed_7a + block8 x repeats[2] + Block8 (no relu, scale 1) + Conv2d_7b_1x1."""
+        c, P = self.conv, "InceptionResnetV2/"
         Q = P + "Mixed_7a/"
         b0 = c(c(net, Q + "Branch_0/Conv2d_0a_1x1", 1), Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
         b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
@@ -139,7 +151,17 @@ class Model:
         for i in range(1, self.repeats[2] + 1):
             net = self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)
         net = self.block(net, P + "Block8/", 1.0, False, 8)          # model.py:188
-        net = c(net, P + "Conv2d_7b_1x1", 1)
+        return c(net, P + "Conv2d_7b_1x1", 1)
+
+    def backbone(self, x):
+        """model.py:67-196.  x [B,3,S,S]."""
+        net = self.stem(x)
+        self.endpoints["MaxPool_5a_3x3"] = net
+        net = self.stage35(net)
+        self.endpoints["block35_10"] = net
+        net = self.stage17(net)
+        self.endpoints["block17_20"] = net
+        net = self.stage8(net)
         self.endpoints["Conv2d_7b_1x1"] = net
         return net
 
