@@ -119,7 +119,8 @@ int mbx_decode_filter_topk(const float* raw_locs /*[B,P,4]*/, const float* conf 
  * the spatially flipped, channel-transposed filter ([C_in][R][S][C_out], see
  * mbx_filter_prepare) and an input dilated by `stride`.                                 */
 typedef enum {
-  MBX_EPI_STORE = 0,    /* y = acc                     (bf16; pre-BN activations, gradients) */
+  MBX_EPI_STORE = 0,    /* y = acc [* rscale] [+ y if accumulate] [* (skip > 0): relu backward mask]
+                           (bf16; pre-BN activations, gradients)                           */
   MBX_EPI_AFFINE = 1,   /* y = act(acc*scale[c] + shift[c])       (frozen / folded batch norm) */
   MBX_EPI_RESIDUAL = 2, /* y = act(skip + rscale*(acc + shift[c]))           (model.py:19-23) */
   MBX_EPI_STORE_F32 = 3 /* y = acc as float32            (head outputs, model.py:213-293)     */

@@ -36,10 +36,21 @@ struct ConvK {
   float* stats;
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
-  int pw;                              // pointwise: R = S = 1, no padding, unit stride, not transposed
+  int pw;                              // pointwise: R = S = 1, no padding, unit stride
+  int dbg;                             // ablation bits (MBX_DBG): 1 no stores, 2 no DMA, 4 no MFMA, 8 no stats
 };
 
 constexpr int kThreads = 256;
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): four v_add_f32_dpp row_ror, every lane
+// ends up with the row sum -- no LDS traffic (ds_bpermute shuffles made the epilogue VALU/LDS-bound).
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
+}
 // exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
 __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
   return (unsigned)(((unsigned long long)m * magic) >> shift);
@@ -267,9 +278,7 @@ conv_igemm_kernel(const ConvK p) {
     for (int a = 0; a < NI; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x1 = s1[a][r], x2 = s2[a][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
         if (frow == 0) {
           const int cl = wn * TN + a * 16 + fch * 4 + r;
           red[(wm * BN + cl) * 2 + 0] = x1;
@@ -307,7 +316,10 @@ __device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WNW, int WMW>
+// EV: epilogue variant fixed at compile time (no per-element branching):
+//   0 store, 1 store + BN statistics partials, 2 accumulate into y (+ optional relu mask from `skip`),
+//   3 affine (+relu), 4 residual (+relu), 5 float32 store.
+template <int BM, int BN, int WNW, int WMW, int EV>
 __global__ void __launch_bounds__(kThreads)
 conv_igemm3_kernel(const ConvK p) {
   static_assert(WNW * WMW == 4, "four waves");
@@ -364,7 +376,7 @@ conv_igemm3_kernel(const ConvK p) {
   int st_issue = 0, st_comp = 0;                        // ring positions
   for (int it = -2; it < nk; ++it) {
     const int lt = it + 2;
-    if (lt < nk) {                                      // LDS-DMA of tile lt into ring slot st_issue
+    if (lt < nk) {          // LDS-DMA of tile lt into ring slot st_issue
       u32x4* sp = smem + st_issue * STAGE + wave * 64;
       const bool kv = kr < p.R;
       if (p.pw) {
@@ -398,7 +410,7 @@ conv_igemm3_kernel(const ConvK p) {
       while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
       st_issue = st_issue == 2 ? 0 : st_issue + 1;
     }
-    if (it >= 0) {                                      // MFMA on tile `it` (ring slot st_comp)
+    if (it >= 0) {                      // MFMA on tile `it` (ring slot st_comp)
       const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
       const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
@@ -447,7 +459,7 @@ conv_igemm3_kernel(const ConvK p) {
     const int c0 = n0 + wn * TN + a * 16 + fch * 4;
     if (c0 >= p.C_out) continue;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.epi == MBX_EPI_AFFINE || p.epi == MBX_EPI_RESIDUAL) {
+    if constexpr (EV == 3 || EV == 4) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (c0 + r < p.C_out) {
@@ -462,61 +474,69 @@ conv_igemm3_kernel(const ConvK p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-      if (p.epi == MBX_EPI_STORE_F32) {
+      if constexpr (EV == 5) {
         float* yp = reinterpret_cast<float*>(p.y) + yo[b] + c0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (c0 + r < p.C_out) yp[r] = v[r];
-        continue;
-      }
-      unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
-      if (p.epi == MBX_EPI_AFFINE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
-      } else if (p.epi == MBX_EPI_RESIDUAL) {
-        const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
-        const float k0 = bf2f(sk.x & 0xffffu), k1 = bf2f(sk.x >> 16), k2 = bf2f(sk.y & 0xffffu), k3 = bf2f(sk.y >> 16);
-        v[0] = k0 + p.rscale * (v[0] + sh[0]);
-        v[1] = k1 + p.rscale * (v[1] + sh[1]);
-        v[2] = k2 + p.rscale * (v[2] + sh[2]);
-        v[3] = k3 + p.rscale * (v[3] + sh[3]);
       } else {
-        if (p.rscale != 0.f) {
+        unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
+        if constexpr (EV == 3) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+        } else if constexpr (EV == 4) {
+          const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
+          v[0] = bf2f(sk.x & 0xffffu) + p.rscale * (v[0] + sh[0]);
+          v[1] = bf2f(sk.x >> 16) + p.rscale * (v[1] + sh[1]);
+          v[2] = bf2f(sk.y & 0xffffu) + p.rscale * (v[2] + sh[2]);
+          v[3] = bf2f(sk.y >> 16) + p.rscale * (v[3] + sh[3]);
+        } else {
+          if (p.rscale != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
+          }
         }
-      }
-      if (p.epi == MBX_EPI_STORE && p.accumulate) {
-        const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
-        v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
-        v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
-      }
-      if (p.relu) {
+        if constexpr (EV == 2) {
+          if (p.accumulate) {
+            const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
+            v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
+            v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
+          }
+          if (p.skip) {                    // relu backward of the tensor this gradient belongs to
+            const u32x2 mk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
+            if (!(bf2f(mk.x & 0xffffu) > 0.f)) v[0] = 0.f;
+            if (!(bf2f(mk.x >> 16) > 0.f)) v[1] = 0.f;
+            if (!(bf2f(mk.y & 0xffffu) > 0.f)) v[2] = 0.f;
+            if (!(bf2f(mk.y >> 16) > 0.f)) v[3] = 0.f;
+          }
+        }
+        if constexpr (EV == 3 || EV == 4) {
+          if (p.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      unsigned short q[4];
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+        }
+        unsigned short q[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
-      *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
-      if (p.stats) {
+        for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
+        *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
+        if constexpr (EV == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
+          for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
+        }
       }
     }
   }
 
-  if (p.stats) {
-    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes,
+  if constexpr (EV == 1) {
+    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes (DPP),
     // then over the WMW pixel-waves through LDS (free after the K loop's last barrier).
     float* red = reinterpret_cast<float*>(smem);   // [WMW][BN][2]
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x1 = s1[a][r], x2 = s2[a][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
         if (frow == 0) {
           const int cl = wn * TN + a * 16 + fch * 4 + r;
           red[(wm * BN + cl) * 2 + 0] = x1;
@@ -690,6 +710,7 @@ conv_wgrad_kernel(const WgradK p) {
 // constants + immediates.
 struct WgradK2 {
   WgradK b;
+  int dbg;           // ablation bits (MBX_DBG): 1 no atomics, 2 no DMA, 4 no MFMA
   int pw;            // x rows contiguous: offset = m * ldx (1x1, stride 1, no padding, dense images)
   int ydense;        // dy rows contiguous: offset = m * ld_dy
 };
@@ -760,7 +781,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   for (int it = 1 - NST; it < nsteps; ++it) {
     const int lt = it + NST - 1;
-    if (lt < nsteps) {                                  // DMA of pixel step lt into ring slot st_issue
+    if (lt < nsteps && !((q.dbg & 2) && lt > 0)) {      // DMA of pixel step lt into ring slot st_issue
       u32x4* sp = smem + st_issue * STAGE + wave * 64;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -785,7 +806,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
       }
       st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;
     }
-    if (it >= 0) {
+    if (it >= 0 && !(q.dbg & 4)) {
       const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -833,7 +854,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
       if (kc >= p.Ktot) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+        if (nb + r < p.C_out && !(q.dbg & 1)) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
     }
   }
   if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
@@ -886,13 +907,23 @@ int launch_igemm(ConvK& k, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
   } else {
     const size_t lds = 3 * (size_t)(BM + BN) * 128;
-    static bool attr_set3 = false;
-    if (!attr_set3) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set3 = true;
+    const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
+                   : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+    static bool attr_set3[6] = {false, false, false, false, false, false};
+#define MBX_LAUNCH_EV(EV)                                                                                     \
+    case EV:                                                                                                  \
+      if (!attr_set3[EV]) {                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV>),   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        attr_set3[EV] = true;                                                                                 \
+      }                                                                                                       \
+      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV>), dim3(k.tiles_m * k.tiles_n),            \
+                         dim3(kThreads), lds, s, k);                                                          \
+      break;
+    switch (ev) {
+      MBX_LAUNCH_EV(0) MBX_LAUNCH_EV(1) MBX_LAUNCH_EV(2) MBX_LAUNCH_EV(3) MBX_LAUNCH_EV(4) MBX_LAUNCH_EV(5)
     }
-    hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
+#undef MBX_LAUNCH_EV
   }
   MBX_LAUNCH_CHECK();
   return MBX_OK;
@@ -935,7 +966,8 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   if (d->epilogue == MBX_EPI_RESIDUAL && (!d->skip || d->ld_skip % 4 || (reinterpret_cast<uintptr_t>(d->skip) & 7)))
     return MBX_ERR_INVALID_ARG;
   if ((long long)d->N * d->y_img_stride >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
-  if (d->stats_partial && d->epilogue != MBX_EPI_STORE) return MBX_ERR_INVALID_ARG;
+  if (d->stats_partial && (d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip)) return MBX_ERR_INVALID_ARG;
+  if (d->epilogue == MBX_EPI_STORE && d->skip && (d->ld_skip % 4 || (reinterpret_cast<uintptr_t>(d->skip) & 7))) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   ConvK k;
   k.x = reinterpret_cast<const unsigned short*>(d->x);
@@ -956,6 +988,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   hipStream_t s = mbx_s(stream);
   switch (choose_cfg(k.M, k.C_out)) {
     case 0: return launch_igemm<128, 128, 2, 2>(k, s);
@@ -1017,6 +1050,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   } else {
     WgradK2 k2;
     k2.b = k;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k2.dbg = dbg; }
     k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
              d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;

@@ -522,6 +522,20 @@ class Net:
         self.filter_table = torch.from_numpy(raw).to(self.dev)
         self.filter_blocks, self.filter_entries = blocks, len(entries)
 
+        # relu backward of a residual block output N_i = relu(...) is fused into the epilogue of the LAST
+        # writer of its gradient, i.e. the data-gradient conv of the FIRST forward consumer of N_i.
+        mask_of = {}               # id(consumer ConvOp) -> residual op whose output it masks
+        fused_mask = set()         # id(residual op) whose relu_mask launch is not needed
+        for r in self.convs:
+            if r.kind == "residual" and r.relu and r.trainable:
+                for c in self.fwd:
+                    if isinstance(c, ConvOp) and c.x.buf is r.out.buf:
+                        if c.need_dx and c.x.ch_off == r.out.ch_off and c.x.C == r.out.C:
+                            mask_of[id(c)] = r
+                            fused_mask.add(id(r))
+                        break
+                    if isinstance(c, PoolOp) and c.x.buf is r.out.buf:
+                        break
         L = []
         self.bwd_ops = []          # the forward op each backward launch belongs to (same order as L)
         for op in reversed(self.fwd):
@@ -553,7 +567,7 @@ class Net:
                 zb = id(self.grad_of(op.x).buf)     # per-stage branch gradient buffer is reused by every block
                 self.written = {k for k in self.written if k[0] != zb}
                 dyv, scale, db = gout, op.rscale, self._sl(self.Wg, op.b_off, K)
-                if op.relu:
+                if op.relu and id(op) not in fused_mask:
                     pre = lambda s, gout=gout, op=op: _lib.check(
                         l.mbx_relu_mask(gout.ptr, gout.ld, op.out.ptr, op.out.ld, op.M, op.K, s), "relu_mask")
                 else:
@@ -581,9 +595,10 @@ class Net:
                 gx = self._gview(op.x)
                 acc = self._claim(gx)
                 dyin = View(dyv.buf, dyv.N, dyv.H, dyv.W, op.kpad, dyv.ld, dyv.ch_off, 2)
+                mr = mask_of.get(id(op))
                 ddesc = ops.make_desc(dyin, self.Wd[op.dgrad_off:], op.Cin, op.R, op.S, op.stride,
                                       op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
-                                      rscale=(scale if scale != 1.0 else 0.0))
+                                      rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None))
 
             def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
                 s = st()
