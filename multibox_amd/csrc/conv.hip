@@ -715,22 +715,31 @@ struct WgradK2 {
   int ydense;        // dy rows contiguous: offset = m * ld_dy
 };
 
-template <int NST>
-__global__ void __launch_bounds__(kThreads)
+// NG = 2: eight waves; the two 4-wave groups reduce disjoint halves of the block's pixel range into the
+// SAME (n, k) tile and are summed through LDS before the atomics -> half the atomic bytes per FLOP
+// (the fp32 atomics ran at the chip-wide atomic rate and cost ~35 % of the 1x1 weight gradients).
+template <int NST, int NG>
+__global__ void __launch_bounds__(kThreads * NG)
 conv_wgrad2_kernel(const WgradK2 q) {
   const WgradK& p = q.b;
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];     // [NST][Y 64x16 | X 64x16] slots
   constexpr int STAGE = 2 * 64 * 16;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = wave_id();
+  const int lane = threadIdx.x & 63;
+  const int wave8 = wave_id();
+  const int grp = NG == 2 ? (wave8 >> 2) : 0, wave = wave8 & 3;
+  const int tid = threadIdx.x & 255;                   // thread index inside its 4-wave group
   const int wn = wave & 1, wk = wave >> 1;
   const int ntiles = p.tiles_n * p.tiles_k;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = lid % ntiles, split = lid / ntiles;
   const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int blk_begin = split * p.m_per_split;
+  const int blk_end = min(p.M, blk_begin + p.m_per_split);
+  // group 0 takes the first half of the block's pixels (rounded up to 64), group 1 the rest
+  const int half = NG == 2 ? ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63) : (blk_end - blk_begin);
+  const int m_begin = blk_begin + grp * half;
+  const int m_end = NG == 2 ? (grp == 0 ? min(blk_end, blk_begin + half) : blk_end) : blk_end;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
 
@@ -775,14 +784,14 @@ conv_wgrad2_kernel(const WgradK2 q) {
   float bsum = 0.f;
   const bool do_bias = p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
 
-  const int nsteps = (m_end - m_begin + 63) >> 6;
+  const int nsteps = (half + 63) >> 6;                   // same trip count for both groups (barriers are block-wide)
   int st_issue = 0, st_comp = 0;
   typedef s16x4 __attribute__((address_space(3))) * lds_tr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   for (int it = 1 - NST; it < nsteps; ++it) {
     const int lt = it + NST - 1;
     if (lt < nsteps && !((q.dbg & 2) && lt > 0)) {      // DMA of pixel step lt into ring slot st_issue
-      u32x4* sp = smem + st_issue * STAGE + wave * 64;
+      u32x4* sp = smem + (grp * NST + st_issue) * STAGE + wave * 64;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool mv = m_run < m_end;
@@ -807,7 +816,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
       st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;
     }
     if (it >= 0 && !(q.dbg & 4)) {
-      const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
+      const char* base = reinterpret_cast<const char*>(smem + (grp * NST + st_comp) * STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 yf[4], xf[4];
@@ -845,6 +854,28 @@ conv_wgrad2_kernel(const WgradK2 q) {
     }
   }
   wait_vmcnt<0>();
+  if (NG == 2) {                                        // group 1 -> LDS -> group 0 (rings are idle now)
+    float* xch = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[((a * 4 + b) * 4 + r) * 256 + tid] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (grp == 1) {
+      if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
+      return;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += xch[((a * 4 + b) * 4 + r) * 256 + tid];
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
@@ -1020,9 +1051,14 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   const int tiles = k.tiles_n * k.tiles_k;
   // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
   static int target = 0;
-  if (!target) { const char* e = getenv("MBX_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+  if (!target) {
+    const char* g1 = getenv("MBX_WGRAD_NG");
+    const bool v1e = getenv("MBX_WGRAD_V1") != nullptr;
+    const int dflt = ((g1 && g1[0] == '1') || v1e) ? 512 : 256;       // 8-wave blocks: one per CU
+    const char* e = getenv("MBX_WGRAD_TARGET"); target = e ? atoi(e) : dflt; if (target < 1) target = dflt;
+  }
   int splits = target / tiles;                 // floor: all blocks resident in one round (2 per CU)
-  const int max_splits = (k.M + 255) / 256;
+  const int max_splits = (k.M + 511) / 512;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = (k.M + splits - 1) / splits;
@@ -1040,11 +1076,8 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.H_out = d->H_out;
   k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
   k.dy_bytes = (unsigned)(2 * ((long long)(d->N - 1) * dy_img_stride + ((long long)k.HW_out - 1) * ld_dy + ((d->C_out + 7) / 8) * 8));
-  static int v1 = -1, nst = 2;
-  if (v1 < 0) {
-    const char* e = getenv("MBX_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0;
-    const char* n = getenv("MBX_WGRAD_NST"); if (n) nst = atoi(n) == 3 ? 3 : 2;
-  }
+  static int v1 = -1;
+  if (v1 < 0) { const char* e = getenv("MBX_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
   if (v1) {
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(kThreads), 0, mbx_s(stream), k);
   } else {
@@ -1054,13 +1087,15 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
              d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
-    static bool attr2 = false, attr3 = false;
-    if (nst == 3) {
-      if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768); attr3 = true; }
-      hipLaunchKernelGGL(conv_wgrad2_kernel<3>, dim3(tiles * splits), dim3(kThreads), 3 * 32768, mbx_s(stream), k2);
+    static int ng = 0;
+    if (!ng) { const char* e = getenv("MBX_WGRAD_NG"); ng = (e && e[0] == '1') ? 1 : 2; }
+    static bool attr_a = false, attr_b = false;
+    if (ng == 2) {
+      if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768); attr_b = true; }
+      hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2>), dim3(tiles * splits), dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
     } else {
-      if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); attr2 = true; }
-      hipLaunchKernelGGL(conv_wgrad2_kernel<2>, dim3(tiles * splits), dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
+      if (!attr_a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); attr_a = true; }
+      hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1>), dim3(tiles * splits), dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
     }
   }
   MBX_LAUNCH_CHECK();

@@ -32,20 +32,29 @@ inline int grid_for(long long work_items) {
 }
 
 // ------------------------------------------------------------------ batch norm: finalize
-// one wave per channel: 64 lanes stride over the partial rows, then a wave reduction.
+// one workgroup per channel: the 256 lanes stride over the partial rows (all loads in flight at once),
+// wave reduction + LDS; latency of this kernel sits between every conv and its normalisation.
+__device__ __forceinline__ void block_sum2(double& s1, double& s2) {
+  __shared__ double red[kT / 64][2];
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
+  __syncthreads();
+  s1 = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  s2 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+}
+
 __global__ void __launch_bounds__(kT)
 bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_count, float eps, float decay,
                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ mmean,
                    float* __restrict__ mvar) {
-  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = lane; r < rows; r += 64) {
+  for (int r = threadIdx.x; r < rows; r += kT) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
     s1 += v.x; s2 += v.y;
   }
-  s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) {
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
     const double m = s1 * inv_count;
     double var = s2 * inv_count - m * m;
     if (var < 0.0) var = 0.0;
@@ -154,15 +163,14 @@ bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const uns
 __global__ void __launch_bounds__(kT)
 bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_M, float* __restrict__ dbeta,
                        float* __restrict__ m12) {
-  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = lane; r < rows; r += 64) {
+  for (int r = threadIdx.x; r < rows; r += kT) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
     s1 += v.x; s2 += v.y;
   }
-  s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) {
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
     if (dbeta) dbeta[c] += (float)s1;
     m12[c] = (float)(s1 * inv_M);
     m12[C + c] = (float)(s2 * inv_M);
@@ -476,7 +484,7 @@ extern "C" int mbx_bn_finalize(const float* part, int rows, int C, int64_t count
                                float* rstd, float* mmean, float* mvar, mbx_stream_t stream) {
   if (!part || !mean || !rstd || rows <= 0 || C <= 0 || count <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, mbx_s(stream), part, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, mbx_s(stream), part, rows, C,
                      1.0 / (double)count, eps, decay, mean, rstd, mmean, mvar);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
@@ -526,7 +534,7 @@ extern "C" int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_
                                    mbx_stream_t stream) {
   if (!partial || !m12 || rows <= 0 || C <= 0 || M <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, mbx_s(stream), partial, rows, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, mbx_s(stream), partial, rows, C,
                      1.0 / (double)M, dbeta, m12);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
