@@ -284,6 +284,7 @@ class Net:
         self.pool("avg", feat, g1, 8, 1, pad=0)
         grids.append((H + "1x1/", g1, f1, 1))
         # prediction index: off_g + (i*g + j)*k + a  (model.py:296-319)
+        self.head_ld = max(8, (5 * k + 7) // 8 * 8)       # 5k head channels padded to 8 (k=5: 32, k=7: 40)
         self.P = sum(g * g * kk for _, _, g, kk in grids)
         self.grid_sizes = [g for _, _, g, _ in grids]
         self.locs = torch.zeros((B, self.P, 4), dtype=torch.float32, device=self.dev)
@@ -292,7 +293,7 @@ class Net:
         self.d_logits = torch.zeros_like(self.logits)
         off = 0
         for scope, src, g, kk in grids:
-            o = self.alloc(g, g, 32, dtype=torch.float32, zero=True)        # [M_g, 32] f32: 4k locs | k logits
+            o = self.alloc(g, g, self.head_ld, dtype=torch.float32, zero=True)   # [M_g, head_ld] f32: 4k locs | k logits
             if scope.endswith("1x1/"):
                 names = [(scope + "Conv", 4), (scope + "Conv_1", 1)]
             elif scope.endswith("4x4/"):
@@ -477,7 +478,7 @@ class Net:
                 def run(d=d, op=op, cells=cells, kk=kk, off=off):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
-                    _lib.check(l.mbx_head_gather(op.out.buf.data_ptr(), 32, self.B, cells, kk, self.P, off,
+                    _lib.check(l.mbx_head_gather(op.out.buf.data_ptr(), self.head_ld, self.B, cells, kk, self.P, off,
                                                  self.locs.data_ptr(), self.logits.data_ptr(), s), "head_gather")
                 L.append(run)
         return L
@@ -554,13 +555,13 @@ class Net:
             wdesc.C_out = K
             if op.kind == "head":
                 cells, kk, off = op.head
-                g = View(torch.zeros((M, 32), dtype=torch.bfloat16, device=self.dev), op.out.N, op.out.H, op.out.W, 32)
+                g = View(torch.zeros((M, self.head_ld), dtype=torch.bfloat16, device=self.dev), op.out.N, op.out.H, op.out.W, self.head_ld)
                 self._bufs.append(g.buf)
                 dyv, scale, db = g, 1.0, None
                 pre = lambda s, g=g, cells=cells, kk=kk, off=off: _lib.check(
                     l.mbx_head_scatter(self.d_locs.data_ptr(), self.d_logits.data_ptr(), self.B, cells, kk, self.P, off,
-                                       g.buf.data_ptr(), 32, s), "head_scatter")
-                dy_C = op.kpad if op.need_dx else 32
+                                       g.buf.data_ptr(), self.head_ld, s), "head_scatter")
+                dy_C = op.kpad if op.need_dx else self.head_ld
             elif op.kind == "residual":
                 gout = self._gview(op.out)          # == gradient of skip (same trunk buffer, in place)
                 self._claim(self._gview(op.skip))

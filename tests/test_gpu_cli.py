@@ -1,0 +1,65 @@
+"""End-to-end drop-in CLIs on the GPU: train.py (synthetic input) -> checkpoint -> detect.py -> results JSON
+with the reference's record format (detect.py:438-460)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = """
+NUM_BBOXES_PER_CELL : 5
+MAX_NUM_BBOXES : 13
+LOCATION_LOSS_ALPHA : 1000.0
+BATCH_SIZE : 4
+INPUT_SIZE : 299
+NUM_TRAIN_EXAMPLES : 56945
+NUM_TRAIN_ITERATIONS : 1000000
+LOG_EVERY_N_STEPS : 1
+DETECTION :
+  USE_ORIGINAL_IMAGE : true
+  ORIGINAL_IMAGE_MAX_TO_KEEP : 200
+"""
+
+
+def test_train_then_detect(tmp_path):
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import priors as PR
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CFG)
+    pri = tmp_path / "priors.pkl"
+    PR.save_priors(str(pri), PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]))
+    logdir, outdir = tmp_path / "log", tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(logdir),
+                        "--config", str(cfg), "--max_number_of_steps", "3", "--synthetic"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(logdir / "model.ckpt-3.pt")
+    log = [json.loads(l) for l in open(logdir / "train_log.jsonl")]
+    assert len(log) == 3 and all(np.isfinite(x["total_loss"]) for x in log)
+    assert abs(log[0]["total_loss"] - (log[0]["location_loss"] + log[0]["confidence_loss"])) < 0.01 * log[0]["total_loss"] + 5
+    # resume: slim.learning.train picks the latest checkpoint of logdir (train.py:33-37)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(logdir),
+                        "--config", str(cfg), "--max_number_of_steps", "4", "--synthetic", "--fine_tune"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "Resumed from" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(logdir / "model.ckpt-4.pt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "detect.py"), "--priors", str(pri), "--checkpoint_path", str(logdir),
+                        "--config", str(cfg), "--save_dir", str(outdir), "--synthetic", "8", "--max_iterations", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(outdir / "results-dense-4.json"))          # global step parsed from the checkpoint name
+    assert len(res) > 0 and set(res[0]) == {"image_id", "bbox", "score"}
+    b = np.array([x["bbox"] for x in res])
+    assert b.shape[1] == 4 and (b >= 0).all() and (b <= 1).all()       # clipped like detect.py:413; no ordering is enforced
+    per_image = {}
+    for x in res:
+        per_image.setdefault(x["image_id"], []).append(x["score"])
+    assert len(per_image) == 8 and all(len(v) <= 200 for v in per_image.values())
+    assert all(v == sorted(v, reverse=True) for v in per_image.values())    # detect.py:423 sort by confidence

@@ -304,3 +304,39 @@ def test_finetune_and_infer_modes(env):
         rl, rz = Model(P, k=5, bn_training=False, q=q_bf16).build(env["images"])
     assert float((locs.cpu() - rl).abs().max()) < 5e-2 * float(rl.abs().max())
     assert float((logits.cpu() - rz).abs().max()) < 5e-2 * float(rz.abs().max())
+
+
+@pytest.mark.parametrize("S,k,B,G", [(299, 7, 2, 100), (512, 7, 2, 100)])
+def test_other_baseline_configs_run(env, S, k, B, G):
+    """BASELINE configs 4/5 geometry: k=7 (P=904) at 299, and 512x512 with the generalised head grids
+    (P=3199, MAX_NUM_BBOXES=100).  One optimisation step; matching must succeed and every gt
+    must be matched to a distinct prediction (size-independent property)."""
+    torch = env["torch"]
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    from multibox_amd import priors as PR
+    from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+    net = Net(batch=B, input_size=S, k=k, mode="train", seed=21)
+    grids, last = PR.head_grids(S)
+    grids = grids + ([1] if last == 1 else [int(round(last ** 0.5))])
+    pri = PR.generate_priors_array(DEFAULT_ASPECT_RATIOS[k], grids=grids) if S == 299 else None
+    if pri is None:
+        # 512: the last head has 7x7 single-prior cells; build [g..., 7 with k=1] by hand
+        main = PR.generate_priors_array(DEFAULT_ASPECT_RATIOS[k], grids=grids[:-1] + [1])[:-1]
+        tail = PR.generate_priors_array([1.0], grids=[grids[-1], 1], min_scale=0.95, max_scale=0.95)[:-1]
+        pri = np.concatenate([main, tail])
+    assert pri.shape[0] == net.P, (pri.shape, net.P)
+    tr = Trainer(net, pri.astype(np.float32), max_num_bboxes=G, use_graph=False)
+    images, gt, n = synthetic_batch(B, S, G, seed=3)
+    n[0] = G
+    rng = np.random.RandomState(0)
+    xy = rng.uniform(0, .7, (G, 2)); wh = rng.uniform(.05, .3, (G, 2))
+    gt[0, :, :2] = xy; gt[0, :, 2:] = xy + wh
+    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    tr.step()
+    torch.cuda.synchronize()
+    assert int(tr.match_status().max()) == 0
+    m = tr.loss.match.cpu().numpy()
+    for b in range(B):
+        assert sorted(m[b][m[b] >= 0].tolist()) == list(range(n[b]))
+    assert all(np.isfinite(x) for x in tr.losses())
