@@ -320,11 +320,12 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //   0 store, 1 store + BN statistics partials, 2 accumulate into y (+ optional relu mask from `skip`),
 //   3 affine (+relu), 4 residual (+relu), 5 float32 store.
 template <int BM, int BN, int WNW, int WMW, int EV>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(64 * WNW * WMW)
 conv_igemm3_kernel(const ConvK p) {
-  static_assert(WNW * WMW == 4, "four waves");
+  static_assert(WNW * WMW == 4 || WNW * WMW == 8, "four or eight waves");
+  constexpr int NT = 64 * WNW * WMW, RPP = NT / 8;      // threads, tile rows filled per DMA pass
   constexpr int TN = BN / WNW, TM = BM / WMW, NI = TN / 16, MI = TM / 16;
-  constexpr int PI = BM / 32, WI = BN / 32, NL = PI + WI;
+  constexpr int PI = BM / RPP, WI = BN / RPP, NL = PI + WI;
   constexpr int STAGE = (BM + BN) * 8;                 // 16-B slots per stage
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
 
@@ -342,7 +343,7 @@ conv_igemm3_kernel(const ConvK p) {
   int hb[PI], wb[PI], ro[PI];
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RPP * i;
     const bool mv = m < p.M;
     const unsigned mm = mv ? (unsigned)m : 0u;
     const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), rem = (int)mm - img * p.HW_out;
@@ -355,7 +356,7 @@ conv_igemm3_kernel(const ConvK p) {
   int wo[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int n = n0 + lrow + 32 * i;
+    const int n = n0 + lrow + RPP * i;
     wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;
   }
 
@@ -383,14 +384,14 @@ conv_igemm3_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
           const unsigned off = (kv && ro[i] >= 0) ? (unsigned)(ro[i] + kc * 2) : kOOB;
-          glds16(xr, sp + i * 256, (int)off);
+          glds16(xr, sp + i * NT, (int)off);
         }
       } else if (!p.shift) {
         const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
           const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) && ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);
-          glds16(xr, sp + i * 256, ok ? (ro[i] + toff) : (int)kOOB);
+          glds16(xr, sp + i * NT, ok ? (ro[i] + toff) : (int)kOOB);
         }
       } else {
 #pragma unroll
@@ -398,14 +399,14 @@ conv_igemm3_kernel(const ConvK p) {
           const int hn = hb[i] + kr, wn_ = wb[i] + ks;
           const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&
                           ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);
-          glds16(xr, sp + i * 256, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB);
+          glds16(xr, sp + i * NT, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB);
         }
       }
       const int kb = (lt * 64 + chunk * 8) * 2;
       u32x4* sw = sp + BM * 8;
 #pragma unroll
       for (int i = 0; i < WI; ++i)
-        glds16(wr, sw + i * 256, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);
+        glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);
       kc += 64;
       while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
       st_issue = st_issue == 2 ? 0 : st_issue + 1;
@@ -893,12 +894,14 @@ conv_wgrad2_kernel(const WgradK2 q) {
 
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
-const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f}};
+const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
+                          {256, 128, 1.30f}, {128, 128, 1.10f}};   // 5, 6: eight-wave blocks (v2 kernel only)
 
 int pick_cfg(long M, int C_out) {
   int best = 0;
   double best_t = 1e300;
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
+    if (i >= 5) continue;                        // eight-wave tiles are opt-in (MBX_FORCE_CFG / chooser below)
     const TileCfg& c = kCfgs[i];
     const long tiles = ((M + c.BM - 1) / c.BM) * ((C_out + c.BN - 1) / c.BN);
     const long lds = 3L * (c.BM + c.BN) * 128;
@@ -911,6 +914,7 @@ int pick_cfg(long M, int C_out) {
   return best;
 }
 
+
 bool use_v1() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MBX_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -920,23 +924,32 @@ bool use_v1() {
 int choose_cfg(long M, int C_out) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
-  return force >= 0 ? force : pick_cfg(M, C_out);
+  if (force >= 0) return force;
+  // measured on MI355X (tools/kbench.py): the eight-wave 256x128 tile wins when there are enough pixels to
+  // fill the chip with one block per CU and at least two 128-channel column tiles; otherwise the model.
+  if (!use_v1() && M >= 16384 && C_out >= 256) return 5;
+  return pick_cfg(M, C_out);
 }
 
 template <int BM, int BN, int WNW, int WMW>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
-  if (use_v1()) {
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
+  bool done_v1 = false;
+  if constexpr (WNW * WMW == 4) {
+    if (use_v1()) {
+      const size_t lds = 2 * (size_t)(BM + BN) * 128;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
+      done_v1 = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
-  } else {
+  }
+  if (!done_v1) {
     const size_t lds = 3 * (size_t)(BM + BN) * 128;
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
                    : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
@@ -949,7 +962,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
         attr_set3[EV] = true;                                                                                 \
       }                                                                                                       \
       hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV>), dim3(k.tiles_m * k.tiles_n),            \
-                         dim3(kThreads), lds, s, k);                                                          \
+                         dim3(64 * WNW * WMW), lds, s, k);                                                          \
       break;
     switch (ev) {
       MBX_LAUNCH_EV(0) MBX_LAUNCH_EV(1) MBX_LAUNCH_EV(2) MBX_LAUNCH_EV(3) MBX_LAUNCH_EV(4) MBX_LAUNCH_EV(5)
@@ -1026,6 +1039,8 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     case 1: return launch_igemm<128, 64, 2, 2>(k, s);
     case 2: return launch_igemm<64, 128, 2, 2>(k, s);
     case 3: return launch_igemm<128, 32, 1, 4>(k, s);
+    case 5: return launch_igemm<256, 128, 2, 4>(k, s);
+    case 6: return launch_igemm<128, 128, 2, 4>(k, s);
     default: return launch_igemm<64, 64, 2, 2>(k, s);
   }
 }
