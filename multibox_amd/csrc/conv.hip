@@ -437,121 +437,131 @@ conv_igemm3_kernel(const ConvK p) {
   }
   wait_vmcnt<0>();
   // ---------------------------------------------------------------- epilogue
-  // lane: pixel = tile col (lane & 15), channels = (lane >> 4) * 4 + {0..3}
-  int yo[MI], so[MI];
-  bool mok[MI];
+  if constexpr (EV == 5) {
+    // float32 head outputs (tiny): straight from the accumulators; lane = pixel (lane & 15), 4 channels
 #pragma unroll
-  for (int b = 0; b < MI; ++b) {
-    const int m = m0 + wm * TM + b * 16 + frow;
-    mok[b] = m < p.M;
-    const unsigned mm = mok[b] ? (unsigned)m : 0u;
-    const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), pix = (int)mm - img * p.HW_out;
-    yo[b] = img * p.y_img_stride + pix * p.ldy;
-    so[b] = img * p.skip_img_stride + pix * p.ld_skip;
-  }
-  float s1[NI][4], s2[NI][4];
+    for (int b = 0; b < MI; ++b) {
+      const int m = m0 + wm * TM + b * 16 + frow;
+      if (m >= p.M) continue;
+      const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+      float* yrow = reinterpret_cast<float*>(p.y) + img * p.y_img_stride + pix * p.ldy;
 #pragma unroll
-  for (int a = 0; a < NI; ++a)
+      for (int a = 0; a < NI; ++a) {
+        const int c0 = n0 + wn * TN + a * 16 + fch * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
-
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r < p.C_out) yrow[c0 + r] = acc[a][b][r];
+      }
+    }
+  } else {
+    // Stage the fp32 tile through the (now idle) LDS ring, then walk it ROW-wise: every global access of
+    // the epilogue (store, residual skip, accumulate, relu mask) is a 16-byte-per-lane access with the
+    // lanes of a row contiguous, instead of 8-byte accesses strided by the pixel pitch.
+    constexpr int LDT = BN + 4;                                // floats per tile row (+16 B: bank spread)
+    float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    const int c0 = n0 + wn * TN + a * 16 + fch * 4;
-    if (c0 >= p.C_out) continue;
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+        *reinterpret_cast<f32x4*>(tile + (wm * TM + b * 16 + frow) * LDT + wn * TN + a * 16 + fch * 4) = acc[a][b];
+    __syncthreads();
+    constexpr int TPR = BN / 8, RPP2 = NT / TPR, NPASS = BM / RPP2;
+    const int cg = tid % TPR, r0 = tid / TPR;
+    const int c0 = n0 + cg * 8;
+    const bool cok = c0 < p.C_out;                             // C_out % 8 == 0 for bf16 outputs
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
     if constexpr (EV == 3 || EV == 4) {
+      if (cok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (c0 + r < p.C_out) {
-          if (p.scale) sc[r] = p.scale[c0 + r];
-          if (p.shiftv) sh[r] = p.shiftv[c0 + r];
+        for (int j = 0; j < 8; ++j) {
+          if (p.scale) sc[j] = p.scale[c0 + j];
+          if (p.shiftv) sh[j] = p.shiftv[c0 + j];
         }
       }
     }
+    float s1[8], s2[8];
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-      if (!mok[b]) continue;
-      float v[4];
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-      if constexpr (EV == 5) {
-        float* yp = reinterpret_cast<float*>(p.y) + yo[b] + c0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r < p.C_out) yp[r] = v[r];
-      } else {
-        unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP2 + r0;
+      const int m = m0 + row;
+      if (m < p.M && cok) {
+        const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8 + 4);
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + img * p.y_img_stride + pix * p.ldy + c0;
         if constexpr (EV == 3) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
         } else if constexpr (EV == 4) {
-          const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
-          v[0] = bf2f(sk.x & 0xffffu) + p.rscale * (v[0] + sh[0]);
-          v[1] = bf2f(sk.x >> 16) + p.rscale * (v[1] + sh[1]);
-          v[2] = bf2f(sk.y & 0xffffu) + p.rscale * (v[2] + sh[2]);
-          v[3] = bf2f(sk.y >> 16) + p.rscale * (v[3] + sh[3]);
+          const u32x4 sk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+          const unsigned w[4] = {sk.x, sk.y, sk.z, sk.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[2 * j]);
+            v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[2 * j + 1]);
+          }
         } else {
           if (p.rscale != 0.f) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
+            for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
           }
         }
         if constexpr (EV == 2) {
           if (p.accumulate) {
-            const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
-            v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
-            v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
+            const u32x4 old = *reinterpret_cast<const u32x4*>(yp);
+            const unsigned w[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
           }
-          if (p.skip) {                    // relu backward of the tensor this gradient belongs to
-            const u32x2 mk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
-            if (!(bf2f(mk.x & 0xffffu) > 0.f)) v[0] = 0.f;
-            if (!(bf2f(mk.x >> 16) > 0.f)) v[1] = 0.f;
-            if (!(bf2f(mk.y & 0xffffu) > 0.f)) v[2] = 0.f;
-            if (!(bf2f(mk.y >> 16) > 0.f)) v[3] = 0.f;
+          if (p.skip) {                      // relu backward of the tensor this gradient belongs to
+            const u32x4 mk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+            const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
+              if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
+            }
           }
         }
         if constexpr (EV == 3 || EV == 4) {
           if (p.relu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           }
         }
-        unsigned short q[4];
+        unsigned q8[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
-        *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
+        for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
+        *reinterpret_cast<u32x4*>(yp) = u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)};
         if constexpr (EV == 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
+          for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[j] += f; s2[j] += f * f; }
         }
       }
     }
-  }
-
-  if constexpr (EV == 1) {
-    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes (DPP),
-    // then over the WMW pixel-waves through LDS (free after the K loop's last barrier).
-    float* red = reinterpret_cast<float*>(smem);   // [WMW][BN][2]
+    if constexpr (EV == 1) {
+      // batch-norm statistics partials of this tile: per-thread sums over its rows, then over the RPP2
+      // row groups through LDS (the staged tile is dead after the barrier).
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);           // [RPP2][BN][2]
 #pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
-        if (frow == 0) {
-          const int cl = wn * TN + a * 16 + fch * 4 + r;
-          red[(wm * BN + cl) * 2 + 0] = x1;
-          red[(wm * BN + cl) * 2 + 1] = x2;
-        }
+      for (int j = 0; j < 8; ++j) {
+        red[(r0 * BN + cg * 8 + j) * 2] = s1[j];
+        red[(r0 * BN + cg * 8 + j) * 2 + 1] = s2[j];
       }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.C_out) {
-      float x1 = 0.f, x2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-      float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
-      o[0] = x1;
-      o[1] = x2;
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.C_out) {
+        float x1 = 0.f, x2 = 0.f;
+        for (int w = 0; w < RPP2; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+        float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
+        o[0] = x1;
+        o[1] = x2;
+      }
     }
   }
 }
@@ -1006,12 +1016,12 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   if (!d->w || !d->y) return MBX_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(d->w) & 15)) return MBX_ERR_INVALID_ARG;
   const bool f32 = d->epilogue == MBX_EPI_STORE_F32;
-  if (!f32 && (d->C_out % 4 || d->ldy % 4 || (reinterpret_cast<uintptr_t>(d->y) & 7))) return MBX_ERR_INVALID_ARG;
-  if (d->epilogue == MBX_EPI_RESIDUAL && (!d->skip || d->ld_skip % 4 || (reinterpret_cast<uintptr_t>(d->skip) & 7)))
+  if (!f32 && (d->C_out % 8 || d->ldy % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15))) return MBX_ERR_INVALID_ARG;
+  if (d->epilogue == MBX_EPI_RESIDUAL && (!d->skip || d->ld_skip % 8 || (reinterpret_cast<uintptr_t>(d->skip) & 15)))
     return MBX_ERR_INVALID_ARG;
   if ((long long)d->N * d->y_img_stride >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
   if (d->stats_partial && (d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip)) return MBX_ERR_INVALID_ARG;
-  if (d->epilogue == MBX_EPI_STORE && d->skip && (d->ld_skip % 4 || (reinterpret_cast<uintptr_t>(d->skip) & 7))) return MBX_ERR_INVALID_ARG;
+  if (d->epilogue == MBX_EPI_STORE && d->skip && (d->ld_skip % 8 || (reinterpret_cast<uintptr_t>(d->skip) & 15))) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   ConvK k;
   k.x = reinterpret_cast<const unsigned short*>(d->x);
