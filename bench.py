@@ -123,14 +123,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("MBX_FORCE_DIST"):       # MBX_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
     import __graft_entry__ as g
     if rank == 0:
         g.build()
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
     from multibox_amd.engine import Net
     from multibox_amd.trainer import Trainer, decay_steps
@@ -147,7 +147,7 @@ def main():
     tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
 
     def sync():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +159,7 @@ def main():
         tr.step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -187,7 +187,7 @@ def main():
             out["roofline"] = conv_roofline(tr)
         except Exception as e:      # evidence only; never fail the benchmark line on it
             out["roofline"] = {"error": repr(e)}
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         try:
@@ -196,7 +196,7 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

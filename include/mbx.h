@@ -231,7 +231,7 @@ typedef struct {
   int64_t src_off;  /* element offset of the KRSC filter in the bf16 flat buffer           */
   int64_t dst_off;  /* element offset of the [C][R][S][Kpad] copy in the dgrad buffer       */
   int32_t K, R, S, C, Kpad;
-  int32_t first_block; /* prefix sum of ceil(C*R*S*Kpad / 2048) over the entries            */
+  int32_t first_block; /* prefix sum of R*S*ceil(C/32)*ceil(Kpad/64) over the entries            */
 } mbx_filter_entry;
 int mbx_filter_prepare(const void* w_bf16, void* w_dgrad, const mbx_filter_entry* table /*DEVICE*/,
                        int n_entries, int total_blocks, mbx_stream_t stream);

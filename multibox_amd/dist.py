@@ -13,6 +13,8 @@ bucket of 60 MB moves 2*(7/8)*60 MB per GPU; 4 buckets keep each message large e
 link-bound rather than latency-bound."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,7 +26,7 @@ class BucketReducer:
 
     @property
     def enabled(self):
-        return self.pg is not None and dist.get_world_size(self.pg) > 1
+        return self.pg is not None and (dist.get_world_size(self.pg) > 1 or bool(os.environ.get("MBX_FORCE_DIST")))
 
     def reduce_async(self, flat, lo, hi):
         """Start SUM all-reduce of flat[lo:hi] (in place)."""

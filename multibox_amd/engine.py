@@ -515,7 +515,7 @@ class Net:
                 op.dgrad_off, op.kpad = d_off, kpad
                 n = op.Cin * op.R * op.S * kpad
                 d_off += (n + 7) // 8 * 8
-                blocks += (n + 2047) // 2048
+                blocks += op.R * op.S * ((op.Cin + 31) // 32) * ((kpad + 63) // 64)
                 entries.append(e)
         self.Wd = torch.zeros(max(d_off, 8), dtype=torch.bfloat16, device=self.dev)
         arr = (_lib.FilterEntry * len(entries))(*entries)

@@ -121,13 +121,14 @@ class Trainer:
                 f()
         torch.cuda.synchronize()
         graphs = []
+        # thread_local: RCCL's watchdog thread may query events while we capture (data-parallel runs)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._front()
         graphs.append(g)
         for fns, _, _ in self._segments:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 for f in fns:
                     f()
             graphs.append(g)

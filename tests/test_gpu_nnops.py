@@ -219,7 +219,7 @@ def test_filter_prepare(T):
         n = Cc * R * S_ * kpad
         src_off += w.numel()
         dst_off += (n + 7) // 8 * 8
-        blocks += (n + 2047) // 2048
+        blocks += R * S_ * ((Cc + 31) // 32) * ((kpad + 63) // 64)
     wsrc = torch.cat(flat).to(torch.bfloat16).cuda()
     wdst = torch.zeros(dst_off, dtype=torch.bfloat16, device="cuda")
     arr = (_lib.FilterEntry * len(entries))(*entries)
