@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--log-losses", action="store_true", help="print the loss after every step to stderr (adds host syncs)")
     return ap.parse_args()
 
 
@@ -105,9 +106,16 @@ def conv_roofline(tr):
     total_flops = sum(f for _, _, f in recs)
     n = len(recs)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+        pj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        traffic = json.load(open(pj))["conv_igemm3_kernel"]["MB_per_launch"] * 1e6
+        traffic_src = "profiles/r01_hbm_traffic_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "conv_igemm3_kernel (forward + data-gradient launches)",
             "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": n, "avg_launch_us": round(1e3 * total_ms / n, 2),
             "algorithmic_gflop_per_launch": round(total_flops / n / 1e9, 3)}
 
@@ -153,10 +161,14 @@ def main():
 
     for _ in range(args.warmup):
         tr.step()
+        if args.log_losses and rank == 0:
+            print("warmup step %d losses (loc, conf, reg, total) %s" % (tr.global_step, tr.losses()), file=sys.stderr)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.step()
+        if args.log_losses and rank == 0:
+            print("step %d losses (loc, conf, reg, total) %s" % (tr.global_step, tr.losses()), file=sys.stderr)
     sync()
     dt = time.perf_counter() - t0
     if pg is not None:
