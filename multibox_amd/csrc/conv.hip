@@ -375,43 +375,46 @@ conv_igemm3_kernel(const ConvK p) {
   while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
   const int ldx2 = p.ldx * 2;
   int st_issue = 0, st_comp = 0;                        // ring positions
-  for (int it = -2; it < nk; ++it) {
-    const int lt = it + 2;
-    if (lt < nk) {          // LDS-DMA of tile lt into ring slot st_issue
-      u32x4* sp = smem + st_issue * STAGE + wave * 64;
-      const bool kv = kr < p.R;
-      if (p.pw) {
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const unsigned off = (kv && ro[i] >= 0) ? (unsigned)(ro[i] + kc * 2) : kOOB;
-          glds16(xr, sp + i * NT, (int)off);
-        }
-      } else if (!p.shift) {
-        const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) && ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);
-          glds16(xr, sp + i * NT, ok ? (ro[i] + toff) : (int)kOOB);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const int hn = hb[i] + kr, wn_ = wb[i] + ks;
-          const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&
-                          ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);
-          glds16(xr, sp + i * NT, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB);
-        }
-      }
-      const int kb = (lt * 64 + chunk * 8) * 2;
-      u32x4* sw = sp + BM * 8;
-#pragma unroll
-      for (int i = 0; i < WI; ++i)
-        glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);
-      kc += 64;
-      while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
-      st_issue = st_issue == 2 ? 0 : st_issue + 1;
-    }
-    if (it >= 0) {                      // MFMA on tile `it` (ring slot st_comp)
+  // LDS-DMA of K tile LT into ring slot st_issue.  (A macro, not a lambda: the three call sites must be
+  // straight-line code so that the MFMA accumulators never leave the accumulator registers.)
+#define MBX_ISSUE_TILE(LT)                                                                                   \
+  do {                                                                                                       \
+    u32x4* sp = smem + st_issue * STAGE + wave * 64;                                                         \
+    const bool kv = kr < p.R;                                                                                \
+    if (p.pw) {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < PI; ++i)                                                         \
+        glds16(xr, sp + i * NT, (kv && ro[i] >= 0) ? (ro[i] + kc * 2) : (int)kOOB);                          \
+    } else if (!p.shift) {                                                                                   \
+      const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;                                                   \
+      _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                       \
+        const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) &&                                 \
+                        ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);                                         \
+        glds16(xr, sp + i * NT, ok ? (ro[i] + toff) : (int)kOOB);                                            \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                       \
+        const int hn = hb[i] + kr, wn_ = wb[i] + ks;                                                         \
+        const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&         \
+                        ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);                                           \
+        glds16(xr, sp + i * NT, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB); \
+      }                                                                                                      \
+    }                                                                                                        \
+    const int kb = ((LT) * 64 + chunk * 8) * 2;                                                              \
+    u32x4* sw = sp + BM * 8;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                           \
+      glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                                \
+    kc += 64;                                                                                                \
+    while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }                                \
+    st_issue = st_issue == 2 ? 0 : st_issue + 1;                                                             \
+  } while (0)
+
+  MBX_ISSUE_TILE(0);
+  if (nk > 1) { MBX_ISSUE_TILE(1); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
+  raw_barrier();
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + 2 < nk;
+    if (more) MBX_ISSUE_TILE(it + 2);
+    {                                                   // MFMA on tile `it` (ring slot st_comp)
       const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
       const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
@@ -430,11 +433,10 @@ conv_igemm3_kernel(const ConvK p) {
       }
       st_comp = st_comp == 2 ? 0 : st_comp + 1;
     }
-    if (it >= -1) {                                     // tile it+1 landed (own DMAs), then everyone's
-      if (lt < nk) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-      raw_barrier();
-    }
+    if (more) wait_vmcnt<NL>(); else wait_vmcnt<0>();   // tile it+1 landed (own DMAs), then everyone's
+    raw_barrier();
   }
+#undef MBX_ISSUE_TILE
   wait_vmcnt<0>();
   // ---------------------------------------------------------------- epilogue
   if constexpr (EV == 5) {
@@ -799,34 +801,41 @@ conv_wgrad2_kernel(const WgradK2 q) {
   int st_issue = 0, st_comp = 0;
   typedef s16x4 __attribute__((address_space(3))) * lds_tr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  for (int it = 1 - NST; it < nsteps; ++it) {
-    const int lt = it + NST - 1;
-    if (lt < nsteps && !((q.dbg & 2) && lt > 0)) {      // DMA of pixel step lt into ring slot st_issue
-      u32x4* sp = smem + (grp * NST + st_issue) * STAGE + wave * 64;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool mv = m_run < m_end;
-        int xoff, yoff;
-        if (q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;
-        else {
-          const int hb = oh * p.stride - p.pad_t + tr, wb = ow * p.stride - p.pad_l + ts;
-          const bool ok = mv && ((unsigned)hb < (unsigned)p.H_in) && ((unsigned)wb < (unsigned)p.W_in);
-          xoff = ok ? ((img * p.x_img_stride + ((oh * p.stride - p.pad_t) * p.W_in + ow * p.stride - p.pad_l) * p.ldx) * 2 + toff) : (int)kOOB;
-        }
-        if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;
-        else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB;
-        glds16(yr, sp + i * 256, yoff);
-        glds16(xr, sp + 1024 + i * 256, xoff);
-        m_run += 16;
-        if (!(q.pw && q.ydense)) {                      // step the pixel coordinates by 16
-          ow += 16;
-          while (ow >= p.W_out) { ow -= p.W_out; ++oh; }
-          while (oh >= p.H_out) { oh -= p.H_out; ++img; }
-        }
-      }
-      st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;
-    }
-    if (it >= 0 && !(q.dbg & 4)) {
+  // DMA of pixel step LT into ring slot st_issue (macro: straight-line call sites, see igemm)
+#define MBX_ISSUE_STEP()                                                                                      \
+  do {                                                                                                        \
+    u32x4* sp = smem + (grp * NST + st_issue) * STAGE + wave * 64;                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+      const bool mv = m_run < m_end;                                                                          \
+      int xoff, yoff;                                                                                         \
+      if (q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;                                \
+      else {                                                                                                  \
+        const int hb = oh * p.stride - p.pad_t + tr, wb = ow * p.stride - p.pad_l + ts;                       \
+        const bool ok = mv && ((unsigned)hb < (unsigned)p.H_in) && ((unsigned)wb < (unsigned)p.W_in);         \
+        xoff = ok ? ((img * p.x_img_stride + ((oh * p.stride - p.pad_t) * p.W_in + ow * p.stride - p.pad_l) * p.ldx) * 2 + toff) \
+                  : (int)kOOB;                                                                                \
+      }                                                                                                       \
+      if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                             \
+      else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB; \
+      glds16(yr, sp + i * 256, yoff);                                                                         \
+      glds16(xr, sp + 1024 + i * 256, xoff);                                                                  \
+      m_run += 16;                                                                                            \
+      if (!(q.pw && q.ydense)) {                                                                              \
+        ow += 16;                                                                                             \
+        while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                        \
+        while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                       \
+      }                                                                                                       \
+    }                                                                                                         \
+    st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
+  } while (0)
+
+  static_assert(NST == 2, "ring depth 2: one step in flight");
+  if (nsteps > 0) MBX_ISSUE_STEP();
+  wait_vmcnt<0>();
+  raw_barrier();
+  for (int it = 0; it < nsteps; ++it) {
+    if (it + 1 < nsteps) MBX_ISSUE_STEP();
+    {
       const char* base = reinterpret_cast<const char*>(smem + (grp * NST + st_comp) * STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -858,12 +867,10 @@ conv_wgrad2_kernel(const WgradK2 q) {
       }
       st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
     }
-    if (it >= -1) {
-      if (NST == 3) { if (lt < nsteps) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
-      else wait_vmcnt<0>();
-      raw_barrier();
-    }
+    wait_vmcnt<0>();
+    raw_barrier();
   }
+#undef MBX_ISSUE_STEP
   wait_vmcnt<0>();
   if (NG == 2) {                                        // group 1 -> LDS -> group 0 (rings are idle now)
     float* xch = reinterpret_cast<float*>(smem);
@@ -896,7 +903,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
       if (kc >= p.Ktot) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (nb + r < p.C_out && !(q.dbg & 1)) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
     }
   }
   if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
