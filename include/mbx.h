@@ -173,6 +173,13 @@ int mbx_bn_finalize(const float* stats_partial /*[rows,C,2]*/, int rows, int C, 
 /* a = relu?((y - mean) * rstd + beta): y bf16 [M,C] contiguous -> a bf16 view (ld_a).     */
 int mbx_bn_apply(const void* y, int64_t M, int C, const float* mean, const float* rstd,
                  const float* beta, int relu, void* a, int ld_a, mbx_stream_t stream);
+/* mbx_bn_finalize + mbx_bn_apply in ONE launch (each workgroup re-reduces the partials of its own 64
+ * channels; used when rows <= 16, otherwise it issues the two launches: re-reducing hundreds of partial
+ * rows per workgroup measured slower than the extra launch).  Same results either way.                          */
+int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, float eps, float decay,
+                       const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
+                       float* mean, float* rstd, float* moving_mean, float* moving_var,
+                       mbx_stream_t stream);
 /* Frozen BN folded into the conv epilogue (detect.py:313-326, train.py:124-131):
  * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
 int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,
@@ -190,6 +197,11 @@ int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_t M, float*
 int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y,
                      int64_t M, int C, const float* mean, const float* rstd, const float* m12,
                      void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
+
+/* mbx_bn_bwd_finalize + mbx_bn_bwd_apply in ONE launch (partial = output of mbx_bn_bwd_reduce).       */
+int mbx_bn_bwd_apply_fused(const float* partial, int rows, float* dbeta /*[C] +=*/, const void* da,
+                           int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
+                           const float* mean, const float* rstd, void* dy, mbx_stream_t stream);
 
 /* ---------------------------------------------------------------------- pooling (K9)
  * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap

@@ -44,6 +44,8 @@ _SIGS = {
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
+    "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
+    "mbx_bn_bwd_apply_fused": (I, [P, I, P, P, I, P, I, I, P, C.c_int64, I, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
     "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P]),
     "mbx_bn_bwd_finalize": (I, [P, I, I, C.c_int64, P, P, P]),

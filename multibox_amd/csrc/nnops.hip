@@ -202,6 +202,127 @@ bn_bwd_apply_kernel(const unsigned short* __restrict__ da, int ld_da, const unsi
   }
 }
 
+// ---------------------------------------------------------- batch norm: fused finalize + apply
+// One launch instead of two: every workgroup owns a 64-channel group and a chunk of rows; it first
+// re-reduces the conv-epilogue partials of ITS 64 channels (rows <= 1024: a few hundred L2-resident
+// loads per lane), keeps mean / rstd in LDS, then normalises its rows.  The chunk-0 workgroup of each
+// group also publishes mean / rstd (for the backward pass) and updates the moving statistics.
+constexpr int kBnGroup = 64;
+
+__global__ void __launch_bounds__(kT)
+bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count, float eps, float decay,
+                      const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ beta, int relu,
+                      unsigned short* __restrict__ a, int ld_a, float* __restrict__ mean, float* __restrict__ rstd,
+                      float* __restrict__ mmean, float* __restrict__ mvar, int rows_per_chunk) {
+  __shared__ double red[4][kBnGroup][2];
+  __shared__ float s_mean[kBnGroup], s_rstd[kBnGroup], s_beta[kBnGroup];
+  const int c0 = blockIdx.x * kBnGroup;
+  const int cw = min(kBnGroup, C - c0);
+  {
+    const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    if (ch < cw)
+      for (int r = rl; r < rows; r += 4) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c0 + ch) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+    red[rl][ch][0] = s1; red[rl][ch][1] = s2;
+    __syncthreads();
+    if (rl == 0 && ch < cw) {
+      for (int r = 1; r < 4; ++r) { s1 += red[r][ch][0]; s2 += red[r][ch][1]; }
+      const double m = s1 * inv_count;
+      double var = s2 * inv_count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float fm = (float)m, fr = (float)(1.0 / sqrt(var + (double)eps));
+      s_mean[ch] = fm; s_rstd[ch] = fr; s_beta[ch] = beta[c0 + ch];
+      if (blockIdx.y == 0) {
+        mean[c0 + ch] = fm; rstd[c0 + ch] = fr;
+        if (mmean) mmean[c0 + ch] -= (1.0f - decay) * (mmean[c0 + ch] - fm);
+        if (mvar) mvar[c0 + ch] -= (1.0f - decay) * (mvar[c0 + ch] - (float)var);
+      }
+    }
+    __syncthreads();
+  }
+  const int V = cw >> 3;                                  // 16-byte vectors per row in this group
+  const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+  long long r_end = r_begin + rows_per_chunk;
+  if (r_end > M) r_end = M;
+  const long long total = (r_end - r_begin) * V;
+  for (long long i = threadIdx.x; i < total; i += kT) {
+    const long long m = r_begin + i / V;
+    const int vc = (int)(i % V) << 3;
+    float f[8];
+    unpack8(ld8(y + m * C + c0 + vc), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (f[j] - s_mean[vc + j]) * s_rstd[vc + j] + s_beta[vc + j];
+      f[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+    st8(a + m * ld_a + c0 + vc, pack8(f));
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+bn_bwd_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_M, float* __restrict__ dbeta,
+                          const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
+                          int relu, const unsigned short* __restrict__ y, long long M, int C,
+                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                          unsigned short* __restrict__ dy, int rows_per_chunk) {
+  __shared__ double red[4][kBnGroup][2];
+  __shared__ float s_mean[kBnGroup], s_rstd[kBnGroup], s_m1[kBnGroup], s_m2[kBnGroup];
+  const int c0 = blockIdx.x * kBnGroup;
+  const int cw = min(kBnGroup, C - c0);
+  {
+    const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    if (ch < cw)
+      for (int r = rl; r < rows; r += 4) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c0 + ch) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+    red[rl][ch][0] = s1; red[rl][ch][1] = s2;
+    __syncthreads();
+    if (rl == 0 && ch < cw) {
+      for (int r = 1; r < 4; ++r) { s1 += red[r][ch][0]; s2 += red[r][ch][1]; }
+      s_m1[ch] = (float)(s1 * inv_M); s_m2[ch] = (float)(s2 * inv_M);
+      s_mean[ch] = mean[c0 + ch]; s_rstd[ch] = rstd[c0 + ch];
+      if (blockIdx.y == 0 && dbeta) dbeta[c0 + ch] += (float)s1;
+    }
+    __syncthreads();
+  }
+  const int V = cw >> 3;
+  const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+  long long r_end = r_begin + rows_per_chunk;
+  if (r_end > M) r_end = M;
+  const long long total = (r_end - r_begin) * V;
+  for (long long i = threadIdx.x; i < total; i += kT) {
+    const long long m = r_begin + i / V;
+    const int vc = (int)(i % V) << 3;
+    float g[8], yy[8], aa[8], o[8];
+    unpack8(ld8(da + m * ld_da + c0 + vc), g);
+    unpack8(ld8(y + m * C + c0 + vc), yy);
+    if (relu) unpack8(ld8(a + m * ld_a + c0 + vc), aa);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+      const float rs = s_rstd[vc + j];
+      const float xh = (yy[j] - s_mean[vc + j]) * rs;
+      o[j] = rs * (gj - s_m1[vc + j] - xh * s_m2[vc + j]);
+    }
+    st8(dy + m * C + c0 + vc, pack8(o));
+  }
+}
+
+inline void bn_fused_grid(long long M, int C, int& groups, int& chunks, int& rpc) {
+  groups = (C + kBnGroup - 1) / kBnGroup;
+  long long want = 1024 / groups;
+  if (want < 1) want = 1;
+  long long maxc = (M + 255) / 256;
+  if (want > maxc) want = maxc;
+  rpc = (int)((M + want - 1) / want);
+  chunks = (int)((M + rpc - 1) / rpc);
+}
+
 // ------------------------------------------------------------------------------- pooling
 __global__ void __launch_bounds__(kT)
 maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
@@ -675,6 +796,44 @@ extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float e
   if (!ema || !value || n <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), ema, value, (long long)n, ema_decay);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, float eps, float decay, const void* y,
+                                  int64_t M, int C, const float* beta, int relu, void* a, int ld_a, float* mean,
+                                  float* rstd, float* mmean, float* mvar, mbx_stream_t stream) {
+  if (!stats_partial || !y || !a || !beta || !mean || !rstd || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_a % 8 ||
+      count <= 0 || !al16(y) || !al16(a))
+    return MBX_ERR_INVALID_ARG;
+  if (rows > 16) {            // re-reducing more partial rows per workgroup costs more than the extra launch (measured)
+    int st = mbx_bn_finalize(stats_partial, rows, C, count, eps, decay, mean, rstd, mmean, mvar, stream);
+    if (st != MBX_OK) return st;
+    return mbx_bn_apply(y, M, C, mean, rstd, beta, relu, a, ld_a, stream);
+  }
+  MBX_ENTER();
+  int groups, chunks, rpc;
+  bn_fused_grid(M, C, groups, chunks, rpc);
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
+                     1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
+                     mvar, rpc);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_apply_fused(const float* partial, int rows, float* dbeta, const void* da, int ld_da, const void* a,
+                                      int ld_a, int relu, const void* y, int64_t M, int C, const float* mean,
+                                      const float* rstd, void* dy, mbx_stream_t stream) {
+  if (!partial || !da || !y || !mean || !rstd || !dy || (relu && !a) || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_da % 8 ||
+      (relu && ld_a % 8))
+    return MBX_ERR_INVALID_ARG;
+  if (!al16(da) || !al16(y) || !al16(dy) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  int groups, chunks, rpc;
+  bn_fused_grid(M, C, groups, chunks, rpc);
+  hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), partial, rows,
+                     1.0 / (double)M, dbeta, (cus)da, ld_da, (cus)a, ld_a, relu, (cus)y, (long long)M, C, mean, rstd,
+                     (us)dy, rpc);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

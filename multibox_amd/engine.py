@@ -458,10 +458,9 @@ class Net:
                 def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
-                    _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, self.bn_decay,
-                                                 mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_finalize")
-                    _lib.check(l.mbx_bn_apply(op.y.data_ptr(), op.M, op.K, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                                              int(op.relu), out.ptr, out.ld, s), "bn_apply")
+                    _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, self.bn_decay,
+                                                    op.y.data_ptr(), op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
+                                                    mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_apply_fused")
                 L.append(run)
             elif op.kind == "frozen":
                 d = self._desc(op, op.out, epilogue=ops.EPI_AFFINE, relu=op.relu,

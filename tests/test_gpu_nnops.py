@@ -86,6 +86,19 @@ def test_bn_forward_backward(T, M, Cc, relu):
     assert torch.allclose(dbeta.cpu() - 1.0, br.grad, rtol=2e-3, atol=2e-2 * float(br.grad.abs().max()))
     ok, msg = close_bf16(dy, yr.grad)
     assert ok or float((dy.float().cpu() - yr.grad).abs().max()) < 2e-2 * float(yr.grad.abs().max()), "bn_bwd: " + msg
+    # ---- the fused one-launch forms give the same results as the two-launch forms
+    av2 = ops.View.alloc(1, 1, M, Cc + 8, zero=True).slice(8, Cc)
+    dm2, dr2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    mm2, mv2 = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    _lib.check(l.mbx_bn_apply_fused(part.data_ptr(), 2, M, 0.001, 0.9, yd.data_ptr(), M, Cc, bd.data_ptr(), relu, av2.ptr, av2.ld,
+                                    dm2.data_ptr(), dr2.data_ptr(), mm2.data_ptr(), mv2.data_ptr(), S()))
+    assert torch.equal(av2.tensor(), av.tensor()) and torch.equal(dm2, dm) and torch.equal(dr2, dr)
+    assert torch.equal(mm2, mm) and torch.equal(mv2, mv)
+    dbeta2 = torch.ones(Cc, device="cuda")
+    dy2 = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_bn_bwd_apply_fused(partial.data_ptr(), rows, dbeta2.data_ptr(), dav.ptr, dav.ld, av.ptr, av.ld, relu,
+                                        yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), dy2.data_ptr(), S()))
+    assert torch.equal(dy2, dy) and torch.equal(dbeta2, dbeta)
 
 
 def test_bn_fold(T):
