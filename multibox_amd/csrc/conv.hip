@@ -912,7 +912,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
-                          {256, 128, 1.30f}, {128, 128, 1.10f}};   // 5, 6: eight-wave blocks (v2 kernel only)
+                          {256, 128, 1.30f}, {128, 128, 1.10f}, {256, 64, 1.0f}};   // 5-7: eight-wave blocks (v2 kernel only)
 
 int pick_cfg(long M, int C_out) {
   int best = 0;
@@ -944,7 +944,11 @@ int choose_cfg(long M, int C_out) {
   if (force >= 0) return force;
   // measured on MI355X (tools/kbench.py): the eight-wave 256x128 tile wins when there are enough pixels to
   // fill the chip with one block per CU and at least two 128-channel column tiles; otherwise the model.
-  if (!use_v1() && M >= 16384 && C_out >= 256) return 5;
+  if (!use_v1() && C_out >= 256) {
+    const long tiles5 = ((M + 255) / 256) * ((C_out + 127) / 128);
+    const long rounds5 = (tiles5 + 255) / 256;              // one 8-wave block per CU
+    if (tiles5 >= 128 && (double)tiles5 / (double)(rounds5 * 256) >= 0.7) return 5;
+  }
   return pick_cfg(M, C_out);
 }
 
@@ -1058,6 +1062,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     case 3: return launch_igemm<128, 32, 1, 4>(k, s);
     case 5: return launch_igemm<256, 128, 2, 4>(k, s);
     case 6: return launch_igemm<128, 128, 2, 4>(k, s);
+    case 7: return launch_igemm<256, 64, 1, 8>(k, s);
     default: return launch_igemm<64, 64, 2, 2>(k, s);
   }
 }
