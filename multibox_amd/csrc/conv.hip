@@ -4,12 +4,12 @@
 // GEMM view (forward):  Y[m, n] = sum_k P[m, k] * W[n, k]
 //   m = (img, oh, ow) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
 // The MFMA is issued with the FILTER tile as the A operand and the PIXEL tile as the B operand
-// (v_mfma_f32_16x16x32_bf16: D[row = channel][col = pixel]), so each lane ends up holding four
-// CONSECUTIVE channels of one pixel -> 8-byte bf16 stores into NHWC.
+// (v_mfma_f32_16x16x32_bf16: D[row = channel][col = pixel]): each lane holds four consecutive channels
+// of one pixel.  The fp32 tile is staged through LDS at the end and written row-wise (16 B per lane).
 //
 // LDS tiles are [rows][64 k] bf16 = 128-B rows of eight 16-B chunks, XOR-swizzled
-// (chunk ^ (row & 7)) so the ds_read_b128 fragment reads are bank-conflict free; two buffers,
-// one barrier per 64-deep K step, next tile's global loads in flight during the MFMAs.
+// (chunk ^ (row & 7)) so the ds_read_b128 fragment reads are bank-conflict free; a 3-deep ring filled
+// by LDS-DMA, one barrier per 64-deep K step, two tiles of global latency in flight.
 #include "common.h"
 #include <stdlib.h>
 
@@ -73,236 +73,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WNW, int WMW>
-__global__ void __launch_bounds__(kThreads)
-conv_igemm_kernel(const ConvK p) {
-  static_assert(WNW * WMW == 4, "four waves");
-  constexpr int TN = BN / WNW, TM = BM / WMW, NI = TN / 16, MI = TM / 16;
-  constexpr int PI = BM / 32, WI = BN / 32;
-  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  u32x4* sP = smem;                    // [2][BM*8]
-  u32x4* sW = smem + 2 * BM * 8;       // [2][BN*8]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave % WNW, wm = wave / WNW;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // ---- loader state: thread owns 16-B chunk `chunk` of rows lrow + 32*i
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
-  const int chunk = tid & 7, lrow = tid >> 3;
-  int hb[PI], wb[PI], ro[PI];          // first-tap input coordinates and byte offset of each pixel row
-#pragma unroll
-  for (int i = 0; i < PI; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    const bool mv = m < p.M;
-    const int mm = mv ? m : 0;
-    const int img = mm / p.HW_out, rem = mm - img * p.HW_out;
-    const int oh = rem / p.W_out, ow = rem - oh * p.W_out;
-    hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);       // rows past M fail every bounds check
-    wb[i] = ow * p.mul - p.pad_l;
-    ro[i] = p.shift ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
-  }
-  int wo[WI];
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int n = n0 + lrow + 32 * i;
-    wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;
-  }
-  u32x4 rp[PI], rw[WI];
-
-  f32x4 acc[NI][MI];
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int sw_st = chunk ^ (lrow & 7);
-  const int nk = (p.Ktot + 63) >> 6;
-  // this thread's chunk of the K axis as (tap row r, tap col s, channel c); advanced by 64 per step
-  int kc = chunk * 8, kr = 0, ks = 0;
-  while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
-  const int ldx2 = p.ldx * 2;
-  // One code instance of load / compute / store: iteration kt = -1 only stages tile 0.
-  for (int kt = -1; kt < nk; ++kt) {
-    const bool stage = kt + 1 < nk;
-    if (stage) {                                     // global -> registers, tile kt+1 (branch-free)
-      const bool kv = kr < p.R;
-      if (!p.shift) {
-        const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) && ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);
-          rp[i] = buf_load16(xr, ok ? (unsigned)(ro[i] + toff) : kOOB);
-        }
-      } else {                                       // transposed, stride 2: input dilated by 2
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const int hn = hb[i] + kr, wn_ = wb[i] + ks;
-          const bool ok = kv && (((hn | wn_) & 1) == 0) && ((unsigned)(hn >> 1) < (unsigned)p.H_in) &&
-                          ((unsigned)(wn_ >> 1) < (unsigned)p.W_in);
-          rp[i] = buf_load16(xr, ok ? (unsigned)(ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : kOOB);
-        }
-      }
-      const int kb = ((kt + 1) * 64 + chunk * 8) * 2;
-#pragma unroll
-      for (int i = 0; i < WI; ++i) rw[i] = buf_load16(wr, (kv && wo[i] >= 0) ? (unsigned)(wo[i] + kb) : kOOB);
-      kc += 64;
-      while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
-    }
-    if (kt >= 0) {                                   // MFMA on tile kt
-      const u32x4* cW = sW + (kt & 1) * BN * 8;
-      const u32x4* cP = sP + (kt & 1) * BM * 8;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 wf[NI], pf[MI];
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-          const int row = wn * TN + a * 16 + frow;
-          wf[a] = __builtin_bit_cast(bf16x8, cW[row * 8 + ((kk * 4 + fch) ^ (row & 7))]);
-        }
-#pragma unroll
-        for (int b = 0; b < MI; ++b) {
-          const int row = wm * TM + b * 16 + frow;
-          pf[b] = __builtin_bit_cast(bf16x8, cP[row * 8 + ((kk * 4 + fch) ^ (row & 7))]);
-        }
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-#pragma unroll
-          for (int b = 0; b < MI; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
-      }
-    }
-    if (stage) {                                     // registers -> LDS buffer (kt+1)&1
-      u32x4* dP = sP + ((kt + 1) & 1) * BM * 8;
-      u32x4* dW = sW + ((kt + 1) & 1) * BN * 8;
-#pragma unroll
-      for (int i = 0; i < PI; ++i) dP[(lrow + 32 * i) * 8 + sw_st] = rp[i];
-#pragma unroll
-      for (int i = 0; i < WI; ++i) dW[(lrow + 32 * i) * 8 + sw_st] = rw[i];
-    }
-    __syncthreads();
-  }
-
-  // ---------------------------------------------------------------- epilogue
-  // lane: pixel = tile col (lane & 15), channels = (lane >> 4) * 4 + {0..3}
-  int yo[MI], so[MI];
-  bool mok[MI];
-#pragma unroll
-  for (int b = 0; b < MI; ++b) {
-    const int m = m0 + wm * TM + b * 16 + frow;
-    mok[b] = m < p.M;
-    const int mm = mok[b] ? m : 0;
-    const int img = mm / p.HW_out, pix = mm - img * p.HW_out;
-    yo[b] = img * p.y_img_stride + pix * p.ldy;
-    so[b] = img * p.skip_img_stride + pix * p.ld_skip;
-  }
-  float s1[NI][4], s2[NI][4];
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
-
-#pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    const int c0 = n0 + wn * TN + a * 16 + fch * 4;
-    if (c0 >= p.C_out) continue;
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.epi == MBX_EPI_AFFINE || p.epi == MBX_EPI_RESIDUAL) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (c0 + r < p.C_out) {
-          if (p.scale) sc[r] = p.scale[c0 + r];
-          if (p.shiftv) sh[r] = p.shiftv[c0 + r];
-        }
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-      if (!mok[b]) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-      if (p.epi == MBX_EPI_STORE_F32) {
-        float* yp = reinterpret_cast<float*>(p.y) + yo[b] + c0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r < p.C_out) yp[r] = v[r];
-        continue;
-      }
-      unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yo[b] + c0;
-      if (p.epi == MBX_EPI_AFFINE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
-      } else if (p.epi == MBX_EPI_RESIDUAL) {
-        const u32x2 sk = *reinterpret_cast<const u32x2*>(p.skip + so[b] + c0);
-        const float k0 = bf2f(sk.x & 0xffffu), k1 = bf2f(sk.x >> 16), k2 = bf2f(sk.y & 0xffffu), k3 = bf2f(sk.y >> 16);
-        v[0] = k0 + p.rscale * (v[0] + sh[0]);
-        v[1] = k1 + p.rscale * (v[1] + sh[1]);
-        v[2] = k2 + p.rscale * (v[2] + sh[2]);
-        v[3] = k3 + p.rscale * (v[3] + sh[3]);
-      } else {
-        if (p.rscale != 0.f) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= p.rscale;
-        }
-      }
-      if (p.epi == MBX_EPI_STORE && p.accumulate) {
-        const u32x2 old = *reinterpret_cast<const u32x2*>(yp);
-        v[0] += bf2f(old.x & 0xffffu); v[1] += bf2f(old.x >> 16);
-        v[2] += bf2f(old.y & 0xffffu); v[3] += bf2f(old.y >> 16);
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      unsigned short q[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] = f2bf(v[r]);
-      *reinterpret_cast<u32x2*>(yp) = u32x2{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16)};
-      if (p.stats) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float f = bf2f(q[r]); s1[a][r] += f; s2[a][r] += f * f; }
-      }
-    }
-  }
-
-  if (p.stats) {
-    // per-channel partial sums of this block's BM pixels: reduce over the 16 pixel lanes,
-    // then over the WMW pixel-waves through LDS (free after the K loop's last barrier).
-    float* red = reinterpret_cast<float*>(smem);   // [WMW][BN][2]
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
-        if (frow == 0) {
-          const int cl = wn * TN + a * 16 + fch * 4 + r;
-          red[(wm * BN + cl) * 2 + 0] = x1;
-          red[(wm * BN + cl) * 2 + 1] = x2;
-        }
-      }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.C_out) {
-      float x1 = 0.f, x2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-      float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
-      o[0] = x1;
-      o[1] = x2;
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------
-// v2: the same GEMM, staged by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip) into a
+// The GEMM loop: tiles staged by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip) into a
 // 3-deep ring of 64-deep K tiles: tile t+2 is in flight while tile t is multiplied, so two tiles of
-// global latency are covered per block.  The LDS image is the XOR-swizzled [row][8 chunks] layout of
-// v1; because an LDS-DMA wave-instruction writes 64 consecutive 16-B slots (8 rows x 8 chunks), the
+// global latency are covered per block.  The LDS image is the XOR-swizzled [row][8 chunks] layout;
+// because an LDS-DMA wave-instruction writes 64 consecutive 16-B slots (8 rows x 8 chunks), the
 // swizzle is applied to the SOURCE chunk each lane fetches (chunk = slot ^ (row & 7)).
 // Counted s_waitcnt vmcnt + raw s_barrier: nothing in the loop drains the DMA queue.
 // LDS-DMA: 16 B per lane from buffer offset `off` to lds_dst + lane (lds_dst wave-uniform); offsets
@@ -587,135 +362,8 @@ struct WgradK {
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* tile, int row0, int cb, int lane) {
-  // rows row0 + 8*(lane>>4) + {0..7}, columns 16*cb + (lane & 15); tile rows are 256 B (16 chunks)
-  const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
-  const int r_lo = row0 + 8 * g + q, r_hi = r_lo + 4;
-  const int ch = 2 * cb + (pp >> 1);
-  const unsigned short* a_lo = tile + r_lo * 128 + ((ch ^ wg_swz(r_lo)) << 3) + ((pp & 1) << 2);
-  const unsigned short* a_hi = tile + r_hi * 128 + ((ch ^ wg_swz(r_hi)) << 3) + ((pp & 1) << 2);
-  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_lo));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_hi));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-__global__ void __launch_bounds__(kThreads)
-conv_wgrad_kernel(const WgradK p) {
-  // block tile: 128 output channels x 128 k-columns, 64 pixels per step
-  __shared__ __attribute__((aligned(16))) unsigned short sY[2][64 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned short sX[2][64 * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 1, wk = wave >> 1;
-  // 1-D grid, XCD-aware: all (n, k) tiles of one pixel split run on one XCD, so the split's dy / x
-  // panels are fetched into that L2 once instead of once per XCD.
-  const int ntiles = p.tiles_n * p.tiles_k;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = lid % ntiles, split = lid / ntiles;
-  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
-
-  const int lrow = tid >> 2, cq = tid & 3;           // row 0..63, chunks cq + 4*i
-  // fixed per-thread k-column decode (chunk of 8 input channels at one tap)
-  int tr_[4], ts_[4], toff[4], yoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + (cq + 4 * i) * 8;
-    const bool kv = k < p.Ktot;
-    const int kk = kv ? k : 0;
-    const int tap = kk / p.C_in, tc = kk - tap * p.C_in;
-    tr_[i] = kv ? tap / p.S : (1 << 24);              // invalid columns fail the bounds check
-    ts_[i] = tap - (tap / p.S) * p.S;
-    toff[i] = ((tr_[i] * p.W_in + ts_[i]) * p.ldx + tc) * 2;
-    yoff[i] = (n0 + (cq + 4 * i) * 8 < p.C_out) ? (n0 + (cq + 4 * i) * 8) * 2 : -1;
-  }
-  u32x4 ry[4], rx[4];
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;                                   // bias gradient: channel n0 + tid (tid < 128)
-  const bool do_bias = p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
-  const int sw_st = wg_swz(lrow);
-
-  // One code instance of load / compute / store; the first iteration only stages step 0.
-  int it = -1;
-  for (int ms = m_begin - 64; ms < m_end; ms += 64, ++it) {
-    const bool stage = ms + 64 < m_end;
-    if (stage) {
-      const int m = ms + 64 + lrow;
-      const bool mv = m < m_end;
-      const unsigned mm = mv ? (unsigned)m : 0u;
-      const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), pix = (int)mm - img * p.HW_out;
-      const int oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w), ow = pix - oh * p.W_out;
-      const int hb = mv ? oh * p.stride - p.pad_t : -(1 << 25), wb = ow * p.stride - p.pad_l;
-      const int xrow = (img * p.x_img_stride + (hb * p.W_in + wb) * p.ldx) * 2;
-      const int yrow = (img * p.dy_img_stride + pix * p.ld_dy) * 2;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ry[i] = buf_load16(yr, (mv && yoff[i] >= 0) ? (unsigned)(yrow + yoff[i]) : kOOB);
-        const bool ok = ((unsigned)(hb + tr_[i]) < (unsigned)p.H_in) && ((unsigned)(wb + ts_[i]) < (unsigned)p.W_in);
-        rx[i] = buf_load16(xr, ok ? (unsigned)(xrow + toff[i]) : kOOB);
-      }
-    }
-    if (it >= 0) {
-      const unsigned short* cY = sY[it & 1];
-      const unsigned short* cX = sX[it & 1];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 yf[4], xf[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) yf[a] = tr_frag(cY, kk * 32, wn * 4 + a, lane);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) xf[b] = tr_frag(cX, kk * 32, wk * 4 + b, lane);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
-      }
-      if (do_bias) {
-        const int ch = tid >> 3, e = tid & 7;
-        for (int r = 0; r < 64; ++r) bsum += bf2f(cY[r * 128 + ((ch ^ wg_swz(r)) << 3) + e]);
-      }
-    }
-    if (stage) {
-      unsigned short* dY = sY[(it + 1) & 1];
-      unsigned short* dX = sX[(it + 1) & 1];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ch = (cq + 4 * i) ^ sw_st;
-        *reinterpret_cast<u32x4*>(&dY[lrow * 128 + ch * 8]) = ry[i];
-        *reinterpret_cast<u32x4*>(&dX[lrow * 128 + ch * 8]) = rx[i];
-      }
-    }
-    __syncthreads();
-  }
-  // D[row = channel (lane>>4)*4 + r][col = k-column lane & 15]
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
-      if (kc >= p.Ktot) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
-    }
-  }
-  if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
-}
-
 // ------------------------------------------------------------------------------------------
-// wgrad v2: same tiling and transpose-read MFMA loop, tiles staged by LDS-DMA into an NST-deep ring.
+// The kernel: 128 x 128 output tile, 64 pixels per step, tiles staged by LDS-DMA into an NST-deep ring.
 // One DMA wave-instruction fills 4 rows x 16 chunks; the swizzle moves to the source chunk
 // (chunk = slot ^ swz(row), constant per lane because row & 3 and row bit 3 are lane constants).
 // Pixel rows advance by 16 per instruction: decoded once, then stepped incrementally; 1x1 convs
@@ -932,11 +580,6 @@ int pick_cfg(long M, int C_out) {
 }
 
 
-bool use_v1() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MBX_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
 
 int choose_cfg(long M, int C_out) {
   static int force = -2;
@@ -944,7 +587,7 @@ int choose_cfg(long M, int C_out) {
   if (force >= 0) return force;
   // measured on MI355X (tools/kbench.py): the eight-wave 256x128 tile wins when there are enough pixels to
   // fill the chip with one block per CU and at least two 128-channel column tiles; otherwise the model.
-  if (!use_v1() && C_out >= 256) {
+  if (C_out >= 256) {
     const long tiles5 = ((M + 255) / 256) * ((C_out + 127) / 128);
     const long rounds5 = (tiles5 + 255) / 256;              // one 8-wave block per CU
     if (tiles5 >= 128 && (double)tiles5 / (double)(rounds5 * 256) >= 0.7) return 5;
@@ -956,21 +599,7 @@ template <int BM, int BN, int WNW, int WMW>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
-  bool done_v1 = false;
-  if constexpr (WNW * WMW == 4) {
-    if (use_v1()) {
-      const size_t lds = 2 * (size_t)(BM + BN) * 128;
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WNW, WMW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-      }
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WNW, WMW>), dim3(k.tiles_m * k.tiles_n), dim3(kThreads), lds, s, k);
-      done_v1 = true;
-    }
-  }
-  if (!done_v1) {
+  {
     const size_t lds = 3 * (size_t)(BM + BN) * 128;
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
                    : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
@@ -1090,8 +719,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   static int target = 0;
   if (!target) {
     const char* g1 = getenv("MBX_WGRAD_NG");
-    const bool v1e = getenv("MBX_WGRAD_V1") != nullptr;
-    const int dflt = ((g1 && g1[0] == '1') || v1e) ? 512 : 256;       // 8-wave blocks: one per CU
+    const int dflt = (g1 && g1[0] == '1') ? 512 : 256;                // 8-wave blocks: one per CU
     const char* e = getenv("MBX_WGRAD_TARGET"); target = e ? atoi(e) : dflt; if (target < 1) target = dflt;
   }
   int splits = target / tiles;                 // floor: all blocks resident in one round (2 per CU)
@@ -1113,11 +741,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.H_out = d->H_out;
   k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
   k.dy_bytes = (unsigned)(2 * ((long long)(d->N - 1) * dy_img_stride + ((long long)k.HW_out - 1) * ld_dy + ((d->C_out + 7) / 8) * 8));
-  static int v1 = -1;
-  if (v1 < 0) { const char* e = getenv("MBX_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
-  if (v1) {
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(kThreads), 0, mbx_s(stream), k);
-  } else {
+  {
     WgradK2 k2;
     k2.b = k;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k2.dbg = dbg; }
