@@ -3,8 +3,9 @@
 (`results-dense-<global_step>.json`, detect.py:438-460).  Forward pass + decode/clip/filter/
 top-K/convert all run on the GPU (libmbx); NO NMS, exactly like the reference.
 
-Not yet wired: --tfrecords multi-crop input; `--synthetic N` feeds N seeded
-synthetic patches with whole-image metadata instead."""
+`--tfrecords` runs the reference's multi-crop input (original / flipped / sliding crops per
+config.yaml DETECTION, detect.py:134-292) through multibox_amd/inputs.py (host, PIL JPEG decode, TF-0.11
+bilinear resize); `--synthetic N` feeds N seeded synthetic patches with whole-image metadata instead."""
 import argparse
 import json
 import os
@@ -26,6 +27,8 @@ def parse_args():
                    help="accepted for compatibility; unused by the reference too (detect.py:294)")
     p.add_argument("--save_dir", dest="save_dir", type=str, required=True)
     p.add_argument("--synthetic", type=int, default=0, help="[new] number of synthetic images instead of --tfrecords")
+    p.add_argument("--keep_partial_batch", action="store_true",
+                   help="[new] also process the last incomplete batch (the reference's tf.train.batch drops it)")
     return p.parse_args()
 
 
@@ -40,8 +43,8 @@ def main():
     print("Command line arguments:")
     pprint.pprint(vars(args))
     cfg = with_defaults(parse_config_file(args.config_file))
-    if args.tfrecords and not args.synthetic:
-        raise SystemExit("--tfrecords input is not wired yet (SURVEY 8f F3); run with --synthetic N")
+    if not args.tfrecords and not args.synthetic:
+        raise SystemExit("give --tfrecords FILE... or --synthetic N")
     g.build()
     bbox_priors = PR.load_priors(args.priors)
     ckpt = CK.latest_checkpoint(args.checkpoint_path)
@@ -53,20 +56,32 @@ def main():
     global_step = CK.restore_for_inference(ckpt, net)
     print("Found model for global step: %d" % global_step)
     det = cfg.get("DETECTION", {})
-    max_keep = int(det.get("ORIGINAL_IMAGE_MAX_TO_KEEP", 200))
-    pp = D.DetectPostprocess(bbox_priors, B, k_max=max(max_keep, 1))
+    keeps = [int(det.get("ORIGINAL_IMAGE_MAX_TO_KEEP", 200)), int(det.get("FLIPPED_IMAGE_MAX_TO_KEEP", 0))]
+    keeps += [int(c.MAX_TO_KEEP) for c in (det.get("CROPS", None) or [])]
+    max_keep = max(keeps + [1])
+    pp = D.DetectPostprocess(bbox_priors, B, k_max=max_keep)
     conf = torch.empty((B, net.P), dtype=torch.float32, device="cuda")
     results, step = [], 0
-    n_images = args.synthetic
     S = cfg.INPUT_SIZE
-    for start in range(0, n_images - n_images % B if n_images >= B else 0, B):
-        rng = np.random.RandomState(start)
-        images = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
-        ids = np.arange(start, start + B)
-        meta = D.make_patch_meta(np.zeros((B, 2), np.int32), np.tile([[S, S]], (B, 1)), np.zeros((B, 1), np.int32),
-                                 np.tile([[0., 0., 1., 1.]], (B, 1)), np.full((B, 1), max_keep), np.tile([[S, S]], (B, 1)))
+
+    def synthetic_batches():
+        n_images = args.synthetic
+        for start in range(0, n_images - n_images % B if n_images >= B else 0, B):
+            rng = np.random.RandomState(start)
+            yield dict(images=rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32), offsets=np.zeros((B, 2), np.int32),
+                       dims=np.tile([[S, S]], (B, 1)), is_flipped=np.zeros((B, 1), np.int32),
+                       restrictions=np.tile([[0., 0., 1., 1.]], (B, 1)), max_to_keep=np.full((B, 1), keeps[0]),
+                       image_hw=np.tile([[S, S]], (B, 1)), image_ids=list(range(start, start + B)))
+    if args.tfrecords and not args.synthetic:
+        from multibox_amd.inputs import detect_batches
+        batches = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch)
+    else:
+        batches = synthetic_batches()
+    for batch in batches:
+        meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
+                                 batch["max_to_keep"], batch["image_hw"])
         t = time.time()
-        net.set_input(torch.from_numpy(images).cuda())
+        net.set_input(torch.from_numpy(batch["images"]).cuda())
         locs, logits = net.forward()
         _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "sigmoid")
@@ -76,6 +91,7 @@ def main():
         boxes, scores, _, count = pp(locs, conf, meta)
         torch.cuda.synchronize()
         dt2 = time.time() - t2
+        ids = [int(i) if str(i).lstrip("-").isdigit() else i for i in batch["image_ids"]]     # detect.py:410 int(image_id)
         results += D.results_to_json_records(boxes, scores, count, ids)
         step += 1
         print("Step: %d, Time/image (ms): %.1f, Post-process/image (ms): %.3f" % (step, dt / B * 1000, dt2 / B * 1000))

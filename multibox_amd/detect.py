@@ -84,5 +84,5 @@ def results_to_json_records(boxes, scores, count, image_ids):
     out = []
     for b in range(boxes.shape[0]):
         for k in range(int(count[b])):
-            out.append({"image_id": int(image_ids[b]), "bbox": boxes[b, k].tolist(), "score": float(scores[b, k])})
+            out.append({"image_id": image_ids[b], "bbox": boxes[b, k].tolist(), "score": float(scores[b, k])})
     return out

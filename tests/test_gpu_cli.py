@@ -63,3 +63,44 @@ def test_train_then_detect(tmp_path):
         per_image.setdefault(x["image_id"], []).append(x["score"])
     assert len(per_image) == 8 and all(len(v) <= 200 for v in per_image.values())
     assert all(v == sorted(v, reverse=True) for v in per_image.values())    # detect.py:423 sort by confidence
+
+
+def test_detect_from_tfrecords(tmp_path):
+    """detect.py --tfrecords: the reference's multi-crop input (detect.py:134-292) end to end on three JPEG images."""
+    import __graft_entry__ as g
+    g.build()
+    import torch
+    from multibox_amd import priors as PR, checkpoint as CK
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    from tests.test_inputs_cpu import _make_records
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CFG + """  USE_FLIPPED_ORIGINAL_IMAGE : true
+  FLIPPED_IMAGE_MAX_TO_KEEP : 100
+  CROPS :
+    - HEIGHT : 299
+      WIDTH : 299
+      HEIGHT_STRIDE : 113
+      WIDTH_STRIDE : 113
+      FLIP : false
+      MAX_TO_KEEP : 50
+""")
+    pri = tmp_path / "priors.pkl"
+    priors = PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.])
+    PR.save_priors(str(pri), priors)
+    rec = str(tmp_path / "val.tfrecords")
+    _make_records(rec, [(320, 420, []), (300, 300, []), (412, 412, [])])      # patches: 2+1, 2+1, 2+4 = 12
+    net = Net(batch=4, input_size=299, k=5, mode="train")
+    tr = Trainer(net, np.array(priors, np.float32), use_graph=False)
+    CK.save(str(tmp_path / "log"), tr)
+    del tr, net
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "detect.py"), "--priors", str(pri), "--checkpoint_path", str(tmp_path / "log"),
+                        "--config", str(cfg), "--save_dir", str(tmp_path / "out"), "--tfrecords", rec],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(tmp_path / "out" / "results-dense-0.json"))
+    ids = sorted(set(x["image_id"] for x in res))
+    assert ids == [1000, 1001, 1002] and "Step: 3" in r.stdout
+    b = np.array([x["bbox"] for x in res])
+    assert (b >= 0).all() and (b <= 1).all()

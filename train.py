@@ -3,9 +3,10 @@
 same priors.pkl; the step runs on libmbx (one process per GPU; launch with torch.distributed.run
 for data parallelism).
 
-Not yet wired: --tfrecords input (F1: TFRecord/JPEG/augmentation pipeline) and
---pretrained_model import of TF checkpoints (F2).  Until then `--synthetic` feeds seeded
-synthetic batches of the reference's input contract (inputs.py:340-351)."""
+`--tfrecords` reads the reference's TFRecords (inputs.py:225-247) through multibox_amd/inputs.py WITHOUT the
+random augmentations (set DO_RANDOM_BBOX_SHIFT / DO_RANDOM_CROP / DO_COLOR_DISTORTION to 0; the seeded flip is
+supported) -- SURVEY 8f F1, first cut; `--synthetic` feeds seeded synthetic batches of the same input contract
+(inputs.py:340-351).  Not yet wired: --pretrained_model import of TF checkpoints (F2)."""
 import argparse
 import json
 import os
@@ -56,8 +57,8 @@ def main():
         cfg.NUM_TRAIN_ITERATIONS = args.max_number_of_steps
     if args.batch_size is not None:
         cfg.BATCH_SIZE = args.batch_size
-    if args.tfrecords and not args.synthetic:
-        raise SystemExit("--tfrecords input is not wired yet (SURVEY 8f F1); run with --synthetic")
+    if not args.tfrecords and not args.synthetic:
+        raise SystemExit("give --tfrecords FILE... or --synthetic")
     if args.pretrained_model and not os.path.exists(args.pretrained_model):
         raise SystemExit("pretrained model not found: %s" % args.pretrained_model)
     if args.trainable_scopes:
@@ -91,8 +92,16 @@ def main():
     t_save = t_log = time.time()
     log = open(os.path.join(args.logdir, "train_log.jsonl"), "a") if rank == 0 and (os.makedirs(args.logdir, exist_ok=True) or True) else None
     step0 = tr.global_step
+    real = None
+    if args.tfrecords and not args.synthetic:
+        from multibox_amd.inputs import train_batches
+        files = args.tfrecords[rank::world] if len(args.tfrecords) >= world else args.tfrecords     # shard files over ranks
+        real = train_batches(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + rank)
     while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
-        images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
+        if real is not None:
+            images, gt, n, _ = next(real)
+        else:
+            images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
         tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
         tr.step()
         if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
