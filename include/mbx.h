@@ -184,24 +184,21 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
  * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
 int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,
                 int C, float* scale, float* shift, mbx_stream_t stream);
-/* Backward through relu + batch norm.  g = da * (a > 0) (relu) ; xhat = (y-mean)*rstd;
+/* Backward through relu + batch norm.  xhat = (y-mean)*rstd;  g = da * (a > 0) (relu) -- or, when
+ * relu != 0 and a == NULL, g = da * (xhat + beta > 0): the mask is recomputed from y with the forward
+ * expression, so the activation is not read at all (`beta` is only needed for that form).
  * pass 1 writes partial sums {sum g, sum g*xhat} [rows,C,2]; mbx_bn_bwd_finalize reduces them,
  * ACCUMULATES dbeta += sum g and stores m1 = sum g / M, m2 = sum g*xhat / M;
- * pass 2: dy = rstd * (g - m1 - xhat*m2)  (bf16 [M,C]).                                     */
+ * pass 2: dy = rstd * (g - m1 - xhat*m2)  (bf16 [M,C]).                                          */
 int mbx_bn_bwd_rows(int64_t M, int C);
 int mbx_bn_bwd_reduce(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y,
-                      int64_t M, int C, const float* mean, const float* rstd,
+                      int64_t M, int C, const float* mean, const float* rstd, const float* beta,
                       float* partial /*[mbx_bn_bwd_rows,C,2]*/, mbx_stream_t stream);
 int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_t M, float* dbeta /*[C] +=*/,
                         float* m12 /*[2,C]*/, mbx_stream_t stream);
 int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y,
-                     int64_t M, int C, const float* mean, const float* rstd, const float* m12,
-                     void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
-
-/* mbx_bn_bwd_finalize + mbx_bn_bwd_apply in ONE launch (partial = output of mbx_bn_bwd_reduce).       */
-int mbx_bn_bwd_apply_fused(const float* partial, int rows, float* dbeta /*[C] +=*/, const void* da,
-                           int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
-                           const float* mean, const float* rstd, void* dy, mbx_stream_t stream);
+                     int64_t M, int C, const float* mean, const float* rstd, const float* beta,
+                     const float* m12, void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
 
 /* ---------------------------------------------------------------------- pooling (K9)
  * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap

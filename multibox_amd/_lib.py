@@ -45,11 +45,10 @@ _SIGS = {
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
-    "mbx_bn_bwd_apply_fused": (I, [P, I, P, P, I, P, I, I, P, C.c_int64, I, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
-    "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P]),
+    "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P]),
     "mbx_bn_bwd_finalize": (I, [P, I, I, C.c_int64, P, P, P]),
-    "mbx_bn_bwd_apply": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P]),
+    "mbx_bn_bwd_apply": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),
     "mbx_maxpool_fwd": (I, [P, C.c_int64, I, I, I, I, I, I, I, P, C.c_int64, I, I, I, P, P]),
     "mbx_maxpool_bwd": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, I, I, P, C.c_int64, I, I, P]),
     "mbx_avgpool_fwd": (I, [P, C.c_int64, I, I, I, I, I, I, I, P, C.c_int64, I, I, I, P]),

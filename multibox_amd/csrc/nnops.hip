@@ -111,19 +111,25 @@ inline BnBwdGeom bn_bwd_geom(long long M, int C) {
   return g;
 }
 
+// MASK: 0 = no relu, 1 = relu mask from the stored activation (a > 0), 2 = relu mask recomputed from y with
+// the forward expression ((y-mean)*rstd+beta > 0), so that `a` is not read at all (4 instead of 6 bytes/element).
+template <int MASK>
 __global__ void __launch_bounds__(kT)
 bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
-                     int relu, const unsigned short* __restrict__ y, long long M, int C,
-                     const float* __restrict__ mean, const float* __restrict__ rstd, int rpi, int rpb,
-                     float* __restrict__ partial) {
+                     const unsigned short* __restrict__ y, long long M, int C,
+                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
+                     int rpi, int rpb, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16]
   const int C8 = C >> 3;
   const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
   const bool active = rr < rpi;
   const int c = vc << 3;
-  float s1[8], s2[8], mu[8], rs[8];
+  float s1[8], s2[8], mu[8], rs[8], be[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[c + j]; rs[j] = rstd[c + j];
+    be[j] = MASK == 2 ? beta[c + j] : 0.f;
+  }
   const long long r0 = (long long)blockIdx.x * rpb;
   long long r1 = r0 + rpb;
   if (r1 > M) r1 = M;
@@ -132,12 +138,14 @@ bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const uns
       float g[8], yy[8], aa[8];
       unpack8(ld8(da + m * ld_da + c), g);
       unpack8(ld8(y + m * C + c), yy);
-      if (relu) unpack8(ld8(a + m * ld_a + c), aa);
+      if (MASK == 1) unpack8(ld8(a + m * ld_a + c), aa);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+        const float xh = (yy[j] - mu[j]) * rs[j];
+        const bool pass = MASK == 0 || (MASK == 1 ? aa[j] > 0.f : xh + be[j] > 0.f);
+        const float gj = pass ? g[j] : 0.f;
         s1[j] += gj;
-        s2[j] += gj * ((yy[j] - mu[j]) * rs[j]);
+        s2[j] += gj * xh;
       }
     }
   if (active) {
@@ -177,11 +185,12 @@ bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, double i
   }
 }
 
+template <int MASK>
 __global__ void __launch_bounds__(kT)
 bn_bwd_apply_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
-                    int relu, const unsigned short* __restrict__ y, long long M, int C,
-                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m12,
-                    unsigned short* __restrict__ dy) {
+                    const unsigned short* __restrict__ y, long long M, int C,
+                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
+                    const float* __restrict__ m12, unsigned short* __restrict__ dy) {
   const int C8 = C >> 3;
   const long long total = M * C8;
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
@@ -190,12 +199,13 @@ bn_bwd_apply_kernel(const unsigned short* __restrict__ da, int ld_da, const unsi
     float g[8], yy[8], aa[8], o[8];
     unpack8(ld8(da + m * ld_da + c), g);
     unpack8(ld8(y + m * C + c), yy);
-    if (relu) unpack8(ld8(a + m * ld_a + c), aa);
+    if (MASK == 1) unpack8(ld8(a + m * ld_a + c), aa);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
       const float rs = rstd[c + j];
       const float xh = (yy[j] - mean[c + j]) * rs;
+      const bool pass = MASK == 0 || (MASK == 1 ? aa[j] > 0.f : xh + beta[c + j] > 0.f);
+      const float gj = pass ? g[j] : 0.f;
       o[j] = rs * (gj - m12[c + j] - xh * m12[C + c + j]);
     }
     st8(dy + m * C + c, pack8(o));
@@ -259,57 +269,6 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
       f[j] = relu ? fmaxf(v, 0.f) : v;
     }
     st8(a + m * ld_a + c0 + vc, pack8(f));
-  }
-}
-
-__global__ void __launch_bounds__(kT)
-bn_bwd_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_M, float* __restrict__ dbeta,
-                          const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
-                          int relu, const unsigned short* __restrict__ y, long long M, int C,
-                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                          unsigned short* __restrict__ dy, int rows_per_chunk) {
-  __shared__ double red[4][kBnGroup][2];
-  __shared__ float s_mean[kBnGroup], s_rstd[kBnGroup], s_m1[kBnGroup], s_m2[kBnGroup];
-  const int c0 = blockIdx.x * kBnGroup;
-  const int cw = min(kBnGroup, C - c0);
-  {
-    const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    double s1 = 0.0, s2 = 0.0;
-    if (ch < cw)
-      for (int r = rl; r < rows; r += 4) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c0 + ch) * 2);
-        s1 += v.x; s2 += v.y;
-      }
-    red[rl][ch][0] = s1; red[rl][ch][1] = s2;
-    __syncthreads();
-    if (rl == 0 && ch < cw) {
-      for (int r = 1; r < 4; ++r) { s1 += red[r][ch][0]; s2 += red[r][ch][1]; }
-      s_m1[ch] = (float)(s1 * inv_M); s_m2[ch] = (float)(s2 * inv_M);
-      s_mean[ch] = mean[c0 + ch]; s_rstd[ch] = rstd[c0 + ch];
-      if (blockIdx.y == 0 && dbeta) dbeta[c0 + ch] += (float)s1;
-    }
-    __syncthreads();
-  }
-  const int V = cw >> 3;
-  const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
-  long long r_end = r_begin + rows_per_chunk;
-  if (r_end > M) r_end = M;
-  const long long total = (r_end - r_begin) * V;
-  for (long long i = threadIdx.x; i < total; i += kT) {
-    const long long m = r_begin + i / V;
-    const int vc = (int)(i % V) << 3;
-    float g[8], yy[8], aa[8], o[8];
-    unpack8(ld8(da + m * ld_da + c0 + vc), g);
-    unpack8(ld8(y + m * C + c0 + vc), yy);
-    if (relu) unpack8(ld8(a + m * ld_a + c0 + vc), aa);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gj = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
-      const float rs = s_rstd[vc + j];
-      const float xh = (yy[j] - s_mean[vc + j]) * rs;
-      o[j] = rs * (gj - s_m1[vc + j] - xh * s_m2[vc + j]);
-    }
-    st8(dy + m * C + c0 + vc, pack8(o));
   }
 }
 
@@ -644,17 +603,27 @@ extern "C" int mbx_bn_bwd_rows(int64_t M, int C) {
   return bn_bwd_geom(M, C).rows;
 }
 
+// relu with a == NULL: the mask is recomputed from y (needs beta) instead of read from the activation.
+static int bn_bwd_args_ok(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
+                          const float* mean, const float* rstd, const float* beta) {
+  if (!da || !y || !mean || !rstd || (relu && !a && !beta) || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || (a && ld_a % 8))
+    return 0;
+  return al16(da) && al16(y) && (!a || al16(a));
+}
+
 extern "C" int mbx_bn_bwd_reduce(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
-                                 int C, const float* mean, const float* rstd, float* partial, mbx_stream_t stream) {
-  if (!da || !y || !mean || !rstd || !partial || (relu && !a) || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || (relu && ld_a % 8))
-    return MBX_ERR_INVALID_ARG;
+                                 int C, const float* mean, const float* rstd, const float* beta, float* partial,
+                                 mbx_stream_t stream) {
+  if (!partial || !bn_bwd_args_ok(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta)) return MBX_ERR_INVALID_ARG;
   if (C > 2048) return MBX_ERR_UNSUPPORTED;
-  if (!al16(da) || !al16(y) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
   const BnBwdGeom g = bn_bwd_geom(M, C);
   MBX_ENTER();
   const size_t lds = (size_t)g.rows_per_iter * g.C8 * 16 * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.rows), dim3(kT), lds, mbx_s(stream), (cus)da, ld_da, (cus)a, ld_a, relu,
-                     (cus)y, (long long)M, C, mean, rstd, g.rows_per_iter, g.rpb, partial);
+#define MBX_BN_RED(MASK)                                                                                              \
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<MASK>, dim3(g.rows), dim3(kT), lds, mbx_s(stream), (cus)da, ld_da, (cus)a, \
+                     ld_a, (cus)y, (long long)M, C, mean, rstd, beta, g.rows_per_iter, g.rpb, partial)
+  if (!relu) MBX_BN_RED(0); else if (a) MBX_BN_RED(1); else MBX_BN_RED(2);
+#undef MBX_BN_RED
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -670,14 +639,16 @@ extern "C" int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_
 }
 
 extern "C" int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
-                                int C, const float* mean, const float* rstd, const float* m12, void* dy,
-                                mbx_stream_t stream) {
-  if (!da || !y || !mean || !rstd || !m12 || !dy || (relu && !a) || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || (relu && ld_a % 8))
+                                int C, const float* mean, const float* rstd, const float* beta, const float* m12,
+                                void* dy, mbx_stream_t stream) {
+  if (!m12 || !dy || !al16(dy) || !bn_bwd_args_ok(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta))
     return MBX_ERR_INVALID_ARG;
-  if (!al16(da) || !al16(y) || !al16(dy) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)da, ld_da, (cus)a,
-                     ld_a, relu, (cus)y, (long long)M, C, mean, rstd, m12, (us)dy);
+#define MBX_BN_APP(MASK)                                                                                            \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<MASK>, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)da,   \
+                     ld_da, (cus)a, ld_a, (cus)y, (long long)M, C, mean, rstd, beta, m12, (us)dy)
+  if (!relu) MBX_BN_APP(0); else if (a) MBX_BN_APP(1); else MBX_BN_APP(2);
+#undef MBX_BN_APP
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -817,23 +788,6 @@ extern "C" int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t 
   hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
                      1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
                      mvar, rpc);
-  MBX_LAUNCH_CHECK();
-  return MBX_OK;
-}
-
-extern "C" int mbx_bn_bwd_apply_fused(const float* partial, int rows, float* dbeta, const void* da, int ld_da, const void* a,
-                                      int ld_a, int relu, const void* y, int64_t M, int C, const float* mean,
-                                      const float* rstd, void* dy, mbx_stream_t stream) {
-  if (!partial || !da || !y || !mean || !rstd || !dy || (relu && !a) || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_da % 8 ||
-      (relu && ld_a % 8))
-    return MBX_ERR_INVALID_ARG;
-  if (!al16(da) || !al16(y) || !al16(dy) || (relu && !al16(a))) return MBX_ERR_INVALID_ARG;
-  MBX_ENTER();
-  int groups, chunks, rpc;
-  bn_fused_grid(M, C, groups, chunks, rpc);
-  hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), partial, rows,
-                     1.0 / (double)M, dbeta, (cus)da, ld_da, (cus)a, ld_a, relu, (cus)y, (long long)M, C, mean, rstd,
-                     (us)dy, rpc);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

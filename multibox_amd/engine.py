@@ -581,14 +581,17 @@ class Net:
                 rows = l.mbx_bn_bwd_rows(M, K)
                 scale, db, dy_C = 1.0, None, K
 
-                def pre(s, op=op, da=da, mean=mean, rstd=rstd, dbeta=dbeta, rows=rows, K=K, M=M):
-                    a = op.out
-                    _lib.check(l.mbx_bn_bwd_reduce(da.ptr, da.ld, a.ptr, a.ld, int(op.relu), op.y.data_ptr(), M, K,
-                                                   mean.data_ptr(), rstd.data_ptr(), self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce")
+                beta = self._sl(self.Bt, op.beta_off, K)
+
+                def pre(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, K=K, M=M):
+                    # relu mask recomputed from y (a = NULL): the activation is not re-read in the backward pass
+                    _lib.check(l.mbx_bn_bwd_reduce(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
+                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                                                   self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce")
                     _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, K, M, dbeta.data_ptr(),
                                                      self.m12.data_ptr(), s), "bn_bwd_finalize")
-                    _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, a.ptr, a.ld, int(op.relu), op.y.data_ptr(), M, K,
-                                                  mean.data_ptr(), rstd.data_ptr(), self.m12.data_ptr(),
+                    _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
+                                                  mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                   self.dy_scratch.data_ptr(), s), "bn_bwd_apply")
             ddesc = None
             if op.need_dx:

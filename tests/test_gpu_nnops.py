@@ -78,15 +78,20 @@ def test_bn_forward_backward(T, M, Cc, relu):
     dbeta = torch.ones(Cc, device="cuda")                   # accumulates on top of existing content
     m12 = torch.zeros(2 * Cc, device="cuda")
     dy = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
-    _lib.check(l.mbx_bn_bwd_reduce(dav.ptr, dav.ld, av.ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), partial.data_ptr(), S()))
-    _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta.data_ptr(), m12.data_ptr(), S()))
-    _lib.check(l.mbx_bn_bwd_apply(dav.ptr, dav.ld, av.ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), m12.data_ptr(), dy.data_ptr(), S()))
-    # the kernel masks with the STORED activation (bf16 a > 0); the reference with the float one: identical sets
-    # except where rounding flips a tiny positive to 0 -- tolerate through the tolerance on dbeta / dy.
-    assert torch.allclose(dbeta.cpu() - 1.0, br.grad, rtol=2e-3, atol=2e-2 * float(br.grad.abs().max()))
-    ok, msg = close_bf16(dy, yr.grad)
-    assert ok or float((dy.float().cpu() - yr.grad).abs().max()) < 2e-2 * float(yr.grad.abs().max()), "bn_bwd: " + msg
-    # ---- the fused one-launch forms give the same results as the two-launch forms
+    # two forms of the relu mask: read from the stored activation, or (a = NULL) recomputed from y and beta
+    for a_ptr in (av.ptr, None):
+        dbeta.fill_(1.0)
+        _lib.check(l.mbx_bn_bwd_reduce(dav.ptr, dav.ld, a_ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(),
+                                       bd.data_ptr(), partial.data_ptr(), S()))
+        _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta.data_ptr(), m12.data_ptr(), S()))
+        _lib.check(l.mbx_bn_bwd_apply(dav.ptr, dav.ld, a_ptr, av.ld, relu, yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(),
+                                      bd.data_ptr(), m12.data_ptr(), dy.data_ptr(), S()))
+        # the kernel masks with the STORED activation (bf16 a > 0); the reference with the float one: identical sets
+        # except where rounding flips a tiny positive to 0 -- tolerate through the tolerance on dbeta / dy.
+        assert torch.allclose(dbeta.cpu() - 1.0, br.grad, rtol=2e-3, atol=2e-2 * float(br.grad.abs().max()))
+        ok, msg = close_bf16(dy, yr.grad)
+        assert ok or float((dy.float().cpu() - yr.grad).abs().max()) < 2e-2 * float(yr.grad.abs().max()), "bn_bwd: " + msg
+    # ---- the fused one-launch form gives the same results as the two-launch form
     av2 = ops.View.alloc(1, 1, M, Cc + 8, zero=True).slice(8, Cc)
     dm2, dr2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     mm2, mv2 = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
@@ -94,11 +99,6 @@ def test_bn_forward_backward(T, M, Cc, relu):
                                     dm2.data_ptr(), dr2.data_ptr(), mm2.data_ptr(), mv2.data_ptr(), S()))
     assert torch.equal(av2.tensor(), av.tensor()) and torch.equal(dm2, dm) and torch.equal(dr2, dr)
     assert torch.equal(mm2, mm) and torch.equal(mv2, mv)
-    dbeta2 = torch.ones(Cc, device="cuda")
-    dy2 = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
-    _lib.check(l.mbx_bn_bwd_apply_fused(partial.data_ptr(), rows, dbeta2.data_ptr(), dav.ptr, dav.ld, av.ptr, av.ld, relu,
-                                        yd.data_ptr(), M, Cc, dm.data_ptr(), dr.data_ptr(), dy2.data_ptr(), S()))
-    assert torch.equal(dy2, dy) and torch.equal(dbeta2, dbeta)
 
 
 def test_bn_fold(T):
