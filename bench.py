@@ -148,7 +148,8 @@ def main():
     B = args.batch
     ars = DEFAULT_ASPECT_RATIOS[args.k]
     priors = np.array(PR.generate_priors(ars), np.float32)
-    net = Net(batch=B, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2)
+    net = Net(batch=B, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2,
+              bn_max_workgroups=192 if world > 1 else 0)     # N>1: leave CUs to the RCCL kernels of the bucket in flight
     tr = Trainer(net, priors, max_num_bboxes=args.max_num_bboxes, location_loss_alpha=1000.0,
                  decay_steps_=decay_steps(56945, B * world, 4), use_graph=not args.no_graph, process_group=pg)
     images, gt, n = synthetic_batch(B, args.input_size, args.max_num_bboxes, seed=100 * rank)    # each rank its own shard

@@ -200,6 +200,20 @@ int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int rel
                      int64_t M, int C, const float* mean, const float* rstd, const float* beta,
                      const float* m12, void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
 
+/* The same backward pass in ONE launch (relu mask recomputed from y): every workgroup keeps its slice of
+ * (da, y) in registers across a grid barrier, so da and y are read once.  Available when the layer fits
+ * one resident workgroup per CU (mbx_bn_bwd_onepass_supported; everything but the 5 stem layers at
+ * BATCH_SIZE 64); otherwise MBX_ERR_UNSUPPORTED and the caller uses the three launches above.
+ * `ws` (mbx_bn_bwd_onepass_workspace_bytes(C), 16-byte aligned) must be ZERO at launch; after the launch word
+ * [4*2*C] holds the grid size and word [4*2*C + 1] a barrier-timeout flag (0 unless the grid was not resident).  dbeta [C] += sum g (may be NULL).  max_workgroups: 0 = one
+ * workgroup per CU; a smaller positive number leaves CUs free for a concurrent stream (e.g. an RCCL
+ * all-reduce in flight), whose kernels would otherwise delay the barrier until they finish.              */
+size_t mbx_bn_bwd_onepass_workspace_bytes(int C);
+int mbx_bn_bwd_onepass_supported(int64_t M, int C, int max_workgroups);
+int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64_t M, int C,
+                       const float* mean, const float* rstd, const float* beta, float* dbeta /*[C] +=*/,
+                       void* dy /*bf16 [M,C]*/, void* ws, int max_workgroups, mbx_stream_t stream);
+
 /* ---------------------------------------------------------------------- pooling (K9)
  * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap
  * index, first maximum) is kept for the backward pass.  avg: k x k stride 1, pad `pad`

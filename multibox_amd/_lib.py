@@ -46,6 +46,9 @@ _SIGS = {
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
+    "mbx_bn_bwd_onepass_workspace_bytes": (C.c_size_t, [I]),
+    "mbx_bn_bwd_onepass_supported": (I, [C.c_int64, I, I]),
+    "mbx_bn_bwd_onepass": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P]),
     "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P]),
     "mbx_bn_bwd_finalize": (I, [P, I, I, C.c_int64, P, P, P]),
     "mbx_bn_bwd_apply": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),

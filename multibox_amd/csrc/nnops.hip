@@ -282,6 +282,204 @@ inline void bn_fused_grid(long long M, int C, int& groups, int& chunks, int& rpc
   chunks = (int)((M + rpc - 1) / rpc);
 }
 
+// ------------------------------------------------- batch norm backward: ONE pass over (da, y)
+// Both passes of the batch-norm backward need every element of da and y, with the per-channel totals in
+// between.  For all but the five stem layers the whole layer (M*C*4 bytes) fits in the register files of one
+// resident 512-thread workgroup per CU, so one launch keeps its slice in VGPRs across a grid barrier:
+//   load slice -> per-channel partial sums -> atomics into kObSlots accumulator copies -> grid barrier ->
+//   totals -> dy from the registers.
+// HBM traffic 4 B read + 2 B written per element instead of 8 + 2, and one launch instead of three.
+// The grid is never larger than the CU count and one workgroup always fits a CU, so every workgroup is
+// resident and the barrier cannot deadlock; the spin is bounded all the same (error flag in the workspace).
+constexpr int kObT = 512;
+constexpr int kObSlots = 4;
+constexpr int kObMaxNV = 20;
+constexpr int kObSub = 16, kObRel = 32, kObLine = 32;           // barrier: counters / release words, words per line
+constexpr int kObCtlWords = kObLine * (2 + kObSub + kObRel);     // line 0: {grid size, timeout flag}
+
+struct ObGeom { int C8, rpi, G, rpb, nv; };
+inline ObGeom ob_geom(long long M, int C, int ncu) {
+  ObGeom g;
+  g.C8 = C / 8;
+  g.rpi = g.C8 <= kObT ? kObT / g.C8 : 0;
+  if (g.rpi == 0) { g.G = g.rpb = 0; g.nv = 1 << 30; return g; }
+  long long G = (M + g.rpi - 1) / g.rpi;
+  if (G > ncu) G = ncu;
+  g.rpb = (int)((M + G - 1) / G);
+  g.G = (int)((M + g.rpb - 1) / g.rpb);                  // no empty workgroups
+  g.nv = (g.rpb + g.rpi - 1) / g.rpi;
+  return g;
+}
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ob_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ob_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);      // past the end -> zeros
+}
+__device__ __forceinline__ void ob_store16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 0);         // past the end -> dropped
+}
+
+template <int NV, bool RELU>
+__global__ void __launch_bounds__(kObT)
+bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ y,
+                      long long M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                      const float* __restrict__ beta, float* __restrict__ dbeta, unsigned short* __restrict__ dy,
+                      float* __restrict__ ws, int rpi, int rpb, float inv_M) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16] partial sums, then [2C] totals
+  const int C8 = C >> 3;
+  const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+  const bool active = rr < rpi;
+  const int c = vc << 3;
+  const long long r0 = (long long)blockIdx.x * rpb;
+  long long nr = (r0 + rpb > M ? M : r0 + rpb) - r0;                           // rows of this workgroup's slice
+  const int nrows = nr > 0 ? (int)nr : 0;
+  // slice-relative buffer descriptors: 32-bit offsets, rows past the slice read zeros / are not stored
+  // (an empty slice gets zero-length descriptors: nothing is ever addressed through them)
+  const __amdgpu_buffer_rsrc_t gr = ob_rsrc(da + r0 * ld_da, nrows ? (unsigned)(((nrows - 1) * ld_da + C) * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t yr = ob_rsrc(y + r0 * C, (unsigned)(nrows * C * 2));
+  const __amdgpu_buffer_rsrc_t dr = ob_rsrc(dy + r0 * C, (unsigned)(nrows * C * 2));
+  constexpr unsigned kPast = 0x80000000u;
+  u32x4 vg[NV], vy[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int lr = rr + i * rpi;
+    const bool ok = active && lr < nrows;
+    vg[i] = ob_load16(gr, ok ? (unsigned)((lr * ld_da + c) * 2) : kPast);   // zero gradient adds nothing to the sums
+    vy[i] = ob_load16(yr, ok ? (unsigned)((lr * C + c) * 2) : kPast);
+  }
+  float s1[8], s2[8], mu[8], rs[8], be[8];
+  {
+    const int cs = active ? c : 0;                        // idle lanes read channel 0 (their gradient is zero)
+    const float4 a0 = *reinterpret_cast<const float4*>(mean + cs), a1 = *reinterpret_cast<const float4*>(mean + cs + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(rstd + cs), b1 = *reinterpret_cast<const float4*>(rstd + cs + 4);
+    mu[0] = a0.x; mu[1] = a0.y; mu[2] = a0.z; mu[3] = a0.w; mu[4] = a1.x; mu[5] = a1.y; mu[6] = a1.z; mu[7] = a1.w;
+    rs[0] = b0.x; rs[1] = b0.y; rs[2] = b0.z; rs[3] = b0.w; rs[4] = b1.x; rs[5] = b1.y; rs[6] = b1.z; rs[7] = b1.w;
+    if (RELU) {
+      const float4 c0 = *reinterpret_cast<const float4*>(beta + cs), c1 = *reinterpret_cast<const float4*>(beta + cs + 4);
+      be[0] = c0.x; be[1] = c0.y; be[2] = c0.z; be[3] = c0.w; be[4] = c1.x; be[5] = c1.y; be[6] = c1.z; be[7] = c1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) be[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  }
+  // The empty volatile asms pin the order: one vector is expanded to floats at a time, and only the PACKED slice
+  // stays live across the barrier (the second phase re-derives xhat / the mask from it).  Without them the
+  // compiler expands the whole slice at once (16 floats per vector pair) and spills.
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    asm volatile("" : "+v"(vg[i]), "+v"(vy[i]));
+    float g[8], yy[8];
+    unpack8(vg[i], g);
+    unpack8(vy[i], yy);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yy[j] - mu[j]) * rs[j];
+      const float gj = (!RELU || xh + be[j] > 0.f) ? g[j] : 0.f;
+      s1[j] += gj;
+      s2[j] += gj * xh;
+    }
+    asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
+    asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
+  }
+  if (active) {
+    float* o = sred + ((size_t)rr * C8 + vc) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = s1[j]; o[8 + j] = s2[j]; }
+  }
+  __syncthreads();
+  float* acc = ws + (size_t)(blockIdx.x & (kObSlots - 1)) * 2 * C;
+  unsigned* ctl = reinterpret_cast<unsigned*>(ws + (size_t)kObSlots * 2 * C);
+  if (threadIdx.x < C8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int r = 0; r < rpi; ++r) {
+      const float* o = sred + ((size_t)r * C8 + threadIdx.x) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+    }
+    // stage the workgroup's sums as [2][C] behind the partials, so that the atomics below are lane-contiguous
+    float* t = sred + (size_t)rpi * C8 * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t[(threadIdx.x << 3) + j] = s1[j]; t[C + (threadIdx.x << 3) + j] = s2[j]; }
+  }
+  __syncthreads();
+  // one wave instruction = 64 consecutive floats: the memory-side atomic unit serialises per instruction and
+  // line (~24 ns each, measured: tools/atomic_bench.hip), so the layout decides the cost, not the lane count
+  for (int e = threadIdx.x; e < 2 * C; e += kObT) atomicAdd(acc + e, sred[(size_t)rpi * C8 * 16 + e]);
+  // ---- grid barrier.  Everything that is polled or counted sits on its own 128-byte line and is shared by few
+  // workgroups (the same 24 ns per access apply): arrivals go to kObSub counters, the last arrival of each to
+  // the top counter, the last of those sets kObRel release words; workgroup b polls release word b % kObRel.
+  // No __threadfence() here: a release fence writes back the whole L2 of the XCD (measured: ~45 us per launch).
+  // The only global writes before the barrier are device-scope atomics, which are performed at the memory
+  // side; waiting for their acknowledgement orders them before the arrival.
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned G = gridDim.x, b = blockIdx.x;
+    const unsigned sub = b % kObSub, n_sub = (G - sub + kObSub - 1) / kObSub, n_top = G < kObSub ? G : kObSub;
+    bool last = atomicAdd(ctl + kObLine * (1 + sub), 1u) == n_sub - 1;
+    if (last) last = atomicAdd(ctl + kObLine * (1 + kObSub), 1u) == n_top - 1;
+    if (last) {
+      for (int r = 0; r < kObRel; ++r)
+        __hip_atomic_store(ctl + kObLine * (2 + kObSub + r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned* rel = ctl + kObLine * (2 + kObSub + b % kObRel);
+      unsigned spins = 0;
+      while (ld_agent(rel) == 0u) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { ctl[1] = 1u; break; }         // cannot happen when the grid is resident
+      }
+    }
+    if (b == 0) ctl[0] = G;
+  }
+  __syncthreads();
+  // device-scope loads (served at the memory side like the atomics): no acquire fence, which would
+  // invalidate the XCD's L2
+  for (int e = threadIdx.x; e < 2 * C; e += kObT) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < kObSlots; ++sl) t += ld_agent(ws + (size_t)sl * 2 * C + e);
+    sred[e] = t;
+  }
+  __syncthreads();
+  float m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t1 = active ? sred[c + j] : 0.f;
+    m1[j] = t1 * inv_M;
+    m2[j] = (active ? sred[C + c + j] : 0.f) * inv_M;
+    if (blockIdx.x == 0 && rr == 0 && dbeta) dbeta[c + j] += t1;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int lr = rr + i * rpi;
+    const bool ok = active && lr < nrows;
+    asm volatile("" : "+v"(vg[i]), "+v"(vy[i]));          // re-derive from the packed registers HERE, not earlier
+    float g[8], yy[8], o[8];
+    unpack8(vg[i], g);
+    unpack8(vy[i], yy);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yy[j] - mu[j]) * rs[j];
+      const float gj = (!RELU || xh + be[j] > 0.f) ? g[j] : 0.f;
+      o[j] = rs[j] * (gj - m1[j] - xh * m2[j]);
+    }
+    ob_store16(dr, ok ? (unsigned)((lr * C + c) * 2) : kPast, pack8(o));
+    asm volatile("" ::: "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------- pooling
 __global__ void __launch_bounds__(kT)
 maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
@@ -649,6 +847,64 @@ extern "C" int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld
                      ld_da, (cus)a, ld_a, (cus)y, (long long)M, C, mean, rstd, beta, m12, (us)dy)
   if (!relu) MBX_BN_APP(0); else if (a) MBX_BN_APP(1); else MBX_BN_APP(2);
 #undef MBX_BN_APP
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+static int ob_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      return 0;
+    ncu = n;
+  }
+  return ncu;
+}
+
+extern "C" size_t mbx_bn_bwd_onepass_workspace_bytes(int C) {
+  return C > 0 ? ((size_t)kObSlots * 2 * C + kObCtlWords) * sizeof(float) : 0;
+}
+
+// workgroups the grid may use: all CUs, or fewer when the caller keeps some free for a concurrent stream
+static int ob_groups(int max_workgroups) {
+  const int ncu = ob_cus();
+  return (max_workgroups > 0 && max_workgroups < ncu) ? max_workgroups : ncu;
+}
+
+extern "C" int mbx_bn_bwd_onepass_supported(int64_t M, int C, int max_workgroups) {
+  if (M <= 0 || C <= 0 || C % 8) return 0;
+  const int ncu = ob_groups(max_workgroups);
+  if (ncu <= 0) return 0;
+  return ob_geom(M, C, ncu).nv <= kObMaxNV;
+}
+
+extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64_t M, int C, const float* mean,
+                                  const float* rstd, const float* beta, float* dbeta, void* dy, void* ws,
+                                  int max_workgroups, mbx_stream_t stream) {
+  if (!da || !y || !mean || !rstd || (relu && !beta) || !dy || !ws || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || !al16(da) ||
+      !al16(y) || !al16(dy) || !al16(ws) || !al16(mean) || !al16(rstd) || (relu && !al16(beta)))
+    return MBX_ERR_INVALID_ARG;
+  const int ncu = ob_groups(max_workgroups);
+  if (ncu <= 0) return MBX_ERR_LAUNCH;
+  const ObGeom g = ob_geom(M, C, ncu);
+  if (g.nv > kObMaxNV) return MBX_ERR_UNSUPPORTED;
+  MBX_ENTER();
+  const size_t lds = ((size_t)g.rpi * g.C8 * 16 + (size_t)2 * C) * sizeof(float);
+#define MBX_OB(NV, RELU)                                                                                               \
+  hipLaunchKernelGGL((bn_bwd_onepass_kernel<NV, RELU>), dim3(g.G), dim3(kObT), lds, mbx_s(stream), (cus)da, ld_da,      \
+                     (cus)y, (long long)M, C, mean, rstd, beta, dbeta, (us)dy, (float*)ws, g.rpi, g.rpb,               \
+                     (float)(1.0 / (double)M))
+#define MBX_OB_NV(NV) do { if (relu) MBX_OB(NV, true); else MBX_OB(NV, false); } while (0)
+  if (g.nv <= 2) MBX_OB_NV(2);
+  else if (g.nv <= 4) MBX_OB_NV(4);
+  else if (g.nv <= 8) MBX_OB_NV(8);
+  else if (g.nv <= 12) MBX_OB_NV(12);
+  else if (g.nv <= 16) MBX_OB_NV(16);
+  else MBX_OB_NV(20);
+#undef MBX_OB_NV
+#undef MBX_OB
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

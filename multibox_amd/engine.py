@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -68,13 +69,16 @@ class ConvOp:
 
 class Net:
     def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
-                 bn_decay=0.9997, repeats=(10, 20, 9)):
+                 bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0):
         """repeats: number of block35 / block17 / block8 repetitions (model.py:142,162,187); anything
         but the reference's (10, 20, 9) is a reduced-depth network for tests."""
         assert mode in ("train", "infer")
         self.repeats = tuple(repeats)
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
+        self.no_onepass = bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
+        # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
+        self.bn_max_wg = int(os.environ.get("MBX_BN_MAX_WG", "0")) or (bn_max_workgroups or 0)
         self.convs, self.fwd, self.bwd = [], [], []
         self.grad_alias = {}       # id(activation buffer) -> gradient buffer
         self.written = set()       # gradient regions already written in the backward pass (build time)
@@ -421,6 +425,14 @@ class Net:
                 if op.trainable:
                     max_y = max(max_y, op.M * op.K)
                     max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, op.K) * op.K * 2)
+        # one-launch BN backward: per-layer accumulators + arrival counter, zeroed with the gradients every step
+        ws_floats = 0
+        for op in self.convs:
+            op.bn_ws_off = -1
+            if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, op.K, self.bn_max_wg):
+                op.bn_ws_off = ws_floats
+                ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
+        self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
         self.dy_scratch = torch.zeros(max(max_y, 8), dtype=torch.bfloat16, device=dev)
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
@@ -583,6 +595,14 @@ class Net:
 
                 beta = self._sl(self.Bt, op.beta_off, K)
 
+                def pre_onepass(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, K=K, M=M):
+                    # da and y are read once: the slice stays in registers across a grid barrier
+                    _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, int(op.relu), op.y.data_ptr(), M, K, mean.data_ptr(),
+                                                    rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
+                                                    self.dy_scratch.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
+                                                    self.bn_max_wg, s),
+                               "bn_bwd_onepass")
+
                 def pre(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, K=K, M=M):
                     # relu mask recomputed from y (a = NULL): the activation is not re-read in the backward pass
                     _lib.check(l.mbx_bn_bwd_reduce(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
@@ -593,6 +613,8 @@ class Net:
                     _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                   self.dy_scratch.data_ptr(), s), "bn_bwd_apply")
+                if op.bn_ws_off >= 0 and not self.no_onepass:
+                    pre = pre_onepass
             ddesc = None
             if op.need_dx:
                 gx = self._gview(op.x)
@@ -644,6 +666,7 @@ class Net:
     def zero_grads(self):
         self.Wg.zero_()
         self.Btg.zero_()
+        self.bn_ws.zero_()          # accumulators / arrival counters of the one-launch BN backward
 
     def backward(self):
         """d_locs / d_logits must hold the loss gradients; fills Wg / Btg."""

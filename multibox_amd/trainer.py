@@ -110,8 +110,7 @@ class Trainer:
         net.set_input(self.images)
         net.forward()
         self.loss.forward_backward(net.locs, net.logits, self.gt, self.n_gt)
-        net.Wg.zero_()
-        net.Btg.zero_()
+        net.zero_grads()
 
     def _capture(self):
         """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture."""

@@ -100,6 +100,59 @@ def test_bn_forward_backward(T, M, Cc, relu):
     assert torch.equal(av2.tensor(), av.tensor()) and torch.equal(dm2, dm) and torch.equal(dr2, dr)
     assert torch.equal(mm2, mm) and torch.equal(mv2, mv)
 
+@pytest.mark.parametrize("M,Cc,relu", [(2450, 96, 1), (18496, 160, 1), (18496, 320, 1), (78400, 96, 1), (18496, 512, 0),
+                                       (18496, 768, 1), (78400, 208, 1), (78400, 256, 1), (4096, 1536, 1), (1001, 24, 1),
+                                       (7, 8, 0)])
+def test_bn_backward_onepass(T, M, Cc, relu):
+    """One-launch backward (slice in registers across a grid barrier) == the three-launch form, every register
+    variant (2..20 vectors per lane), ragged rows, channel counts that do not divide the workgroup."""
+    torch = T
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    assert l.mbx_bn_bwd_onepass_supported(M, Cc, 0) == 1
+    gen = torch.Generator().manual_seed(M * 31 + Cc)
+    y = (torch.randn(M, Cc, generator=gen) * 2 + 0.5).to(torch.bfloat16).cuda()
+    dav = ops.View.alloc(1, 1, M, Cc + 16, zero=True).slice(8, Cc)
+    dav.tensor().reshape(M, Cc).copy_(torch.randn(M, Cc, generator=gen).to(torch.bfloat16))
+    mean = y.float().mean(0).contiguous()
+    rstd = torch.rsqrt(y.float().var(0, unbiased=False) + 0.001).contiguous()
+    beta = (torch.randn(Cc, generator=gen) * 0.3).cuda()
+    rows = l.mbx_bn_bwd_rows(M, Cc)
+    partial = torch.zeros((rows, Cc, 2), device="cuda")
+    m12 = torch.zeros(2 * Cc, device="cuda")
+    dbeta_ref, dbeta = torch.ones(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    dy_ref = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
+    dy = torch.full((M + 1, Cc), 7.0, dtype=torch.bfloat16, device="cuda")      # guard row: nothing written past M
+    _lib.check(l.mbx_bn_bwd_reduce(dav.ptr, dav.ld, None, 0, relu, y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
+                                   beta.data_ptr(), partial.data_ptr(), S()))
+    _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta_ref.data_ptr(), m12.data_ptr(), S()))
+    _lib.check(l.mbx_bn_bwd_apply(dav.ptr, dav.ld, None, 0, relu, y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
+                                  beta.data_ptr(), m12.data_ptr(), dy_ref.data_ptr(), S()))
+    nws = l.mbx_bn_bwd_onepass_workspace_bytes(Cc) // 4
+    for max_wg in (0, 192):     # all CUs / a capped grid (the data-parallel setting)
+        if not l.mbx_bn_bwd_onepass_supported(M, Cc, max_wg):
+            continue
+        ws = torch.zeros(nws, device="cuda")
+        dbeta.fill_(1.0)
+        _lib.check(l.mbx_bn_bwd_onepass(dav.ptr, dav.ld, relu, y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
+                                        beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), max_wg, S()))
+        torch.cuda.synchronize()
+        flags = ws[4 * 2 * Cc:4 * 2 * Cc + 2].view(torch.int32).tolist()
+        assert flags[1] == 0, "grid barrier timed out"
+        assert flags[0] > 0
+        assert torch.allclose(dbeta, dbeta_ref, rtol=1e-4, atol=1e-3 * float(dbeta_ref.abs().max()))
+        ok, msg = close_bf16(dy[:M], dy_ref)
+        assert ok, msg
+        assert bool((dy[M] == 7.0).all())
+
+
+def test_bn_backward_onepass_unsupported(T):
+    from multibox_amd import _lib
+    l = _lib.lib()
+    assert l.mbx_bn_bwd_onepass_supported(64 * 147 * 147, 32, 0) == 0     # stem layers: three launches
+    assert l.mbx_bn_bwd_onepass_supported(100, 12, 0) == 0                # channels not a multiple of 8
+    assert l.mbx_bn_bwd_onepass_supported(78400, 256, 0) == 1 and l.mbx_bn_bwd_onepass_supported(78400, 256, 128) == 0
+
 
 def test_bn_fold(T):
     torch = T

@@ -74,7 +74,8 @@ def main():
         torch.distributed.barrier()
     bbox_priors = PR.load_priors(args.priors)                     # train.py:368-370
     net = Net(batch=cfg.BATCH_SIZE, input_size=cfg.INPUT_SIZE, k=cfg.NUM_BBOXES_PER_CELL, mode="train",
-              fine_tune=args.fine_tune, bn_decay=cfg.BATCHNORM_MOVING_AVERAGE_DECAY)
+              fine_tune=args.fine_tune, bn_decay=cfg.BATCHNORM_MOVING_AVERAGE_DECAY,
+              bn_max_workgroups=192 if world > 1 else 0)
     tr = Trainer(net, bbox_priors, max_num_bboxes=cfg.MAX_NUM_BBOXES, location_loss_alpha=cfg.LOCATION_LOSS_ALPHA,
                  initial_learning_rate=cfg.INITIAL_LEARNING_RATE,
                  decay_steps_=decay_steps(cfg.NUM_TRAIN_EXAMPLES, cfg.BATCH_SIZE, cfg.NUM_EPOCHS_PER_DELAY),
