@@ -1,0 +1,55 @@
+"""Join a rocprofv3 kernel trace of bench.py with the engine's launch order: per-layer time of the
+conv forward / data-gradient / weight-gradient kernels in the LAST step of the trace.
+usage: python tools/trace_by_layer.py gpurun_out/prof/x_kernel_trace.csv [batch]"""
+import csv, sys, os, re
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multibox_amd.engine import Net, ConvOp
+
+path = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+rows = [r for r in csv.DictReader(open(path))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+# the last step: from the last pack_input kernel to the end
+starts = [i for i, n in enumerate(names) if "pack_input" in n]
+step = rows[starts[-1]:]
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+ig = [r for r in step if "conv_igemm3" in r["Kernel_Name"]]
+wg = [r for r in step if "conv_wgrad2" in r["Kernel_Name"]]
+net = Net(batch=B, device="cpu")
+convs = [op for op in net.fwd if isinstance(op, ConvOp)]
+bw = [op for op in reversed(net.fwd) if isinstance(op, ConvOp) and op.trainable]
+n_f = len(convs)
+fwd = ig[:n_f]
+dg = ig[n_f:]
+dgi = iter(dg)
+rec = {}
+for op, r in zip(convs, fwd):
+    rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1), "fwd_grid": r["Grid_Size_X"]}
+for op, r in zip(bw, wg):
+    rec[id(op)]["wg"] = dur(r)
+    rec[id(op)]["wg_grid"] = "%sx%s" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"])
+    if op.need_dx:
+        d = next(dgi)
+        rec[id(op)]["dg"] = dur(d)
+        rec[id(op)]["dg_k"] = re.search(r"<([^>]*)>", d["Kernel_Name"]).group(1)
+print("%-58s %7s %5s %5s %3s | %7s %7s %7s | TF/s fwd dg wg | %s" % ("layer", "M", "Cin", "K", "RS", "fwd us", "dg us", "wg us", "cfg"))
+agg = {}
+tot = [0, 0, 0]
+for op in convs:
+    r = rec[id(op)]
+    fl = 2.0 * op.M * op.K * op.R * op.S * op.Cin
+    f, d, w = r["fwd"], r.get("dg", 0), r.get("wg", 0)
+    tot[0] += f; tot[1] += d; tot[2] += w
+    tf = lambda t: fl / t / 1e6 if t else 0
+    name = re.sub(r"_\d+/", "_N/", op.name.replace("InceptionResnetV2/", ""))[:58]
+    key = (name, op.M, op.Cin, op.K, op.R, op.S)
+    a = agg.setdefault(key, [0, 0, 0, 0, fl, r["fwd_k"], r.get("dg_k", ""), r.get("wg_grid", "")])
+    a[0] += f; a[1] += d; a[2] += w; a[3] += 1
+for key, a in agg.items():
+    name, M, Cin, K, R, S = key
+    n = a[3]
+    tf = lambda t: a[4] * n / t / 1e6 if t else 0
+    print("%-58s %7d %5d %5d %dx%d | %7.1f %7.1f %7.1f | %4.0f %4.0f %4.0f | x%d f<%s> d<%s> w[%s]" % (
+        name, M, Cin, K, R, S, a[0], a[1], a[2], tf(a[0]), tf(a[1]), tf(a[2]), n, a[5], a[6], a[7]))
+print("totals us: fwd %.0f dgrad %.0f wgrad %.0f" % tuple(tot))
