@@ -1,16 +1,22 @@
-"""Host-side input pipelines (SURVEY 8f, rows F1 and F3 -- first cut, no TensorFlow):
+"""Host-side input pipelines (no TensorFlow):
 
   * detect_batches(): the multi-crop patch generator of detect.input_nodes (detect.py:134-292) --
     original / flipped image resized to INPUT_SIZE, sliding crops (extract_patches, detect.py:20-72),
     per-patch metadata, batches of BATCH_SIZE patches across images; like tf.train.batch with
     enqueue_many the incomplete last batch is NOT emitted (detect.py:283-289).
-  * train_batches(): inputs.input_nodes (inputs.py:200-373) WITHOUT the random augmentations (bbox shift,
-    distorted crop, random resize method, colour distortion): decode, bilinear resize, optional seeded
-    left-right flip, gt padding to MAX_NUM_BBOXES (inputs.py:340-351).  The augmentations are not built yet.
+  * train_batches(): inputs.input_nodes (inputs.py:200-373): decode, random bbox shift
+    (inputs.py:184-203), distorted crop around the boxes (inputs.py:100-182 over the algorithm of TF's
+    sample_distorted_bounding_box op), resize by a randomly chosen method (bilinear / nearest / bicubic /
+    area, inputs.py:296-302), colour distortion (inputs.py:44-98, 312-320), left-right flip
+    (inputs.py:323-327), gt padding to MAX_NUM_BBOXES and [-1,1] scaling (inputs.py:338-351), shuffle
+    buffer (capacity / min_after_dequeue, inputs.py:353-362).
 
-JPEG decoding uses PIL (libjpeg), TF used its own libjpeg build: "parity unpinned" at the bit level.
-The bilinear resize restates TF-0.11's legacy kernel (align_corners=False: src = dst * in/out, no half-pixel
-offset), which torch's interpolate does not provide.
+Parity: the deterministic arithmetic (box shift clipping, crop -> box transform with the reference's clip-to-
+IMAGE-size quirk and minimum-area filter, padding, scaling) is restated exactly and tested; the RANDOM draws
+come from numpy's RandomState, not TF's Philox streams, and JPEG decoding uses PIL (libjpeg) where TF used
+its own build: "parity unpinned" at the bit level.  The bilinear resize restates TF-0.11's legacy kernel
+(align_corners=False: src = dst * in/out, no half-pixel offset), which torch's interpolate does not provide;
+nearest / bicubic / area follow the same legacy coordinate rule.
 """
 from __future__ import annotations
 
@@ -110,35 +116,264 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False):
         yield emit()
 
 
-def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, seed=0):
-    """Yield (images [B,S,S,3] in [-1,1], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B] int32, image_ids)."""
-    for key in ("DO_RANDOM_BBOX_SHIFT", "DO_RANDOM_CROP", "DO_COLOR_DISTORTION"):
-        if float(cfg.get(key, 0) or 0) > 0:
-            raise NotImplementedError("%s > 0: this augmentation of inputs.py is not built yet (SURVEY 8f F1)" % key)
-    rng = np.random.RandomState(seed)
+# ------------------------------------------------------------------ other resize methods (legacy TF kernels)
+def resize_nearest_tf(img, out_h, out_w):
+    """tf.image.resize_nearest_neighbor(align_corners=False), TF 0.11: src = min(floor(dst * in/out), in-1)."""
+    img = np.asarray(img, np.float32)
+    H, W = img.shape[0], img.shape[1]
+    ys = np.minimum(np.floor(np.arange(out_h, dtype=np.float32) * np.float32(H / float(out_h))).astype(np.int64), H - 1)
+    xs = np.minimum(np.floor(np.arange(out_w, dtype=np.float32) * np.float32(W / float(out_w))).astype(np.int64), W - 1)
+    return img[ys][:, xs]
+
+
+def _cubic_weights(frac, a=-0.75):
+    """Keys cubic convolution coefficients (A = -0.75, TF's resize_bicubic) for taps at -1, 0, +1, +2."""
+    t = frac.astype(np.float64)
+    w0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+    w1 = ((a + 2) * t - (a + 3)) * t * t + 1
+    w2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+    w3 = ((a * (2 - t) - 5 * a) * (2 - t) + 8 * a) * (2 - t) - 4 * a
+    return np.stack([w0, w1, w2, w3], 0)
+
+
+def resize_bicubic_tf(img, out_h, out_w):
+    """tf.image.resize_bicubic(align_corners=False), TF 0.11: src = dst * in/out, taps clamped to the image
+    (the kernel's 1024-entry coefficient table is replaced by the closed form: < 1e-3 difference)."""
+    img = np.asarray(img, np.float32)
+
+    def axis(x, n_in, n_out, ax):
+        pos = np.arange(n_out, dtype=np.float32) * np.float32(n_in / float(n_out))
+        i0 = np.floor(pos).astype(np.int64)
+        w = _cubic_weights(pos - i0)                                     # [4, n_out]
+        out = 0.0
+        for k in range(4):
+            idx = np.clip(i0 - 1 + k, 0, n_in - 1)
+            shape = [1] * x.ndim
+            shape[ax] = n_out
+            out = out + np.take(x, idx, axis=ax).astype(np.float64) * w[k].reshape(shape)
+        return out
+    return axis(axis(img, img.shape[0], out_h, 0), img.shape[1], out_w, 1).astype(np.float32)
+
+
+def resize_area_tf(img, out_h, out_w):
+    """tf.image.resize_area: every output pixel is the area-weighted mean of the source rectangle
+    [dst*scale, (dst+1)*scale) (fractional coverage of the border pixels)."""
+    img = np.asarray(img, np.float64)
+
+    def weights(n_in, n_out):
+        scale = n_in / float(n_out)
+        Wm = np.zeros((n_out, n_in), np.float64)
+        for o in range(n_out):
+            lo, hi = o * scale, (o + 1) * scale
+            i = int(np.floor(lo))
+            while i < hi and i < n_in:
+                Wm[o, i] = min(hi, i + 1) - max(lo, i)
+                i += 1
+            Wm[o] /= max(Wm[o].sum(), 1e-12)
+        return Wm
+    Wy, Wx = weights(img.shape[0], out_h), weights(img.shape[1], out_w)
+    return np.einsum("oh,hwc->owc", Wy, np.einsum("pw,hwc->hpc", Wx, img)).astype(np.float32)
+
+
+RESIZE_METHODS = (resize_bilinear_tf, resize_nearest_tf, resize_bicubic_tf, resize_area_tf)   # tf.image.ResizeMethod 0..3
+
+
+# ------------------------------------------------------------------------------- box augmentations
+def shift_bboxes(xmin, ymin, xmax, ymax, image_height, image_width, max_num_pixels_to_shift, rng):
+    """distorted_shifted_bounding_box (inputs.py:184-203): every side moves OUTWARDS by U[0, extent pixels), clipped
+    to [0, 1]."""
+    mw = np.float32(1.0 / float(image_width) * max_num_pixels_to_shift)
+    mh = np.float32(1.0 / float(image_height) * max_num_pixels_to_shift)
+    n = len(xmin)
+    xmin = xmin - rng.uniform(0, mw, n).astype(np.float32)
+    xmax = xmax + rng.uniform(0, mw, n).astype(np.float32)
+    ymin = ymin - rng.uniform(0, mh, n).astype(np.float32)
+    ymax = ymax + rng.uniform(0, mh, n).astype(np.float32)
+    c = lambda v: np.clip(v, np.float32(0.0), np.float32(1.0))
+    return c(xmin), c(ymin), c(xmax), c(ymax)
+
+
+def sample_distorted_bounding_box(height, width, boxes_yxyx, min_object_covered, aspect_ratio_range, area_range,
+                                  max_attempts, rng, use_image_if_no_bounding_boxes=True):
+    """The algorithm of tf.image.sample_distorted_bounding_box (TF 0.11 kernel): up to max_attempts times draw an
+    aspect ratio, a height between the ones that give the minimum / maximum area, a position; accept the first
+    crop that contains at least min_object_covered of ANY box; otherwise the whole image.
+    Returns (y, x, crop_h, crop_w) in pixels.  boxes: [n, 4] normalised (ymin, xmin, ymax, xmax)."""
+    rects = [(int(b[1] * width), int(b[0] * height), int(b[3] * width), int(b[2] * height)) for b in boxes_yxyx]
+    if not rects and use_image_if_no_bounding_boxes:
+        rects = [(0, 0, width, height)]
+    rint = lambda v: int(np.rint(np.float32(v)))
+    for _ in range(int(max_attempts)):
+        ar = rng.uniform(aspect_ratio_range[0], aspect_ratio_range[1])
+        min_area, max_area = area_range[0] * width * height, area_range[1] * width * height
+        if max_area <= 0 or ar <= 0:
+            continue
+        h = rint(np.sqrt(min_area / ar))
+        max_h = rint(np.sqrt(max_area / ar))
+        if rint(max_h * ar) > width:
+            max_h = int((width + 0.5 - 1e-7) / ar)
+        max_h = min(max_h, height)
+        h = min(h, max_h)
+        if h < max_h:
+            h += int(rng.randint(0, max_h - h + 1))
+        w = rint(h * ar)
+        if w * h < min_area:
+            h += 1
+            w = rint(h * ar)
+        area = w * h
+        if area < min_area or area > max_area or w > width or h > height or w <= 0 or h <= 0:
+            continue
+        y = int(rng.randint(0, height - h)) if h < height else 0
+        x = int(rng.randint(0, width - w)) if w < width else 0
+        for (bx0, by0, bx1, by1) in rects:
+            iw, ih = min(bx1, x + w) - max(bx0, x), min(by1, y + h) - max(by0, y)
+            inter = max(iw, 0) * max(ih, 0)
+            if (bx1 - bx0) * (by1 - by0) * min_object_covered <= inter:
+                return y, x, h, w
+    return 0, 0, height, width
+
+
+def crop_bboxes(xmin, ymin, xmax, ymax, image_height, image_width, crop, minimum_area):
+    """The box arithmetic of distorted_bounding_box_crop (inputs.py:128-180): boxes in pixels of the FEATURE image
+    size, clipped to the crop, shifted to its origin, clipped to [0, image size] (the reference clips to the image,
+    not the crop), boxes of area <= minimum_area px dropped, renormalised by the crop size."""
+    y0, x0, ch, cw = [np.float32(v) for v in crop]
+    H, W = np.float32(image_height), np.float32(image_width)
+    sy0 = np.clip(np.maximum(ymin * H, y0) - y0, 0, H)
+    sx0 = np.clip(np.maximum(xmin * W, x0) - x0, 0, W)
+    sy1 = np.clip(np.minimum(ymax * H, y0 + ch) - y0, 0, H)
+    sx1 = np.clip(np.minimum(xmax * W, x0 + cw) - x0, 0, W)
+    keep = (sx1 - sx0) * (sy1 - sy0) > np.float32(minimum_area)
+    return (sx0[keep] / cw).astype(np.float32), (sy0[keep] / ch).astype(np.float32), \
+           (sx1[keep] / cw).astype(np.float32), (sy1[keep] / ch).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------- colour distortion
+def _rgb_to_hsv(rgb):
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    mx, mn = rgb.max(-1), rgb.min(-1)
+    d = mx - mn
+    s = np.where(mx > 0, d / np.where(mx > 0, mx, 1), 0)
+    dz = np.where(d > 0, d, 1)
+    h = np.where(mx == r, (g - b) / dz, np.where(mx == g, 2.0 + (b - r) / dz, 4.0 + (r - g) / dz))
+    h = np.where(d > 0, (h / 6.0) % 1.0, 0.0)
+    return np.stack([h, s, mx], -1)
+
+
+def _hsv_to_rgb(hsv):
+    h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+    dh = h * 6.0
+    dr = np.clip(np.abs(dh - 3.0) - 1.0, 0, 1)
+    dg = np.clip(2.0 - np.abs(dh - 2.0), 0, 1)
+    db = np.clip(2.0 - np.abs(dh - 4.0), 0, 1)
+    return np.stack([(1 - s + s * dr) * v, (1 - s + s * dg) * v, (1 - s + s * db) * v], -1)
+
+
+def distort_color(image, color_ordering, fast_mode, rng):
+    """inputs.py:44-98 with tf.image.random_{brightness,saturation,hue,contrast} restated; result clipped to [0,1]."""
+    img = np.asarray(image, np.float32).astype(np.float64)
+
+    def brightness(x):
+        return x + rng.uniform(-32.0 / 255.0, 32.0 / 255.0)
+
+    def saturation(x):
+        hsv = _rgb_to_hsv(x)
+        hsv[..., 1] = np.clip(hsv[..., 1] * rng.uniform(0.5, 1.5), 0, 1)
+        return _hsv_to_rgb(hsv)
+
+    def hue(x):
+        hsv = _rgb_to_hsv(x)
+        hsv[..., 0] = (hsv[..., 0] + rng.uniform(-0.2, 0.2)) % 1.0
+        return _hsv_to_rgb(hsv)
+
+    def contrast(x):
+        m = x.mean((0, 1), keepdims=True)
+        return (x - m) * rng.uniform(0.5, 1.5) + m
+    if fast_mode:
+        order = (brightness, saturation) if color_ordering == 0 else (saturation, brightness)
+    else:
+        order = {0: (brightness, saturation, hue, contrast), 1: (saturation, brightness, contrast, hue),
+                 2: (contrast, hue, brightness, saturation), 3: (hue, saturation, contrast, brightness)}.get(color_ordering)
+        if order is None:
+            raise ValueError("color_ordering must be in [0, 3]")
+    for f in order:
+        img = f(img)
+    return np.clip(img, 0.0, 1.0).astype(np.float32)
+
+
+def augment_example(image01, image_height, image_width, xmin, ymin, xmax, ymax, cfg, rng):
+    """One example through inputs.py:264-327 (the draws in the reference's order): returns
+    (image [S,S,3] in [0,1], xmin, ymin, xmax, ymax) with the boxes that survived the crop."""
     S = int(cfg.INPUT_SIZE)
+    n = len(xmin)
+    if rng.uniform() < float(cfg.get("DO_RANDOM_BBOX_SHIFT", 0) or 0) and n > 0:                 # inputs.py:264-270
+        xmin, ymin, xmax, ymax = shift_bboxes(xmin, ymin, xmax, ymax, image_height, image_width,
+                                              cfg.RANDOM_BBOX_SHIFT_EXTENT, rng)
+    img = image01
+    if rng.uniform() < float(cfg.get("DO_RANDOM_CROP", 0) or 0):                                 # inputs.py:272-285
+        H, W = img.shape[0], img.shape[1]
+        boxes = np.stack([ymin, xmin, ymax, xmax], 1) if n > 0 else np.zeros((0, 4), np.float32)
+        crop = sample_distorted_bounding_box(H, W, boxes, cfg.RANDOM_CROP_MIN_OBJECT_COVERED,
+                                             cfg.RANDOM_CROP_ASPECT_RATIO_RANGE, cfg.RANDOM_CROP_AREA_RANGE,
+                                             cfg.RANDOM_CROP_MAX_ATTEMPTS, rng)
+        y, x, ch, cw = crop
+        img = img[y:y + ch, x:x + cw]
+        xmin, ymin, xmax, ymax = crop_bboxes(xmin, ymin, xmax, ymax, image_height, image_width, crop,
+                                             cfg.RANDOM_CROP_MINIMUM_AREA)
+    img = RESIZE_METHODS[int(rng.randint(0, 4))](img, S, S)                                      # inputs.py:296-302
+    do_color = rng.uniform() < float(cfg.get("DO_COLOR_DISTORTION", 0) or 0)                     # inputs.py:312-320
+    fast = bool(cfg.get("COLOR_DISTORT_FAST", True))
+    ordering = 0 if fast else int(rng.randint(0, 4))
+    if do_color:
+        img = distort_color(img, ordering, fast, rng)
+    if cfg.get("DO_RANDOM_FLIP_LEFT_RIGHT", False) and rng.uniform() < 0.5:                      # inputs.py:323-327
+        img = img[:, ::-1]
+        xmin, xmax = np.float32(1.0) - xmax, np.float32(1.0) - xmin
+    return np.ascontiguousarray(img, np.float32), xmin, ymin, xmax, ymax
+
+
+def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, seed=0, shuffle=False, capacity=1000,
+                  min_after_dequeue=96):
+    """Yield (images [B,S,S,3] in [-1,1], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B] int32, image_ids).
+    shuffle: a tf.train.shuffle_batch-like buffer (random pick once more than min_after_dequeue examples wait)."""
+    rng = np.random.RandomState(seed)
+    pool, out = [], []
     imgs, boxes, nums, ids = [], [], [], []
-    epoch = 0
-    while num_epochs is None or epoch < num_epochs:
-        got = False
-        for ex in _records(tfrecords):
-            got = True
-            img = resize_bilinear_tf(decode_image(ex["image/encoded"][0]), S, S)
+
+    def examples():
+        epoch = 0
+        while num_epochs is None or epoch < num_epochs:
+            got = False
+            for ex in _records(tfrecords):
+                got = True
+                yield ex
+            if not got:
+                return
+            epoch += 1
+
+    def prepared():
+        for ex in examples():
             n = int(ex["image/object/bbox/count"][0])
-            xmin, ymin = np.array(ex.get("image/object/bbox/xmin", []), np.float32), np.array(ex.get("image/object/bbox/ymin", []), np.float32)
-            xmax, ymax = np.array(ex.get("image/object/bbox/xmax", []), np.float32), np.array(ex.get("image/object/bbox/ymax", []), np.float32)
-            if cfg.get("DO_RANDOM_FLIP_LEFT_RIGHT", False) and rng.uniform() < 0.5:          # inputs.py:319-323
-                img = img[:, ::-1]
-                xmin, xmax = np.float32(1.0) - xmax, np.float32(1.0) - xmin
-            bb = np.zeros((max_num_bboxes, 4), np.float32)                                    # inputs.py:340-348
-            n = min(n, max_num_bboxes)
+            f = lambda k: np.array(ex.get(k, []), np.float32)[:n]
+            img, xmin, ymin, xmax, ymax = augment_example(
+                decode_image(ex["image/encoded"][0]), int(ex["image/height"][0]), int(ex["image/width"][0]),
+                f("image/object/bbox/xmin"), f("image/object/bbox/ymin"), f("image/object/bbox/xmax"),
+                f("image/object/bbox/ymax"), cfg, rng)
+            bb = np.zeros((max_num_bboxes, 4), np.float32)                                    # inputs.py:338-348
+            n = min(len(xmin), max_num_bboxes)
             if n > 0:
                 bb[:n] = np.stack([xmin, ymin, xmax, ymax], 1)[:n]
-            imgs.append((img - np.float32(0.5)) * np.float32(2.0))                            # inputs.py:350-351
-            boxes.append(bb); nums.append(n); ids.append(ex["image/id"][0].decode("utf-8"))
-            if len(imgs) == batch_size:
-                yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), ids
-                imgs, boxes, nums, ids = [], [], [], []
-        if not got:
-            return
-        epoch += 1
+            yield (img - np.float32(0.5)) * np.float32(2.0), bb, n, ex["image/id"][0].decode("utf-8")   # inputs.py:350-351
+
+    def shuffled():
+        for item in prepared():
+            pool.append(item)
+            if len(pool) > max(int(min_after_dequeue), 0) or len(pool) >= int(capacity):
+                yield pool.pop(int(rng.randint(0, len(pool))))
+        while pool:
+            yield pool.pop(int(rng.randint(0, len(pool))))
+    for img, bb, n, image_id in (shuffled() if shuffle else prepared()):
+        imgs.append(img); boxes.append(bb); nums.append(n); ids.append(image_id)
+        if len(imgs) == batch_size:
+            yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), ids
+            imgs, boxes, nums, ids = [], [], [], []

@@ -66,3 +66,45 @@ def load_priors(path):
     with open(path, "rb") as f:
         p = pickle.load(f, encoding="latin1")
     return np.array(p).astype(np.float32)
+
+
+def generate_aspect_ratios(dataset, num_aspect_ratios=11, visualize=False, warp_bboxes=True, random_state=None):
+    """Dataset-specific aspect ratios by 1-D k-means (priors.py:11-183) -- host code, offline.
+
+    dataset: list of dicts with 'id', 'width', 'height', 'object' -> 'bbox' -> 'xmin/xmax/ymin/ymax' (normalised
+    coordinates), as the reference's dataset functions return.  Same arithmetic as the reference: boxes warped so
+    that the image is square (the SHORTER side's coordinates are stretched, priors.py:41-48), aspect = w / h,
+    kept if |a - 5| <= 1e-8 + 5*5 (``np.isclose(a, 5, 5)`` -- rtol 5, priors.py:62) and finite, KMeans, centres
+    sorted by membership count, largest first (priors.py:90-93).  ``visualize`` (matplotlib windows and
+    ``raw_input`` prompts in the reference) is accepted and ignored.  The reference does not seed KMeans;
+    ``random_state`` is this build's addition.  Returns a numpy array of ``num_aspect_ratios`` floats.
+    """
+    from collections import Counter
+    from sklearn.cluster import KMeans
+    feats = []
+    for image_data in dataset:
+        bb = image_data["object"]["bbox"]
+        xmin = np.atleast_2d(np.asarray(bb["xmin"], dtype=np.float64)).T.copy()
+        xmax = np.atleast_2d(np.asarray(bb["xmax"], dtype=np.float64)).T.copy()
+        ymin = np.atleast_2d(np.asarray(bb["ymin"], dtype=np.float64)).T.copy()
+        ymax = np.atleast_2d(np.asarray(bb["ymax"], dtype=np.float64)).T.copy()
+        if warp_bboxes:
+            w, h = float(image_data["width"]), float(image_data["height"])
+            if w > h:
+                ymin *= w / h
+                ymax *= w / h
+            else:
+                xmin *= h / w
+                xmax *= h / w
+        with np.errstate(divide="ignore", invalid="ignore"):
+            feats.extend(((xmax - xmin) / (ymax - ymin)).tolist())
+    X = np.array(feats, dtype=np.float64).reshape(-1, 1)
+    X = X[np.isclose(X[:, 0], 5, 5)]
+    X = X[~np.isinf(X).any(axis=1)]
+    cluster = KMeans(n_clusters=num_aspect_ratios, n_init=10, random_state=random_state)
+    cluster.fit(X)
+    cnt = Counter(list(cluster.labels_.ravel()))
+    cf = [[float(f[0]), cnt[i]] for i, f in enumerate(cluster.cluster_centers_)]
+    cf.sort(key=lambda x: x[1])          # stable sort + reverse, as the reference does (tie order included)
+    cf.reverse()
+    return np.array([x[0] for x in cf])

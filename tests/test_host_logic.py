@@ -99,3 +99,20 @@ def test_backward_segments_cover_gradient_buffer():
             assert h == hi and lo < h
             hi = lo
         assert hi == tr.w_lo
+
+
+def test_generate_aspect_ratios_matches_reference_golden():
+    """SURVEY F4 (priors.py:11-183): golden = the reference's own function run on this dataset (tools/gen_golden.py);
+    well separated clusters, so the unseeded KMeans of the reference has a unique answer."""
+    import os
+    from multibox_amd.priors import generate_aspect_ratios
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aspect_ratios.npz"))
+    dataset = [{"id": i, "width": int(w), "height": int(h),
+                "object": {"bbox": {"xmin": [b[0]], "ymin": [b[1]], "xmax": [b[2]], "ymax": [b[3]]}}}
+               for i, (w, h, b) in enumerate(zip(g["width"], g["height"], g["bbox"]))]
+    for warp, key in ((True, "expected_warp"), (False, "expected_nowarp")):
+        out = generate_aspect_ratios(dataset, num_aspect_ratios=4, warp_bboxes=warp, random_state=0)
+        assert out.shape == (4,)
+        assert np.allclose(out, g[key], rtol=1e-6), (out, g[key])      # same order: membership count, largest first
+    # the warped clusters are the ones the dataset was built from
+    assert np.allclose(sorted(g["expected_warp"]), [0.5, 1.0, 2.0, 3.5], rtol=0.01)

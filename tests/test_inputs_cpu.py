@@ -103,5 +103,84 @@ def test_detect_and_train_batches(tmp_path):
     images, boxes, nums, ids = next(tb)
     assert images.shape == (3, 299, 299, 3) and boxes.shape == (3, 5, 4) and nums.tolist() == [1, 0, 2] and ids == ["1000", "1001", "1002"]
     assert np.allclose(boxes[0, 0], [.1, .2, .5, .6]) and not boxes[1].any() and np.allclose(boxes[2, 1], [.2, .2, .4, .9])
-    with pytest.raises(NotImplementedError):
-        next(I.train_batches([path], Cfg(dict(INPUT_SIZE=299, DO_RANDOM_CROP=0.5)), 2, 5))
+    # every augmentation of inputs.py:264-327 switched on: runs, stays normalised, is reproducible per seed
+    aug = Cfg(dict(INPUT_SIZE=299, DO_RANDOM_FLIP_LEFT_RIGHT=True, DO_RANDOM_BBOX_SHIFT=1.0, RANDOM_BBOX_SHIFT_EXTENT=4,
+                   DO_RANDOM_CROP=1.0, RANDOM_CROP_MIN_OBJECT_COVERED=0.7, RANDOM_CROP_ASPECT_RATIO_RANGE=[0.7, 1.4],
+                   RANDOM_CROP_AREA_RANGE=[0.5, 1.0], RANDOM_CROP_MAX_ATTEMPTS=100, RANDOM_CROP_MINIMUM_AREA=50,
+                   DO_COLOR_DISTORTION=1.0, COLOR_DISTORT_FAST=False))
+    runs = [list(I.train_batches([path], aug, 3, 5, num_epochs=2, seed=11, shuffle=True, min_after_dequeue=2)) for _ in range(2)]
+    assert len(runs[0]) == 2
+    for (im_a, bb_a, n_a, id_a), (im_b, bb_b, n_b, id_b) in zip(*runs):
+        assert np.array_equal(im_a, im_b) and np.array_equal(bb_a, bb_b) and id_a == id_b          # same seed, same stream
+        assert im_a.shape == (3, 299, 299, 3) and im_a.min() >= -1 and im_a.max() <= 1
+        assert bb_a.min() >= 0 and bb_a.max() <= 1 and (n_a <= 2).all()
+        for b, n in zip(bb_a, n_a):
+            assert (b[:n, 2] >= b[:n, 0]).all() and (b[:n, 3] >= b[:n, 1]).all() and not b[n:].any()
+    assert sorted(sum((r[3] for r in runs[0]), [])) == ["1000", "1000", "1001", "1001", "1002", "1002"]
+
+
+def test_bbox_shift_and_crop_arithmetic():
+    """inputs.py:184-203 and 128-180, known answers."""
+    rng = np.random.RandomState(0)
+    x0, y0, x1, y1 = [np.array(v, np.float32) for v in ([.5, .0], [.5, .01], [.6, 1.], [.7, .99])]
+    sx0, sy0, sx1, sy1 = I.shift_bboxes(x0, y0, x1, y1, 200, 400, 5, rng)
+    assert (sx0 <= x0).all() and (sx0 >= np.maximum(x0 - 5 / 400., 0) - 1e-7).all()             # outwards, < extent, clipped
+    assert (sx1 >= x1).all() and (sx1 <= np.minimum(x1 + 5 / 400., 1) + 1e-7).all()
+    assert (sy0 <= y0).all() and (sy0 >= np.maximum(y0 - 5 / 200., 0) - 1e-7).all() and sx0[1] == 0 and sx1[1] == 1
+    # crop (y=50, x=100, h=100, w=200) of a 200 x 400 image
+    xmin, ymin = np.array([.30, .10, .00], np.float32), np.array([.30, .10, .00], np.float32)
+    xmax, ymax = np.array([.60, .20, .26], np.float32), np.array([.60, .20, .26], np.float32)
+    cx0, cy0, cx1, cy1 = I.crop_bboxes(xmin, ymin, xmax, ymax, 200, 400, (50, 100, 100, 200), minimum_area=50)
+    # box 0: px (120..240, 60..120) -> clipped to the crop and shifted: x 20..140, y 10..70 -> /200, /100
+    # box 1: px (40..80, 20..40): entirely left/above the crop -> zero area -> dropped
+    # box 2: px (0..104, 0..52): 4 x 2 px inside the crop = 8 px^2 <= 50 -> dropped
+    assert len(cx0) == 1
+    assert np.allclose([cx0[0], cy0[0], cx1[0], cy1[0]], [20 / 200., 10 / 100., 140 / 200., 70 / 100.], atol=1e-6)
+
+
+def test_sample_distorted_bounding_box_constraints():
+    rng = np.random.RandomState(3)
+    H, W = 240, 320
+    boxes = np.array([[.2, .3, .6, .7], [.5, .1, .9, .4]], np.float32)            # ymin, xmin, ymax, xmax
+    full = 0
+    for _ in range(300):
+        y, x, h, w = I.sample_distorted_bounding_box(H, W, boxes, 0.7, (0.7, 1.4), (0.5, 1.0), 100, rng)
+        assert 0 <= y and 0 <= x and y + h <= H and x + w <= W and h > 0 and w > 0
+        if (y, x, h, w) == (0, 0, H, W):
+            full += 1
+            continue
+        assert 0.5 * H * W <= w * h <= 1.0 * H * W
+        assert 0.7 - 0.02 <= w / float(h) <= 1.4 + 0.02                           # the ratio is rounded to whole pixels
+        cov = []
+        for b in boxes:
+            bx0, by0, bx1, by1 = int(b[1] * W), int(b[0] * H), int(b[3] * W), int(b[2] * H)
+            inter = max(min(bx1, x + w) - max(bx0, x), 0) * max(min(by1, y + h) - max(by0, y), 0)
+            cov.append(inter / float((bx1 - bx0) * (by1 - by0)))
+        assert max(cov) >= 0.7
+    assert full < 30
+    # impossible constraints fall back to the whole image; no boxes -> the image itself is the box to cover
+    assert I.sample_distorted_bounding_box(H, W, boxes, 0.7, (0.7, 1.4), (2.0, 3.0), 20, rng) == (0, 0, H, W)
+    y, x, h, w = I.sample_distorted_bounding_box(H, W, np.zeros((0, 4), np.float32), 0.7, (0.9, 1.1), (0.8, 1.0), 100, rng)
+    assert w * h >= 0.7 * H * W
+
+
+def test_resize_methods_and_colour():
+    rng = np.random.RandomState(5)
+    img = rng.rand(8, 12, 3).astype(np.float32)
+    const = np.full((7, 9, 3), 0.25, np.float32)
+    for f in I.RESIZE_METHODS:
+        assert np.allclose(f(const, 5, 11), 0.25, atol=1e-6) and f(img, 5, 7).shape == (5, 7, 3)
+        assert np.allclose(f(img, 8, 12), img, atol=1e-6)                         # identity size
+    assert np.array_equal(I.resize_nearest_tf(img, 4, 6), img[::2, ::2])          # src = floor(dst * 2)
+    assert np.allclose(I.resize_area_tf(img, 4, 6), img.reshape(4, 2, 6, 2, 3).mean((1, 3)), atol=1e-6)
+    ramp = np.tile((np.arange(16, dtype=np.float32) / 16.0)[None, :, None], (4, 1, 3))
+    up = I.resize_bicubic_tf(ramp, 4, 32)                                         # cubic convolution reproduces a linear ramp
+    assert np.allclose(up[:, 4:-6, 0], (np.arange(32) * 0.5 / 16.0)[4:-6][None], atol=1e-5)
+    # colour: HSV round trip, range, the saturation step keeps grey pixels grey
+    assert np.allclose(I._hsv_to_rgb(I._rgb_to_hsv(img.astype(np.float64))), img, atol=1e-6)
+    for fast in (True, False):
+        for order in ((0,) if fast else (0, 1, 2, 3)):
+            out = I.distort_color(img, order, fast, np.random.RandomState(order))
+            assert out.shape == img.shape and out.min() >= 0 and out.max() <= 1 and not np.allclose(out, img)
+    with pytest.raises(ValueError):
+        I.distort_color(img, 4, False, rng)

@@ -193,6 +193,56 @@ def main():
 
     manifest["_generated_with"] = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                                        patch="loss.py:16 Div->FloorDiv (py2 integer division)")
+    # ------------------------------------------------ aspect-ratio clustering (F4, priors.py:11-183)
+    # The reference's KMeans is unseeded; well separated clusters make the centres unique up to float noise.
+    from sklearn.cluster import KMeans as _KM
+
+    def _KMeansCompat(n_clusters=8, n_jobs=None, **kw):   # sklearn >= 1.0 dropped n_jobs (the reference passes n_jobs=8)
+        return _KM(n_clusters=n_clusters, n_init=10, **kw)
+
+    class _Plt:                            # visualize=False: never called
+        def __getattr__(self, k):
+            raise RuntimeError("matplotlib is not part of the golden run")
+
+    from collections import Counter
+    ar_ns = _load("priors.py", {"generate_aspect_ratios"}, extra_ns={"KMeans": _KMeansCompat, "plt": _Plt(), "Counter": Counter})
+    rng = np.random.RandomState(7)
+    centres = [0.5, 1.0, 2.0, 3.5]
+    sizes = [40, 90, 60, 25]
+    dataset = []
+    img = 0
+    for c, n in zip(centres, sizes):
+        for j in range(n):
+            W_, H_ = [(640, 480), (480, 640), (500, 500)][(img + j) % 3]
+            a = c * (1.0 + 0.01 * rng.randn())             # aspect of the box in the SQUARE-warped image
+            hh = 0.2 + 0.1 * rng.rand()
+            ww = a * hh
+            s_ = max(W_, H_) / float(min(W_, H_))
+            # un-warp: the reference stretches the shorter side's coordinates by s_
+            if W_ > H_:
+                bw, bh = ww, hh / s_
+            else:
+                bw, bh = ww / s_, hh
+            x0, y0 = 0.05 + 0.1 * rng.rand(), 0.05 + 0.1 * rng.rand()
+            dataset.append({"id": img, "width": W_, "height": H_, "filename": "",
+                            "object": {"bbox": {"xmin": [x0], "xmax": [x0 + bw], "ymin": [y0], "ymax": [y0 + bh]}}})
+            img += 1
+    # two degenerate boxes: zero height (inf aspect, dropped at priors.py:67) and aspect 40 (dropped at priors.py:62)
+    dataset.append({"id": img, "width": 500, "height": 500, "filename": "",
+                    "object": {"bbox": {"xmin": [0.1], "xmax": [0.3], "ymin": [0.2], "ymax": [0.2]}}})
+    dataset.append({"id": img + 1, "width": 500, "height": 500, "filename": "",
+                    "object": {"bbox": {"xmin": [0.1], "xmax": [0.9], "ymin": [0.2], "ymax": [0.22]}}})
+    import copy, io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        out_w = ar_ns["generate_aspect_ratios"](copy.deepcopy(dataset), num_aspect_ratios=4, visualize=False, warp_bboxes=True)
+        out_n = ar_ns["generate_aspect_ratios"](copy.deepcopy(dataset), num_aspect_ratios=4, visualize=False, warp_bboxes=False)
+    np.savez(os.path.join(OUT, "aspect_ratios.npz"),
+             width=np.array([d["width"] for d in dataset]), height=np.array([d["height"] for d in dataset]),
+             bbox=np.array([[d["object"]["bbox"][k][0] for k in ("xmin", "ymin", "xmax", "ymax")] for d in dataset]),
+             expected_warp=np.asarray(out_w, np.float64).ravel(), expected_nowarp=np.asarray(out_n, np.float64).ravel())
+    manifest["aspect_ratios"] = dict(boxes=len(dataset), warp=[float(v) for v in np.asarray(out_w).ravel()],
+                                     nowarp=[float(v) for v in np.asarray(out_n).ravel()])
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(OUT)))

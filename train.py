@@ -97,7 +97,9 @@ def main():
     if args.tfrecords and not args.synthetic:
         from multibox_amd.inputs import train_batches
         files = args.tfrecords[rank::world] if len(args.tfrecords) >= world else args.tfrecords     # shard files over ranks
-        real = train_batches(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + rank)
+        real = train_batches(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_epochs=None,
+                             seed=int(cfg.get("RANDOM_SEED", 1)) + rank, shuffle=True,                   # train.py:214-225
+                             capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)))
     while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
         if real is not None:
             images, gt, n, _ = next(real)
