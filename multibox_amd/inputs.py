@@ -377,3 +377,28 @@ def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, s
         if len(imgs) == batch_size:
             yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), ids
             imgs, boxes, nums, ids = [], [], [], []
+
+
+def eval_batches(tfrecords, cfg, batch_size, max_num_bboxes):
+    """eval_inputs.input_nodes (eval_inputs.py:20-115): one epoch, no augmentation -- decode, legacy bilinear resize to
+    INPUT_SIZE, boxes and their original-image areas ('image/object/area') padded to MAX_NUM_BBOXES, [-1,1] scaling;
+    the incomplete last batch is dropped like tf.train.(shuffle_)batch at the end of the epoch.
+    Yields (images [B,S,S,3], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B], areas [B,G], image_ids)."""
+    S = int(cfg.INPUT_SIZE)
+    imgs, boxes, nums, areas, ids = [], [], [], [], []
+    for ex in _records(tfrecords):
+        n = min(int(ex["image/object/bbox/count"][0]), max_num_bboxes)
+        f = lambda k: np.array(ex.get(k, []), np.float32)[:n]
+        bb = np.zeros((max_num_bboxes, 4), np.float32)
+        ar = np.zeros((max_num_bboxes,), np.float32)
+        if n > 0:
+            bb[:n] = np.stack([f("image/object/bbox/xmin"), f("image/object/bbox/ymin"), f("image/object/bbox/xmax"),
+                               f("image/object/bbox/ymax")], 1)
+            a = f("image/object/area")
+            ar[:len(a)] = a
+        img = resize_bilinear_tf(decode_image(ex["image/encoded"][0]), S, S)
+        imgs.append((img - np.float32(0.5)) * np.float32(2.0))
+        boxes.append(bb); nums.append(n); areas.append(ar); ids.append(ex["image/id"][0].decode("utf-8"))
+        if len(imgs) == batch_size:
+            yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), np.stack(areas), ids
+            imgs, boxes, nums, areas, ids = [], [], [], [], []

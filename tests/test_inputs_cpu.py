@@ -27,7 +27,8 @@ def _make_records(path, specs):
             "image/id": str(1000 + i), "image/encoded": _jpeg(h, w, i), "image/height": [h], "image/width": [w],
             "image/object/bbox/xmin": [float(x) for x in boxes[:, 0]], "image/object/bbox/ymin": [float(x) for x in boxes[:, 1]],
             "image/object/bbox/xmax": [float(x) for x in boxes[:, 2]], "image/object/bbox/ymax": [float(x) for x in boxes[:, 3]],
-            "image/object/bbox/count": [len(boxes)]}))
+            "image/object/bbox/count": [len(boxes)],
+            "image/object/area": [float((b[2] - b[0]) * w * (b[3] - b[1]) * h) for b in boxes]}))
     T.write_records(path, payloads)
 
 
@@ -184,3 +185,16 @@ def test_resize_methods_and_colour():
             assert out.shape == img.shape and out.min() >= 0 and out.max() <= 1 and not np.allclose(out, img)
     with pytest.raises(ValueError):
         I.distort_color(img, 4, False, rng)
+
+
+def test_eval_batches(tmp_path):
+    """eval_inputs.py:20-115: no augmentation, areas padded with the boxes, incomplete last batch dropped."""
+    path = str(tmp_path / "e.tfrecords")
+    _make_records(path, [(320, 400, [[.1, .2, .5, .6]]), (300, 300, []), (350, 310, [[.0, .0, 1., 1.], [.2, .2, .4, .9]])])
+    cfg = Cfg(dict(INPUT_SIZE=299))
+    bs = list(I.eval_batches([path], cfg, batch_size=2, max_num_bboxes=4))
+    assert len(bs) == 1
+    images, boxes, nums, areas, ids = bs[0]
+    assert images.shape == (2, 299, 299, 3) and boxes.shape == (2, 4, 4) and areas.shape == (2, 4) and nums.tolist() == [1, 0]
+    assert np.isclose(areas[0, 0], .4 * 400 * .4 * 320) and not areas[0, 1:].any() and not areas[1].any() and ids == ["1000", "1001"]
+    assert np.allclose(images[0], (I.resize_bilinear_tf(I.decode_image(_jpeg(320, 400, 0)), 299, 299) - 0.5) * 2.0)
