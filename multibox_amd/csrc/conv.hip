@@ -37,6 +37,11 @@ struct ConvK {
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
   int pw;                              // pointwise: R = S = 1, no padding, unit stride
+  // stride-2 data gradient (shift = 1): output pixels are walked PARITY-CLASS-major (class = (oh & 1) * 2 + (ow & 1)),
+  // so a pixel tile lies in one class and only the filter taps of that class are multiplied (a quarter of them)
+  int cls_m0[4], cls_hw[4], cls_w[4];  // first pixel index, pixels per image (Hc * Wc) and row length Wc per class
+  int skip_taps;                       // C_in % 64 == 0: K tiles never straddle taps, whole taps can be skipped
+  int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
   int dbg;                             // ablation bits (MBX_DBG): 1 no stores, 2 no DMA, 4 no MFMA, 8 no stats
 };
 
@@ -54,6 +59,29 @@ __device__ __forceinline__ float row_sum16(float v) {
 // exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
 __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
   return (unsigned)(((unsigned long long)m * magic) >> shift);
+}
+// pixel index m -> (image, output row, output column)
+__device__ __forceinline__ void decode_pixel(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {
+  img = (int)fast_div(m, p.mg_hw, p.sh_hw);
+  const int rem = (int)m - img * p.HW_out;
+  oh = (int)fast_div((unsigned)rem, p.mg_w, p.sh_w);
+  ow = rem - oh * p.W_out;
+}
+// ... in the parity-class-major order of the stride-2 data gradient
+__device__ __forceinline__ void decode_pixel_parity(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {
+  const int c = ((int)m >= p.cls_m0[1]) + ((int)m >= p.cls_m0[2]) + ((int)m >= p.cls_m0[3]);
+  const int m0 = c == 0 ? p.cls_m0[0] : c == 1 ? p.cls_m0[1] : c == 2 ? p.cls_m0[2] : p.cls_m0[3];
+  const int hw = c == 0 ? p.cls_hw[0] : c == 1 ? p.cls_hw[1] : c == 2 ? p.cls_hw[2] : p.cls_hw[3];
+  const int wc = c == 0 ? p.cls_w[0] : c == 1 ? p.cls_w[1] : c == 2 ? p.cls_w[2] : p.cls_w[3];
+  unsigned r = m - (unsigned)m0;
+  img = (int)(r / (unsigned)hw);
+  r -= (unsigned)img * (unsigned)hw;
+  const int a = (int)(r / (unsigned)wc), b = (int)r - a * wc;
+  oh = 2 * a + (c >> 1);
+  ow = 2 * b + (c & 1);
+}
+__device__ __forceinline__ int pixel_class(const ConvK& p, int m) {
+  return (m >= p.cls_m0[1]) + (m >= p.cls_m0[2]) + (m >= p.cls_m0[3]);
 }
 constexpr unsigned kOOB = 0x80000000u;      // byte offset beyond every tensor: buffer loads return 0 there
 
@@ -94,7 +122,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // EV: epilogue variant fixed at compile time (no per-element branching):
 //   0 store, 1 store + BN statistics partials, 2 accumulate into y (+ optional relu mask from `skip`),
 //   3 affine (+relu), 4 residual (+relu), 5 float32 store.
-template <int BM, int BN, int WNW, int WMW, int EV>
+// SH: the stride-2 data gradient (input dilated by 2).  Its own instantiation, so that the parity walk below costs
+// the other 400 launches per step nothing (as a run-time branch in one kernel it cost them 0.6 ms per step).
+template <int BM, int BN, int WNW, int WMW, int EV, bool SH = false>
 __global__ void __launch_bounds__(64 * WNW * WMW)
 conv_igemm3_kernel(const ConvK p) {
   static_assert(WNW * WMW == 4 || WNW * WMW == 8, "four or eight waves");
@@ -121,11 +151,11 @@ conv_igemm3_kernel(const ConvK p) {
     const int m = m0 + lrow + RPP * i;
     const bool mv = m < p.M;
     const unsigned mm = mv ? (unsigned)m : 0u;
-    const int img = (int)fast_div(mm, p.mg_hw, p.sh_hw), rem = (int)mm - img * p.HW_out;
-    const int oh = (int)fast_div((unsigned)rem, p.mg_w, p.sh_w), ow = rem - oh * p.W_out;
+    int img, oh, ow;
+    if (SH && p.parity) decode_pixel_parity(p, mm, img, oh, ow); else decode_pixel(p, mm, img, oh, ow);
     hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);
     wb[i] = ow * p.mul - p.pad_l;
-    ro[i] = p.shift ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
+    ro[i] = SH ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
     if (p.pw && !mv) ro[i] = (int)kOOB;
   }
   int wo[WI];
@@ -145,9 +175,21 @@ conv_igemm3_kernel(const ConvK p) {
   // fragment read offsets (16-B slots): row*8 + ((kk*4 + fch) ^ (row & 7)); row & 7 == frow & 7
   const int fr0 = frow * 8 + (fch ^ (frow & 7));
   const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
-  const int nk = (p.Ktot + 63) >> 6;
-  int kc = chunk * 8, kr = 0, ks = 0;
-  while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }
+  // stride-2 data gradient, tile inside one parity class: only taps with kr = kr0 (mod 2), ks = ks0 (mod 2) meet
+  // non-zero rows of the dilated input -- walk those only (steps of 2), a quarter of the K tiles
+  int kr0 = 0, ks0 = 0, kstep = 1, nk = (p.Ktot + 63) >> 6;
+  if (SH && p.skip_taps) {
+    const int mlast = min(m0 + BM, p.M) - 1;
+    const int c0 = pixel_class(p, m0);
+    if (c0 == pixel_class(p, mlast)) {
+      kr0 = (p.pad_t + (c0 >> 1)) & 1;
+      ks0 = (p.pad_l + (c0 & 1)) & 1;
+      kstep = 2;
+      nk = ((p.R - kr0 + 1) >> 1) * ((p.S - ks0 + 1) >> 1) * (p.C_in >> 6);
+    }
+  }
+  int kc = chunk * 8, kr = kr0, ks = ks0;
+  while (kc >= p.C_in) { kc -= p.C_in; if ((ks += kstep) >= p.S) { ks = ks0; kr += kstep; } }
   const int ldx2 = p.ldx * 2;
   int st_issue = 0, st_comp = 0;                        // ring positions
   // LDS-DMA of K tile LT into ring slot st_issue.  (A macro, not a lambda: the three call sites must be
@@ -159,7 +201,7 @@ conv_igemm3_kernel(const ConvK p) {
     if (p.pw) {                                                                                              \
       _Pragma("unroll") for (int i = 0; i < PI; ++i)                                                         \
         glds16(xr, sp + i * NT, (kv && ro[i] >= 0) ? (ro[i] + kc * 2) : (int)kOOB);                          \
-    } else if (!p.shift) {                                                                                   \
+    } else if (!SH) {                                                                                        \
       const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;                                                   \
       _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                       \
         const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) &&                                 \
@@ -174,12 +216,12 @@ conv_igemm3_kernel(const ConvK p) {
         glds16(xr, sp + i * NT, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB); \
       }                                                                                                      \
     }                                                                                                        \
-    const int kb = ((LT) * 64 + chunk * 8) * 2;                                                              \
+    const int kb = SH ? ((kr * p.S + ks) * p.C_in + kc) * 2 : ((LT) * 64 + chunk * 8) * 2;                   \
     u32x4* sw = sp + BM * 8;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                           \
       glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                                \
     kc += 64;                                                                                                \
-    while (kc >= p.C_in) { kc -= p.C_in; if (++ks == p.S) { ks = 0; ++kr; } }                                \
+    while (kc >= p.C_in) { kc -= p.C_in; if ((ks += kstep) >= p.S) { ks = ks0; kr += kstep; } }              \
     st_issue = st_issue == 2 ? 0 : st_issue + 1;                                                             \
   } while (0)
 
@@ -266,7 +308,15 @@ conv_igemm3_kernel(const ConvK p) {
       const int row = ps * RPP2 + r0;
       const int m = m0 + row;
       if (m < p.M && cok) {
-        const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+        int img, pix;
+        if (SH && p.parity) {
+          int oh_, ow_;
+          decode_pixel_parity(p, (unsigned)m, img, oh_, ow_);
+          pix = oh_ * p.W_out + ow_;
+        } else {
+          img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw);
+          pix = m - img * p.HW_out;
+        }
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8 + 4);
         float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
@@ -614,9 +664,26 @@ int launch_igemm(ConvK& k, hipStream_t s) {
       hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV>), dim3(k.tiles_m * k.tiles_n),            \
                          dim3(64 * WNW * WMW), lds, s, k);                                                          \
       break;
+    static bool attr_sh[2] = {false, false};
+#define MBX_LAUNCH_SH(EV, SLOT)                                                                               \
+    do {                                                                                                      \
+      if (!attr_sh[SLOT]) {                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        attr_sh[SLOT] = true;                                                                                 \
+      }                                                                                                       \
+      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, true>), dim3(k.tiles_m * k.tiles_n),      \
+                         dim3(64 * WNW * WMW), lds, s, k);                                                    \
+    } while (0)
+    if (k.shift) {                               // stride-2 data gradient: its own instantiations (store / accumulate)
+      if (ev == 0) MBX_LAUNCH_SH(0, 0);
+      else if (ev == 2) MBX_LAUNCH_SH(2, 1);
+      else return MBX_ERR_UNSUPPORTED;
+    } else
     switch (ev) {
       MBX_LAUNCH_EV(0) MBX_LAUNCH_EV(1) MBX_LAUNCH_EV(2) MBX_LAUNCH_EV(3) MBX_LAUNCH_EV(4) MBX_LAUNCH_EV(5)
     }
+#undef MBX_LAUNCH_SH
 #undef MBX_LAUNCH_EV
   }
   MBX_LAUNCH_CHECK();
@@ -682,6 +749,23 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
+  k.skip_taps = 0; k.parity = 0;
+  for (int c = 0; c < 4; ++c) { k.cls_m0[c] = 0; k.cls_hw[c] = 1; k.cls_w[c] = 1; }
+  static int notap = -1;
+  if (notap < 0) { const char* e = getenv("MBX_NO_TAP_SKIP"); notap = (e && e[0] == '1') ? 1 : 0; }
+  if (k.shift && d->C_in % 64 == 0 && !notap) {  // K tiles never straddle filter taps: whole taps can be skipped
+    // parity classes of the output pixels (class = (oh & 1) * 2 + (ow & 1)); an empty class has the start of the
+    // next one, so pixel_class() steps over it
+    int m0 = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int hc = (d->H_out - (c >> 1) + 1) / 2, wc = (d->W_out - (c & 1) + 1) / 2;
+      k.cls_m0[c] = m0;
+      k.cls_hw[c] = hc * wc > 0 ? hc * wc : 1;
+      k.cls_w[c] = wc > 0 ? wc : 1;
+      m0 += d->N * hc * wc;
+    }
+    k.skip_taps = k.parity = 1;
+  }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   hipStream_t s = mbx_s(stream);
   switch (choose_cfg(k.M, k.C_out)) {
