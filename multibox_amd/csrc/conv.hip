@@ -124,9 +124,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //   3 affine (+relu), 4 residual (+relu), 5 float32 store.
 // SH: the stride-2 data gradient (input dilated by 2).  Its own instantiation, so that the parity walk below costs
 // the other 400 launches per step nothing (as a run-time branch in one kernel it cost them 0.6 ms per step).
-template <int BM, int BN, int WNW, int WMW, int EV, bool SH = false>
+// MODE 1: pointwise (1x1, unit stride, no padding) -- the two-instruction address path, no tap walk: 60 % of the launches.
+template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0>
 __global__ void __launch_bounds__(64 * WNW * WMW)
 conv_igemm3_kernel(const ConvK p) {
+  constexpr bool SH = MODE == 2, PW = MODE == 1;
   static_assert(WNW * WMW == 4 || WNW * WMW == 8, "four or eight waves");
   constexpr int NT = 64 * WNW * WMW, RPP = NT / 8;      // threads, tile rows filled per DMA pass
   constexpr int TN = BN / WNW, TM = BM / WMW, NI = TN / 16, MI = TM / 16;
@@ -156,7 +158,7 @@ conv_igemm3_kernel(const ConvK p) {
     hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);
     wb[i] = ow * p.mul - p.pad_l;
     ro[i] = SH ? img * p.x_img_stride * 2 : (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;
-    if (p.pw && !mv) ro[i] = (int)kOOB;
+    if (PW && !mv) ro[i] = (int)kOOB;
   }
   int wo[WI];
 #pragma unroll
@@ -198,7 +200,7 @@ conv_igemm3_kernel(const ConvK p) {
   do {                                                                                                       \
     u32x4* sp = smem + st_issue * STAGE + wave * 64;                                                         \
     const bool kv = kr < p.R;                                                                                \
-    if (p.pw) {                                                                                              \
+    if (PW) {                                                                                                \
       _Pragma("unroll") for (int i = 0; i < PI; ++i)                                                         \
         glds16(xr, sp + i * NT, (kv && ro[i] >= 0) ? (ro[i] + kc * 2) : (int)kOOB);                          \
     } else if (!SH) {                                                                                        \
@@ -657,22 +659,28 @@ int launch_igemm(ConvK& k, hipStream_t s) {
 #define MBX_LAUNCH_EV(EV)                                                                                     \
     case EV:                                                                                                  \
       if (!attr_set3[EV]) {                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV>),   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         attr_set3[EV] = true;                                                                                 \
       }                                                                                                       \
-      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV>), dim3(k.tiles_m * k.tiles_n),            \
-                         dim3(64 * WNW * WMW), lds, s, k);                                                          \
+      if (k.pw)                                                                                               \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1>), dim3(k.tiles_m * k.tiles_n),       \
+                           dim3(64 * WNW * WMW), lds, s, k);                                                  \
+      else                                                                                                    \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0>), dim3(k.tiles_m * k.tiles_n),       \
+                           dim3(64 * WNW * WMW), lds, s, k);                                                  \
       break;
     static bool attr_sh[2] = {false, false};
 #define MBX_LAUNCH_SH(EV, SLOT)                                                                               \
     do {                                                                                                      \
       if (!attr_sh[SLOT]) {                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, true>), \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         attr_sh[SLOT] = true;                                                                                 \
       }                                                                                                       \
-      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, true>), dim3(k.tiles_m * k.tiles_n),      \
+      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2>), dim3(k.tiles_m * k.tiles_n),      \
                          dim3(64 * WNW * WMW), lds, s, k);                                                    \
     } while (0)
     if (k.shift) {                               // stride-2 data gradient: its own instantiations (store / accumulate)
