@@ -431,7 +431,9 @@ struct WgradK2 {
 // NG = 2: eight waves; the two 4-wave groups reduce disjoint halves of the block's pixel range into the
 // SAME (n, k) tile and are summed through LDS before the atomics -> half the atomic bytes per FLOP
 // (the fp32 atomics ran at the chip-wide atomic rate and cost ~35 % of the 1x1 weight gradients).
-template <int NST, int NG>
+// LIN: x and dy rows are both contiguous in the pixel index (1x1 convs on dense views): offsets are m * ld, no
+// (image, row, column) bookkeeping -- compile-time, like the pointwise mode of the igemm kernel.
+template <int NST, int NG, bool LIN>
 __global__ void __launch_bounds__(kThreads * NG)
 conv_wgrad2_kernel(const WgradK2 q) {
   const WgradK& p = q.b;
@@ -508,19 +510,19 @@ conv_wgrad2_kernel(const WgradK2 q) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
       const bool mv = m_run < m_end;                                                                          \
       int xoff, yoff;                                                                                         \
-      if (q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;                                \
+      if (LIN || q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;                         \
       else {                                                                                                  \
         const int hb = oh * p.stride - p.pad_t + tr, wb = ow * p.stride - p.pad_l + ts;                       \
         const bool ok = mv && ((unsigned)hb < (unsigned)p.H_in) && ((unsigned)wb < (unsigned)p.W_in);         \
         xoff = ok ? ((img * p.x_img_stride + ((oh * p.stride - p.pad_t) * p.W_in + ow * p.stride - p.pad_l) * p.ldx) * 2 + toff) \
                   : (int)kOOB;                                                                                \
       }                                                                                                       \
-      if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                             \
+      if (LIN || q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                      \
       else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB; \
       glds16(yr, sp + i * 256, yoff);                                                                         \
       glds16(xr, sp + 1024 + i * 256, xoff);                                                                  \
       m_run += 16;                                                                                            \
-      if (!(q.pw && q.ydense)) {                                                                              \
+      if (!LIN && !(q.pw && q.ydense)) {                                                                      \
         ow += 16;                                                                                             \
         while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                        \
         while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                       \
@@ -842,13 +844,22 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
     static int ng = 0;
     if (!ng) { const char* e = getenv("MBX_WGRAD_NG"); ng = (e && e[0] == '1') ? 1 : 2; }
-    static bool attr_a = false, attr_b = false;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+      attr_set = true;
+    }
+    const bool lin = k2.pw && k2.ydense;
+    const dim3 grid(tiles * splits);
     if (ng == 2) {
-      if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768); attr_b = true; }
-      hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2>), dim3(tiles * splits), dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
+      if (lin) hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2, true>), grid, dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
+      else hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2, false>), grid, dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
     } else {
-      if (!attr_a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); attr_a = true; }
-      hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1>), dim3(tiles * splits), dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
+      if (lin) hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1, true>), grid, dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
+      else hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1, false>), grid, dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
     }
   }
   MBX_LAUNCH_CHECK();
