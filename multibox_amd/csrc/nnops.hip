@@ -76,12 +76,35 @@ bn_fold_kernel(const float* mm, const float* mv, const float* beta, float eps, i
 }
 
 // ------------------------------------------------------------------ batch norm: apply
+// Every lane owns one 8-channel group for the whole launch (mean / rstd / beta stay in registers) and walks the
+// rows: no per-element index division, no per-element parameter loads.
 __global__ void __launch_bounds__(kT)
 bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ mean,
                 const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
                 unsigned short* __restrict__ a, int ld_a) {
   const int C8 = C >> 3;
-  const long long total = M * C8;
+  if (C8 <= kT) {
+    const int rpi = kT / C8;                              // rows per sweep of the workgroup
+    const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+    if (rr >= rpi) return;
+    const int c = vc << 3;
+    float mu[8], rs[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; be[j] = beta[c + j]; }
+    const long long step = (long long)gridDim.x * rpi;
+    for (long long m = (long long)blockIdx.x * rpi + rr; m < M; m += step) {
+      float f[8];
+      unpack8(ld8(y + m * C + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = (f[j] - mu[j]) * rs[j] + be[j];
+        f[j] = relu ? fmaxf(v, 0.f) : v;
+      }
+      st8(a + m * ld_a + c, pack8(f));
+    }
+    return;
+  }
+  const long long total = M * C8;                         // more than 2048 channels: generic walk
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
     const long long m = i / C8;
     const int c = (int)(i - m * C8) << 3;
