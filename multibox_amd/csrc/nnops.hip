@@ -509,13 +509,14 @@ maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
                    int stride, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo,
                    unsigned char* __restrict__ argmax) {
   const int C8 = C >> 3;
-  const long long total = (long long)N * Ho * Wo * C8;
-  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
-    const int c = (int)(i % C8) << 3;
-    long long t = i / C8;
-    const int ow = (int)(t % Wo); t /= Wo;
-    const int oh = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+  const unsigned total = (unsigned)N * Ho * Wo * C8;            // < 2^31 (checked on the host): 32-bit index math
+  for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    unsigned t = i / (unsigned)C8;
+    const int c = (int)(i - t * C8) << 3;
+    const unsigned t2 = t / (unsigned)Wo;
+    const int ow = (int)(t - t2 * Wo);
+    const int n = (int)(t2 / (unsigned)Ho);
+    const int oh = (int)(t2 - (unsigned)n * Ho);
     float best[8];
     unsigned arg[8];
 #pragma unroll
@@ -545,13 +546,14 @@ maxpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_
                    const unsigned char* __restrict__ argmax, int N, int H, int W, int C, int k, int stride, int Ho,
                    int Wo, unsigned short* __restrict__ dx, long long dxs, int ld_dx, int accumulate) {
   const int C8 = C >> 3;
-  const long long total = (long long)N * H * W * C8;
-  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
-    const int c = (int)(i % C8) << 3;
-    long long t = i / C8;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
+  const unsigned total = (unsigned)N * H * W * C8;              // < 2^31 (checked on the host): 32-bit index math
+  for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    unsigned t = i / (unsigned)C8;
+    const int c = (int)(i - t * C8) << 3;
+    const unsigned t2 = t / (unsigned)W;
+    const int w = (int)(t - t2 * W);
+    const int n = (int)(t2 / (unsigned)H);
+    const int h = (int)(t2 - (unsigned)n * H);
     float acc[8];
     unsigned short* dst = dx + n * dxs + ((long long)h * W + w) * ld_dx + c;
     if (accumulate) unpack8(ld8(dst), acc);
@@ -585,13 +587,14 @@ __global__ void __launch_bounds__(kT)
 avgpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
                    int pad, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo) {
   const int C8 = C >> 3;
-  const long long total = (long long)N * Ho * Wo * C8;
-  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
-    const int c = (int)(i % C8) << 3;
-    long long t = i / C8;
-    const int ow = (int)(t % Wo); t /= Wo;
-    const int oh = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+  const unsigned total = (unsigned)N * Ho * Wo * C8;            // < 2^31 (checked on the host): 32-bit index math
+  for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    unsigned t = i / (unsigned)C8;
+    const int c = (int)(i - t * C8) << 3;
+    const unsigned t2 = t / (unsigned)Wo;
+    const int ow = (int)(t - t2 * Wo);
+    const int n = (int)(t2 / (unsigned)Ho);
+    const int oh = (int)(t2 - (unsigned)n * Ho);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -618,13 +621,14 @@ avgpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_
                    int pad, int Ho, int Wo, unsigned short* __restrict__ dx, long long dxs, int ld_dx,
                    int accumulate) {
   const int C8 = C >> 3;
-  const long long total = (long long)N * H * W * C8;
-  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
-    const int c = (int)(i % C8) << 3;
-    long long t = i / C8;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
+  const unsigned total = (unsigned)N * H * W * C8;              // < 2^31 (checked on the host): 32-bit index math
+  for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    unsigned t = i / (unsigned)C8;
+    const int c = (int)(i - t * C8) << 3;
+    const unsigned t2 = t / (unsigned)W;
+    const int w = (int)(t - t2 * W);
+    const int n = (int)(t2 / (unsigned)H);
+    const int h = (int)(t2 - (unsigned)n * H);
     float acc[8];
     unsigned short* dst = dx + n * dxs + ((long long)h * W + w) * ld_dx + c;
     if (accumulate) unpack8(ld8(dst), acc);
@@ -934,7 +938,8 @@ extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const voi
 
 static int pool_args_ok(const void* x, int ldx, const void* y, int ldy, int N, int H, int W, int C, int k, int Ho, int Wo) {
   return x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && k > 0 && k < 16 &&
-         Ho > 0 && Wo > 0 && al16(x) && al16(y);
+         Ho > 0 && Wo > 0 && al16(x) && al16(y) && (long long)N * H * W * (C / 8) < (1LL << 31) &&
+         (long long)N * Ho * Wo * (C / 8) < (1LL << 31);
 }
 
 extern "C" int mbx_maxpool_fwd(const void* x, int64_t xs, int ldx, int N, int H, int W, int C, int k, int stride, void* y,
