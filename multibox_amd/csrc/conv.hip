@@ -433,7 +433,8 @@ struct WgradK2 {
 // (the fp32 atomics ran at the chip-wide atomic rate and cost ~35 % of the 1x1 weight gradients).
 // LIN: x and dy rows are both contiguous in the pixel index (1x1 convs on dense views): offsets are m * ld, no
 // (image, row, column) bookkeeping -- compile-time, like the pointwise mode of the igemm kernel.
-template <int NST, int NG, bool LIN>
+// BIAS: the bias gradient (column sums of dy) rides along -- only the residual "up" convs have a bias.
+template <int NST, int NG, bool LIN, bool BIAS>
 __global__ void __launch_bounds__(kThreads * NG)
 conv_wgrad2_kernel(const WgradK2 q) {
   const WgradK& p = q.b;
@@ -497,7 +498,7 @@ conv_wgrad2_kernel(const WgradK2 q) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
+  const bool do_bias = BIAS && p.db != nullptr && tile_k == 0 && tid < 128 && n0 + tid < p.C_out;
 
   const int nsteps = (half + 63) >> 6;                   // same trip count for both groups (barriers are block-wide)
   int st_issue = 0, st_comp = 0;
@@ -844,23 +845,28 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
     static int ng = 0;
     if (!ng) { const char* e = getenv("MBX_WGRAD_NG"); ng = (e && e[0] == '1') ? 1 : 2; }
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
-      attr_set = true;
-    }
-    const bool lin = k2.pw && k2.ydense;
+    const bool lin = k2.pw && k2.ydense, bias = db != nullptr;
     const dim3 grid(tiles * splits);
-    if (ng == 2) {
-      if (lin) hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2, true>), grid, dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
-      else hipLaunchKernelGGL((conv_wgrad2_kernel<2, 2, false>), grid, dim3(2 * kThreads), 4 * 32768, mbx_s(stream), k2);
-    } else {
-      if (lin) hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1, true>), grid, dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
-      else hipLaunchKernelGGL((conv_wgrad2_kernel<2, 1, false>), grid, dim3(kThreads), 2 * 32768, mbx_s(stream), k2);
-    }
+    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+#define MBX_WG(NGV, LINV, BIASV)                                                                                       \
+    do {                                                                                                               \
+      constexpr int slot = (NGV - 1) * 4 + (LINV ? 2 : 0) + (BIASV ? 1 : 0);                                            \
+      if (!attr_set[slot]) {                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel<2, NGV, LINV, BIASV>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, NGV * 2 * 32768);                       \
+        attr_set[slot] = true;                                                                                         \
+      }                                                                                                                \
+      hipLaunchKernelGGL((conv_wgrad2_kernel<2, NGV, LINV, BIASV>), grid, dim3(NGV * kThreads), NGV * 2 * 32768,       \
+                         mbx_s(stream), k2);                                                                           \
+    } while (0)
+#define MBX_WG_NG(NGV)                                                                                                 \
+    do {                                                                                                               \
+      if (lin) { if (bias) MBX_WG(NGV, true, true); else MBX_WG(NGV, true, false); }                                   \
+      else { if (bias) MBX_WG(NGV, false, true); else MBX_WG(NGV, false, false); }                                     \
+    } while (0)
+    if (ng == 2) MBX_WG_NG(2); else MBX_WG_NG(1);
+#undef MBX_WG_NG
+#undef MBX_WG
   }
   MBX_LAUNCH_CHECK();
   return MBX_OK;
