@@ -340,3 +340,25 @@ def test_other_baseline_configs_run(env, S, k, B, G):
     for b in range(B):
         assert sorted(m[b][m[b] >= 0].tolist()) == list(range(n[b]))
     assert all(np.isfinite(x) for x in tr.losses())
+
+
+def test_overfits_one_batch(env):
+    """End-to-end sanity of forward + matching + loss + backward + RMSProp/EMA: on ONE fixed batch the loss must
+    collapse (tools/overfit_check.py: 7185 -> 139 in 400 steps).  Here 160 graph-replayed steps, > 8x reduction."""
+    torch = env["torch"]
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    from multibox_amd.synth import synthetic_batch
+    B = 8
+    net = Net(batch=B, input_size=299, k=5, mode="train", seed=3)
+    tr = Trainer(net, env["priors"], max_num_bboxes=13, use_graph=True, initial_learning_rate=0.01)
+    images, gt, n = synthetic_batch(B, 299, 13, seed=5)
+    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    tr.step()
+    first = tr.losses()
+    for _ in range(160):
+        tr.step()
+    last = tr.losses()
+    assert int(tr.match_status().max()) == 0
+    assert np.isfinite(last[3]) and last[3] < first[3] / 8.0, (first, last)
+    assert last[0] < first[0] / 8.0 and last[1] < first[1] / 4.0, (first, last)      # both terms of loss.py:100-101
