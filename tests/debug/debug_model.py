@@ -1,7 +1,7 @@
 """GPU debugging aid: determinism of forward, effect of backward on a following forward,
 and per-endpoint error of the engine against the torch-CPU oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as g
 g.build()
