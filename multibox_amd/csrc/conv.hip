@@ -42,7 +42,6 @@ struct ConvK {
   int cls_m0[4], cls_hw[4], cls_w[4];  // first pixel index, pixels per image (Hc * Wc) and row length Wc per class
   int skip_taps;                       // C_in % 64 == 0: K tiles never straddle taps, whole taps can be skipped
   int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
-  int dbg;                             // ablation bits (MBX_DBG): 1 no stores, 2 no DMA, 4 no MFMA, 8 no stats
 };
 
 constexpr int kThreads = 256;
@@ -423,7 +422,6 @@ __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3
 // constants + immediates.
 struct WgradK2 {
   WgradK b;
-  int dbg;           // ablation bits (MBX_DBG): 1 no atomics, 2 no DMA, 4 no MFMA
   int pw;            // x rows contiguous: offset = m * ldx (1x1, stride 1, no padding, dense images)
   int ydense;        // dy rows contiguous: offset = m * ld_dy
 };
@@ -777,7 +775,6 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     }
     k.skip_taps = k.parity = 1;
   }
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   hipStream_t s = mbx_s(stream);
   switch (choose_cfg(k.M, k.C_out)) {
     case 0: return launch_igemm<128, 128, 2, 2>(k, s);
@@ -839,7 +836,6 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   {
     WgradK2 k2;
     k2.b = k;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MBX_DBG"); dbg = e ? atoi(e) : 0; } k2.dbg = dbg; }
     k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
              d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
