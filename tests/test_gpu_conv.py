@@ -209,3 +209,57 @@ def test_wgrad_odd_cout_padded_dy(T):
     ops.conv_wgrad(d, dyb, dw)
     ok, msg = close(torch, dw, ref, f32=True)
     assert ok, msg
+
+
+# BASELINE config (ii) layer shapes at the full BATCH_SIZE = 64: pixel counts that are not multiples of any tile
+# (18496, 78400), every kernel mode (pointwise, general, stride-2 data gradient with tap skipping), all tile configs.
+FULL = [
+    ("b17_fused_1x1_1088_320", 17, 17, 1088, 320, 1, 1, 1, (0, 0, 0, 0)),
+    ("b17_up_1x1_384_1088", 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)),
+    ("b17_1x7_128_160", 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
+    ("b35_3x3_48_64", 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1)),
+    ("b35_fused_1x1_320_96", 35, 35, 320, 96, 1, 1, 1, (0, 0, 0, 0)),
+    ("m6a_3x3_s2_320_384", 35, 35, 320, 384, 3, 3, 2, (0, 0, 0, 0)),
+    ("m7a_3x3_s2_256_288", 17, 17, 256, 288, 3, 3, 2, (0, 0, 0, 0)),
+    ("head_3x3_s2_same_1536_256", 8, 8, 1536, 256, 3, 3, 2, (0, 0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("g", FULL, ids=[g[0] for g in FULL])
+def test_conv_full_size_b64(T, g):
+    """Forward, data gradient and weight gradient at BATCH_SIZE 64 against a float32 reference computed ON THE GPU
+    from plain torch ops (unfold + matmul + autograd; no kernel of this library), same bf16-rounded inputs."""
+    torch = T
+    import torch.nn.functional as F
+    from multibox_amd import ops
+    name, H, W, Ci, Co, R, S, st, pads = g
+    N = 64
+    gen = torch.Generator().manual_seed(11)
+    x = bf16_round(torch, torch.randn(N, H, W, Ci, generator=gen)).cuda()
+    w = bf16_round(torch, torch.randn(Co, R, S, Ci, generator=gen) / (R * S * Ci) ** 0.5).cuda()
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    dy = bf16_round(torch, torch.randn(N, Ho, Wo, Co, generator=gen)).cuda()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xp = F.pad(xr.permute(0, 3, 1, 2), (pads[1], pads[3], pads[0], pads[2]))
+    cols = F.unfold(xp, (R, S), stride=st)                                   # [N, Ci*R*S, Ho*Wo], channel-major patches
+    wm = wr.permute(0, 3, 1, 2).reshape(Co, Ci * R * S)
+    ref = (cols.transpose(1, 2) @ wm.t()).reshape(N, Ho, Wo, Co)
+    ref.backward(dy)
+    xb, yb = ops.View.alloc(N, H, W, Ci), ops.View.alloc(N, Ho, Wo, Co)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).contiguous()
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb))
+    ok, msg = close(torch, yb.tensor(), ref.detach())
+    assert ok, "forward: " + msg
+    dyb = ops.View.alloc(N, Ho, Wo, Co)
+    dyb.tensor().copy_(dy.to(torch.bfloat16))
+    wT = w.flip(1, 2).permute(3, 1, 2, 0).contiguous().to(torch.bfloat16)
+    dx = ops.View.alloc(N, H, W, Ci, zero=True)
+    ops.conv(ops.make_desc(dyb, wT, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], dx, transposed=1))
+    ok, msg = close(torch, dx.tensor(), xr.grad)
+    assert ok, "dgrad: " + msg
+    dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(ops.make_desc(xb, None, Co, R, S, st, pads[0], pads[1], yb), dyb, dw)
+    ok, msg = close(torch, dw, wr.grad, f32=True)
+    assert ok, "wgrad: " + msg
