@@ -106,6 +106,51 @@ def test_loss_fwd_bwd_vs_oracle(torch_cuda, golden, case):
     assert np.allclose(dz.cpu().numpy(), rdz, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,k,G,seed", [(64, 5, 13, 0), (64, 7, 100, 1)])
+def test_loss_full_batch_vs_oracle_and_additivity(torch_cuda, golden, B, k, G, seed):
+    """BASELINE sizes (64 images per GPU; P = 646 / 904): decode + match + loss + gradients against the numpy oracle,
+    and the size-independent property the reference's batch-sum loss has (loss.py:100-101): the loss of the batch is
+    the sum of the losses of its images, the gradients of an image do not depend on the others."""
+    torch = torch_cuda
+    from multibox_amd import loss as L
+    from oracle import ref_numpy as R
+    P = 129 * k + 1
+    priors = _priors_for(golden, P)
+    rng = np.random.RandomState(seed)
+    raw = (rng.randn(B, P, 4) * 0.05).astype(np.float32)
+    logits = (rng.randn(B, P) * 2 - 2).astype(np.float32)
+    n = rng.randint(0, G + 1, B).astype(np.int32)
+    n[0], n[1] = G, 0
+    gt = np.zeros((B, G, 4), np.float32)
+    for b in range(B):
+        xy = rng.uniform(0, .7, (n[b], 2)); wh = rng.uniform(.05, .3, (n[b], 2))
+        gt[b, :n[b], :2] = xy; gt[b, :n[b], 2:] = xy + wh
+    ml = L.MultiboxLoss(priors, B, G, 1000.0)
+    loss2, dl, dz = ml.forward_backward(torch.from_numpy(raw).cuda(), torch.from_numpy(logits).cuda(),
+                                        torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    torch.cuda.synchronize()
+    assert int(ml.status.max()) == 0
+    ref = R.add_loss(raw, R.sigmoid_f32(logits), gt, n, priors, 1000.0)
+    assert np.array_equal(ml.match.cpu().numpy(), ref["match"])
+    l2 = loss2.cpu().numpy().copy()
+    assert np.isclose(l2[0], ref["loc_loss"], rtol=1e-5) and np.isclose(l2[1], ref["conf_loss"], rtol=1e-5)
+    rdl, rdz = R.add_loss_grads(raw, logits, gt, priors, 1000.0, ref["match"])
+    dl_full, dz_full = dl.cpu().numpy().copy(), dz.cpu().numpy().copy()
+    assert np.allclose(dl_full, rdl, rtol=1e-4, atol=1e-6) and np.allclose(dz_full, rdz, rtol=1e-4, atol=1e-6)
+    # additivity over images: four quarter batches
+    q = B // 4
+    mq = L.MultiboxLoss(priors, q, G, 1000.0)
+    tot = np.zeros(2, np.float64)
+    for i in range(4):
+        sl = slice(i * q, (i + 1) * q)
+        l2q, dlq, dzq = mq.forward_backward(torch.from_numpy(raw[sl]).cuda(), torch.from_numpy(logits[sl]).cuda(),
+                                            torch.from_numpy(gt[sl]).cuda(), torch.from_numpy(n[sl]).cuda())
+        torch.cuda.synchronize()
+        tot += l2q.cpu().numpy()
+        assert np.array_equal(dlq.cpu().numpy(), dl_full[sl]) and np.array_equal(dzq.cpu().numpy(), dz_full[sl])
+    assert np.allclose(tot, l2, rtol=1e-5)
+
+
 def test_add_loss_reference_api_known_answers(torch_cuda):
     """model_tests.py:104-263 on the loss: signs, exact zero location loss with no gt."""
     torch = torch_cuda
