@@ -9,8 +9,8 @@ batch sum, so the reduction is SUM with no rescaling.  Batch-norm statistics sta
 Buckets are contiguous slices of the flat fp32 gradient buffer, one per backward segment
 (heads -> block8 -> block17 -> ...): each is handed to RCCL as soon as its segment's hipGraph has
 been enqueued, so the collective overlaps the rest of backward.  On the 8-GPU xGMI mesh a
-bucket of 60 MB moves 2*(7/8)*60 MB per GPU; 4 buckets keep each message large enough to be
-link-bound rather than latency-bound."""
+bucket of 40 MB moves 2*(7/8)*40 MB per GPU; 6 buckets keep each message large enough to be
+link-bound rather than latency-bound, and the last one -- the only one nothing overlaps -- small."""
 from __future__ import annotations
 
 import os

@@ -38,7 +38,7 @@ class Trainer:
     def __init__(self, net: Net, bbox_priors, max_num_bboxes=13, location_loss_alpha=1000.0, initial_learning_rate=0.01,
                  decay_steps_=7116, learning_rate_decay_factor=0.94, staircase=True, rmsprop_decay=0.9,
                  rmsprop_momentum=0.0, rmsprop_epsilon=1.0, moving_average_decay=0.9999, use_graph=True,
-                 n_segments=4, process_group=None):
+                 n_segments=None, process_group=None):
         assert net.mode == "train"
         self.net = net
         self.loss = MultiboxLoss(bbox_priors, net.B, max_num_bboxes, location_loss_alpha, device=net.dev)
@@ -70,6 +70,10 @@ class Trainer:
             net.fold_bn()
         self.use_graph = use_graph
         self.graphs = None
+        # backward segments = gradient buckets: data-parallel runs use more of them, so that the bucket that can only
+        # start after the LAST backward launch (nothing left to overlap it with) is small
+        if n_segments is None:
+            n_segments = 6 if self.reducer.enabled else 4
         self._segments = self._make_segments(n_segments)
 
     # ------------------------------------------------------------------ segments / buckets
