@@ -124,7 +124,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // SH: the stride-2 data gradient (input dilated by 2).  Its own instantiation, so that the parity walk below costs
 // the other 400 launches per step nothing (as a run-time branch in one kernel it cost them 0.6 ms per step).
 // MODE 1: pointwise (1x1, unit stride, no padding) -- the two-instruction address path, no tap walk: 60 % of the launches.
-template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0>
+// NSTG: ring depth.  3 = two tiles in flight; 2 = one, for 64 KB of LDS per 128x128 eight-wave block, so that TWO
+// blocks share a CU and one's epilogue (HBM-bound: skip read / accumulate / store) overlaps the other's loop.
+template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0, int NSTG = 3>
 __global__ void __launch_bounds__(64 * WNW * WMW)
 conv_igemm3_kernel(const ConvK p) {
   constexpr bool SH = MODE == 2, PW = MODE == 1;
@@ -223,15 +225,16 @@ conv_igemm3_kernel(const ConvK p) {
       glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                                \
     kc += 64;                                                                                                \
     while (kc >= p.C_in) { kc -= p.C_in; if ((ks += kstep) >= p.S) { ks = ks0; kr += kstep; } }              \
-    st_issue = st_issue == 2 ? 0 : st_issue + 1;                                                             \
+    st_issue = st_issue == NSTG - 1 ? 0 : st_issue + 1;                                                      \
   } while (0)
 
+  static_assert(NSTG == 2 || NSTG == 3, "ring depth");
   MBX_ISSUE_TILE(0);
-  if (nk > 1) { MBX_ISSUE_TILE(1); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
+  if (NSTG == 3 && nk > 1) { MBX_ISSUE_TILE(1); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
   raw_barrier();
   for (int it = 0; it < nk; ++it) {
-    const bool more = it + 2 < nk;
-    if (more) MBX_ISSUE_TILE(it + 2);
+    const bool more = it + NSTG - 1 < nk;
+    if (more) MBX_ISSUE_TILE(it + NSTG - 1);
     {                                                   // MFMA on tile `it` (ring slot st_comp)
       const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
       const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
@@ -249,9 +252,9 @@ conv_igemm3_kernel(const ConvK p) {
           for (int b = 0; b < MI; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
       }
-      st_comp = st_comp == 2 ? 0 : st_comp + 1;
+      st_comp = st_comp == NSTG - 1 ? 0 : st_comp + 1;
     }
-    if (more) wait_vmcnt<NL>(); else wait_vmcnt<0>();   // tile it+1 landed (own DMAs), then everyone's
+    if (NSTG == 3 && more) wait_vmcnt<NL>(); else wait_vmcnt<0>();   // tile it+1 landed (own DMAs), then everyone's
     raw_barrier();
   }
 #undef MBX_ISSUE_TILE
@@ -613,7 +616,8 @@ conv_wgrad2_kernel(const WgradK2 q) {
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
-                          {256, 128, 1.30f}, {128, 128, 1.10f}, {256, 64, 1.0f}};   // 5-7: eight-wave blocks (v2 kernel only)
+                          {256, 128, 1.30f}, {128, 128, 1.10f}, {256, 64, 1.0f},    // 5-7: eight-wave blocks
+                          {128, 128, 1.10f}};                                      // 8: eight waves, 2-deep ring, two blocks per CU
 
 int pick_cfg(long M, int C_out) {
   int best = 0;
@@ -638,8 +642,14 @@ int choose_cfg(long M, int C_out) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force;
-  // measured on MI355X (tools/kbench.py): the eight-wave 256x128 tile wins when there are enough pixels to
-  // fill the chip with one block per CU and at least two 128-channel column tiles; otherwise the model.
+  // measured on MI355X (tools/kbench.py, all B=64 layer shapes, plain / residual / accumulate epilogues): the
+  // eight-wave 128x128 tile with the 2-deep ring (two blocks per CU: one's epilogue and prologue overlap the
+  // other's loop) wins wherever its blocks fill both slots of most CUs and the 128-wide column tile is not
+  // mostly padding; then the eight-wave 256x128 tile (one block per CU); otherwise the model.
+  {
+    const long cols = (C_out + 127) / 128, tiles8 = ((M + 127) / 128) * cols;
+    if (tiles8 >= 384 && (double)C_out >= 0.6 * (double)(cols * 128)) return 8;
+  }
   if (C_out >= 256) {
     const long tiles5 = ((M + 255) / 256) * ((C_out + 127) / 128);
     const long rounds5 = (tiles5 + 255) / 256;              // one 8-wave block per CU
@@ -648,40 +658,41 @@ int choose_cfg(long M, int C_out) {
   return pick_cfg(M, C_out);
 }
 
-template <int BM, int BN, int WNW, int WMW>
+template <int BM, int BN, int WNW, int WMW, int NSTG = 3>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
   {
-    const size_t lds = 3 * (size_t)(BM + BN) * 128;
+    const size_t ring = NSTG * (size_t)(BM + BN) * 128, stage = (size_t)BM * (BN + 4) * 4;   // the epilogue stages fp32
+    const size_t lds = ring > stage ? ring : stage;
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
                    : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
     static bool attr_set3[6] = {false, false, false, false, false, false};
 #define MBX_LAUNCH_EV(EV)                                                                                     \
     case EV:                                                                                                  \
       if (!attr_set3[EV]) {                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0>), \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1>), \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1, NSTG>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         attr_set3[EV] = true;                                                                                 \
       }                                                                                                       \
       if (k.pw)                                                                                               \
-        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1>), dim3(k.tiles_m * k.tiles_n),       \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1, NSTG>), dim3(k.tiles_m * k.tiles_n),       \
                            dim3(64 * WNW * WMW), lds, s, k);                                                  \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0>), dim3(k.tiles_m * k.tiles_n),       \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>), dim3(k.tiles_m * k.tiles_n),       \
                            dim3(64 * WNW * WMW), lds, s, k);                                                  \
       break;
     static bool attr_sh[2] = {false, false};
 #define MBX_LAUNCH_SH(EV, SLOT)                                                                               \
     do {                                                                                                      \
       if (!attr_sh[SLOT]) {                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2>), \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2, NSTG>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         attr_sh[SLOT] = true;                                                                                 \
       }                                                                                                       \
-      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2>), dim3(k.tiles_m * k.tiles_n),      \
+      hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2, NSTG>), dim3(k.tiles_m * k.tiles_n),      \
                          dim3(64 * WNW * WMW), lds, s, k);                                                    \
     } while (0)
     if (k.shift) {                               // stride-2 data gradient: its own instantiations (store / accumulate)
@@ -784,6 +795,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     case 5: return launch_igemm<256, 128, 2, 4>(k, s);
     case 6: return launch_igemm<128, 128, 2, 4>(k, s);
     case 7: return launch_igemm<256, 64, 1, 8>(k, s);
+    case 8: return launch_igemm<128, 128, 2, 4, 2>(k, s);
     default: return launch_igemm<64, 64, 2, 2>(k, s);
   }
 }

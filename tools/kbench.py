@@ -65,6 +65,12 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
     d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, stats=stats)
     d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1)
     d_w = ops.make_desc(x, None, Co, R, S, st, pt, pl, y)
+    if os.environ.get("KB_EPI") == "res":             # the epilogue-heavy forms of the residual stages:
+        skip = ops.View.alloc(B, Ho, Wo, Co); skip.buf.normal_()      # forward: relu(skip + s * (acc + bias))
+        bias = torch.zeros(Co, device="cuda")
+        d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=bias, skip=skip, rscale=0.1)
+        act = ops.View.alloc(B, H, W, Ci); act.buf.normal_()         # data gradient: accumulate + relu mask
+        d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1, accumulate=1, skip=act)
     tf = timeit(lambda: ops.conv(d_f))
     td = timeit(lambda: ops.conv(d_d))
     tw = timeit(lambda: ops.conv_wgrad(d_w, dy, dw))
