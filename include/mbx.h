@@ -142,7 +142,11 @@ typedef struct {
   const void* skip; int64_t skip_img_stride; int32_t ld_skip; float rscale;
   float* stats_partial; /* [mbx_conv_stats_rows()][C_out][2] partial sum / sum-of-squares of the stored
                            y (bf16-rounded) for batch-norm statistics, or NULL              */
+  int32_t tile_config;  /* 0: the library picks the tile; n > 0: use tile configuration n-1 (0..MBX_CONV_TILE_CONFIGS-1)
+                           -- for callers that time the candidates on their own shapes.  Results do not depend on
+                           it (same K order), only mbx_conv_stats_rows() does.                */
 } mbx_conv_desc;
+#define MBX_CONV_TILE_CONFIGS 11
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);

@@ -617,7 +617,8 @@ conv_wgrad2_kernel(const WgradK2 q) {
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
                           {256, 128, 1.30f}, {128, 128, 1.10f}, {256, 64, 1.0f},    // 5-7: eight-wave blocks
-                          {128, 128, 1.10f}};                                      // 8: eight waves, 2-deep ring, two blocks per CU
+                          {128, 128, 1.10f},                                       // 8: eight waves, 2-deep ring, two blocks per CU
+                          {128, 64, 0.85f}, {64, 64, 0.70f}};                      // 9, 10: four waves, 2-deep ring (3+ blocks per CU)
 
 int pick_cfg(long M, int C_out) {
   int best = 0;
@@ -638,10 +639,12 @@ int pick_cfg(long M, int C_out) {
 
 
 
-int choose_cfg(long M, int C_out) {
+constexpr int kNumCfgs = 11;
+int choose_cfg(long M, int C_out, int desc_cfg) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force;
+  if (desc_cfg > 0 && desc_cfg <= kNumCfgs) return desc_cfg - 1;       // the caller measured (mbx_conv_desc.tile_config)
   // measured on MI355X (tools/kbench.py, all B=64 layer shapes, plain / residual / accumulate epilogues): the
   // eight-wave 128x128 tile with the 2-deep ring (two blocks per CU: one's epilogue and prologue overlap the
   // other's loop) wins wherever its blocks fill both slots of most CUs and the 128-wide column tile is not
@@ -733,7 +736,7 @@ int check_desc(const mbx_conv_desc* d) {
 extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   if (!d) return MBX_ERR_INVALID_ARG;
   const long M = (long)d->N * d->H_out * d->W_out;
-  const TileCfg& c = kCfgs[choose_cfg(M, d->C_out)];
+  const TileCfg& c = kCfgs[choose_cfg(M, d->C_out, d->tile_config)];
   return (int)((M + c.BM - 1) / c.BM);
 }
 
@@ -787,7 +790,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     k.skip_taps = k.parity = 1;
   }
   hipStream_t s = mbx_s(stream);
-  switch (choose_cfg(k.M, k.C_out)) {
+  switch (choose_cfg(k.M, k.C_out, d->tile_config)) {
     case 0: return launch_igemm<128, 128, 2, 2>(k, s);
     case 1: return launch_igemm<128, 64, 2, 2>(k, s);
     case 2: return launch_igemm<64, 128, 2, 2>(k, s);
@@ -796,6 +799,8 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     case 6: return launch_igemm<128, 128, 2, 4>(k, s);
     case 7: return launch_igemm<256, 64, 1, 8>(k, s);
     case 8: return launch_igemm<128, 128, 2, 4, 2>(k, s);
+    case 9: return launch_igemm<128, 64, 2, 2, 2>(k, s);
+    case 10: return launch_igemm<64, 64, 2, 2, 2>(k, s);
     default: return launch_igemm<64, 64, 2, 2>(k, s);
   }
 }

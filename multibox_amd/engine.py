@@ -77,6 +77,8 @@ class Net:
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
         self.no_onepass = bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
+        # every conv launch times the library's tile pick against the other tile configurations once, at build time
+        self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
         self.bn_max_wg = int(os.environ.get("MBX_BN_MAX_WG", "0")) or (bn_max_workgroups or 0)
         self.convs, self.fwd, self.bwd = [], [], []
@@ -421,7 +423,7 @@ class Net:
                 op.y = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)      # pre-BN output, kept for backward
                 self._bufs.append(op.y)
                 d = self._desc(op, View(op.y, op.out.N, op.out.H, op.out.W, op.K))
-                max_stats = max(max_stats, ops.conv_stats_rows(d) * op.K * 2)
+                max_stats = max(max_stats, max(ops.conv_stats_rows(d), (op.M + 63) // 64) * op.K * 2)     # any tile height
                 if op.trainable:
                     max_y = max(max_y, op.M * op.K)
                     max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, op.K) * op.K * 2)
@@ -449,6 +451,14 @@ class Net:
     def _sl(self, t, off, n):
         return t[off:off + n]
 
+    def _tune(self, op, d, what):
+        """Pick the tile configuration of one conv launch by measurement (ops.autotune); a no-op on CPU."""
+        if self.autotune:
+            key = (what, op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, d.C_out, d.C_in,
+                   d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip), d.relu)
+            ops.autotune(d, key)
+        return d
+
     def _build_forward_launches(self):
         """Pre-bind every forward launch; returns a list of zero-argument callables."""
         L = []
@@ -460,7 +470,7 @@ class Net:
                 continue
             if op.kind == "bn":
                 yv = View(op.y, op.out.N, op.out.H, op.out.W, op.K)
-                d = self._desc(op, yv, stats=self.stats_scratch)
+                d = self._tune(op, self._desc(op, yv, stats=self.stats_scratch), "fwd")
                 rows = ops.conv_stats_rows(d)
                 mean, rstd = self._sl(self.bn_mean, op.beta_off, op.K), self._sl(self.bn_rstd, op.beta_off, op.K)
                 mm, mv = self._sl(self.MM, op.beta_off, op.K), self._sl(self.MV, op.beta_off, op.K)
@@ -475,12 +485,13 @@ class Net:
                                                     mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_apply_fused")
                 L.append(run)
             elif op.kind == "frozen":
-                d = self._desc(op, op.out, epilogue=ops.EPI_AFFINE, relu=op.relu,
-                               scale=self._sl(self.bn_scale, op.beta_off, op.K), shift=self._sl(self.bn_shift, op.beta_off, op.K))
+                d = self._tune(op, self._desc(op, op.out, epilogue=ops.EPI_AFFINE, relu=op.relu,
+                                              scale=self._sl(self.bn_scale, op.beta_off, op.K),
+                                              shift=self._sl(self.bn_shift, op.beta_off, op.K)), "fwd")
                 L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
             elif op.kind == "residual":
-                d = self._desc(op, op.out, epilogue=ops.EPI_RESIDUAL, relu=op.relu, shift=self._sl(self.W, op.b_off, op.K),
-                               skip=op.skip, rscale=op.rscale)
+                d = self._tune(op, self._desc(op, op.out, epilogue=ops.EPI_RESIDUAL, relu=op.relu,
+                                              shift=self._sl(self.W, op.b_off, op.K), skip=op.skip, rscale=op.rscale), "fwd")
                 L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
             elif op.kind == "head":
                 d = self._desc(op, op.out, epilogue=ops.EPI_STORE_F32)
@@ -624,6 +635,7 @@ class Net:
                 ddesc = ops.make_desc(dyin, self.Wd[op.dgrad_off:], op.Cin, op.R, op.S, op.stride,
                                       op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
                                       rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None))
+                self._tune(op, ddesc, "dgrad")
 
             def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
                 s = st()

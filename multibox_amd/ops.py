@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("skip", C.c_void_p), ("skip_img_stride", C.c_int64), ("ld_skip", C.c_int32), ("rscale", C.c_float),
         ("stats_partial", C.c_void_p),
+        ("tile_config", C.c_int32),
     ]
 
 
@@ -113,3 +114,39 @@ def conv_stats_rows(desc: ConvDesc):
 def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
     _lib.check(_lib.lib().mbx_conv_wgrad(C.byref(desc), dy.ptr, dy.img_stride, dy.ld, dw.data_ptr(), _p(db), _stream()),
                "mbx_conv_wgrad")
+
+
+N_TILE_CONFIGS = 11
+_TUNED = {}          # (shape key) -> tile_config: one measurement per distinct conv in a process
+
+
+def autotune(desc: ConvDesc, key, candidates=None, iters=10):
+    """Time mbx_conv(desc) for the library's own pick (0) and the given tile configurations (1-based) on the
+    descriptor's real buffers; set desc.tile_config to the fastest and return it.  Results of the convolution do
+    not depend on the choice.  Cached per `key` so that equal layers (and later Net instances) agree."""
+    if key in _TUNED:
+        desc.tile_config = _TUNED[key]
+        return desc.tile_config
+    if candidates is None:
+        candidates = (0, 2, 4, 5, 6, 9, 10)
+        if os.environ.get("MBX_AUTOTUNE_SET") == "all":
+            candidates = tuple(range(0, N_TILE_CONFIGS + 1))
+    l = _lib.lib()
+    best, best_t = 0, float("inf")
+    s = _stream()
+    for cfg in candidates:
+        desc.tile_config = cfg
+        if l.mbx_conv(C.byref(desc), s) != 0:          # e.g. a configuration that does not apply
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            l.mbx_conv(C.byref(desc), s)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t * 0.97 or (cfg == 0 and t < best_t):       # a challenger must win by 3 %
+            best, best_t = cfg, t
+    desc.tile_config = best
+    _TUNED[key] = best
+    return best
