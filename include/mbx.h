@@ -146,7 +146,7 @@ typedef struct {
                            -- for callers that time the candidates on their own shapes.  Results do not depend on
                            it (same K order), only mbx_conv_stats_rows() does.                */
 } mbx_conv_desc;
-#define MBX_CONV_TILE_CONFIGS 11
+#define MBX_CONV_TILE_CONFIGS 14
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);

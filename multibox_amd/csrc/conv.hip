@@ -618,7 +618,8 @@ struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
                           {256, 128, 1.30f}, {128, 128, 1.10f}, {256, 64, 1.0f},    // 5-7: eight-wave blocks
                           {128, 128, 1.10f},                                       // 8: eight waves, 2-deep ring, two blocks per CU
-                          {128, 64, 0.85f}, {64, 64, 0.70f}};                      // 9, 10: four waves, 2-deep ring (3+ blocks per CU)
+                          {128, 64, 0.85f}, {64, 64, 0.70f},                       // 9, 10: four waves, 2-deep ring (3+ blocks per CU)
+                          {128, 64, 0.85f}, {256, 64, 1.0f}, {128, 128, 1.0f}};    // 11-13: 2-deep: 8w 128x64, 8w 256x64, 4w 128x128
 
 int pick_cfg(long M, int C_out) {
   int best = 0;
@@ -639,7 +640,7 @@ int pick_cfg(long M, int C_out) {
 
 
 
-constexpr int kNumCfgs = 11;
+constexpr int kNumCfgs = 14;
 int choose_cfg(long M, int C_out, int desc_cfg) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
@@ -801,6 +802,9 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     case 8: return launch_igemm<128, 128, 2, 4, 2>(k, s);
     case 9: return launch_igemm<128, 64, 2, 2, 2>(k, s);
     case 10: return launch_igemm<64, 64, 2, 2, 2>(k, s);
+    case 11: return launch_igemm<128, 64, 2, 4, 2>(k, s);
+    case 12: return launch_igemm<256, 64, 1, 8, 2>(k, s);
+    case 13: return launch_igemm<128, 128, 2, 2, 2>(k, s);
     default: return launch_igemm<64, 64, 2, 2>(k, s);
   }
 }

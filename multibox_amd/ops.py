@@ -116,7 +116,7 @@ def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
                "mbx_conv_wgrad")
 
 
-N_TILE_CONFIGS = 11
+N_TILE_CONFIGS = 14
 _TUNED = {}          # (shape key) -> tile_config: one measurement per distinct conv in a process
 
 
@@ -128,7 +128,7 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
         desc.tile_config = _TUNED[key]
         return desc.tile_config
     if candidates is None:
-        candidates = (0, 2, 4, 5, 6, 9, 10)
+        candidates = (0, 2, 4, 5, 6, 9, 10, 12, 13, 14)      # the tiles that won somewhere on the B=64 layer shapes
         if os.environ.get("MBX_AUTOTUNE_SET") == "all":
             candidates = tuple(range(0, N_TILE_CONFIGS + 1))
     l = _lib.lib()
