@@ -829,13 +829,23 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.tiles_k = (k.Ktot + 127) / 128;
   const int tiles = k.tiles_n * k.tiles_k;
   // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
-  static int target = 0;
-  if (!target) {
+  static int env_ng = 0, env_target = 0;
+  if (!env_ng) {
     const char* g1 = getenv("MBX_WGRAD_NG");
-    const int dflt = (g1 && g1[0] == '1') ? 512 : 256;                // 8-wave blocks: one per CU
-    const char* e = getenv("MBX_WGRAD_TARGET"); target = e ? atoi(e) : dflt; if (target < 1) target = dflt;
+    env_ng = (g1 && g1[0] == '1') ? 1 : 2;
+    const char* e = getenv("MBX_WGRAD_TARGET"); env_target = e ? atoi(e) : -1;
   }
-  int splits = target / tiles;                 // floor: all blocks resident in one round (2 per CU)
+  // mbx_conv_desc.tile_config selects the block shape for the weight gradient too: 0 library default (eight waves,
+  // 256 blocks: one per CU), 1 eight waves / 256, 2 four waves / 512 (two per CU), 3 eight waves / 192, 4 four waves / 384
+  int ng = env_ng, target = env_target > 0 ? env_target : (env_ng == 1 ? 512 : 256);
+  switch (d->tile_config) {
+    case 1: ng = 2; target = 256; break;
+    case 2: ng = 1; target = 512; break;
+    case 3: ng = 2; target = 192; break;
+    case 4: ng = 1; target = 384; break;
+    default: break;
+  }
+  int splits = target / tiles;                 // floor: all blocks resident in one round
   const int max_splits = (k.M + 511) / 512;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -860,8 +870,6 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
              d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
-    static int ng = 0;
-    if (!ng) { const char* e = getenv("MBX_WGRAD_NG"); ng = (e && e[0] == '1') ? 1 : 2; }
     const bool lin = k2.pw && k2.ydense, bias = db != nullptr;
     const dim3 grid(tiles * splits);
     static bool attr_set[8] = {false, false, false, false, false, false, false, false};

@@ -637,6 +637,11 @@ class Net:
                                       rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None))
                 self._tune(op, ddesc, "dgrad")
 
+            if self.autotune and int(os.environ.get("MBX_AUTOTUNE_WGRAD", "1")):
+                ops.autotune_wgrad(wdesc, dyv, scale, dw, db,
+                                   ("wgrad", op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
+                                    dyv.ld, db is not None))
+
             def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
                 s = st()
                 if pre is not None:

@@ -150,3 +150,31 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     desc.tile_config = best
     _TUNED[key] = best
     return best
+
+
+def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4), iters=10):
+    """The same for mbx_conv_wgrad_scaled: block shape / pixel-split count (mbx.h, tile_config 1..4).  The launches add
+    into `dw`: call it where dw is scratch (the engine zeroes its gradient buffer at the start of every step)."""
+    if key in _TUNED:
+        desc.tile_config = _TUNED[key]
+        return desc.tile_config
+    l = _lib.lib()
+    s = _stream()
+    best, best_t = 0, float("inf")
+    args = (dy.ptr, dy.img_stride, dy.ld, float(scale), dw.data_ptr(), _p(db), s)
+    for cfg in candidates:
+        desc.tile_config = cfg
+        if l.mbx_conv_wgrad_scaled(C.byref(desc), *args) != 0:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            l.mbx_conv_wgrad_scaled(C.byref(desc), *args)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t * 0.97 or (cfg == 0 and t < best_t):
+            best, best_t = cfg, t
+    desc.tile_config = best
+    _TUNED[key] = best
+    return best
