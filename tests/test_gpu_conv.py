@@ -188,6 +188,32 @@ def test_conv_dgrad_wgrad(T, g):
     assert ok, "wgrad: " + msg
     ok, msg = close(torch, db, dy.reshape(-1, Co).sum(0), f32=True)
     assert ok, "bias grad: " + msg
+    # every selectable block shape / split count (mbx_conv_desc.tile_config 1..4) gives the same sums
+    for cfg in (1, 2, 3, 4):
+        d.tile_config = cfg
+        dw.zero_(); db.zero_()
+        ops.conv_wgrad(d, dyb, dw, db)
+        ok, msg = close(torch, dw, wr.grad, f32=True)
+        assert ok, "wgrad tile_config %d: %s" % (cfg, msg)
+        ok, msg = close(torch, db, dy.reshape(-1, Co).sum(0), f32=True)
+        assert ok, "bias grad tile_config %d: %s" % (cfg, msg)
+    d.tile_config = 0
+    # ... and so does every igemm tile configuration, forward and data gradient (same K order: bit-identical outputs)
+    yv2 = ops.View.alloc(N, Ho, Wo, Co)
+    wdev = w.to(torch.bfloat16).cuda().contiguous()             # keep it alive: the descriptor holds a raw pointer
+    dfw = ops.make_desc(xb, wdev, Co, R, S, st, pads[0], pads[1], yv)
+    ops.conv(dfw)
+    ddg = ops.make_desc(dyb, wT, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], dx, transposed=1)
+    dx_ref = dx.tensor().clone()
+    for cfg in range(1, ops.N_TILE_CONFIGS + 1):
+        dfw.tile_config = cfg
+        dfw.y = yv2.ptr
+        ops.conv(dfw)
+        assert torch.equal(yv2.tensor(), yv.tensor()), "forward tile_config %d" % cfg
+        ddg.tile_config = cfg
+        dx.tensor().zero_()
+        ops.conv(ddg)
+        assert torch.equal(dx.tensor(), dx_ref), "dgrad tile_config %d" % cfg
 
 
 def test_wgrad_odd_cout_padded_dy(T):
