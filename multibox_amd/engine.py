@@ -379,6 +379,8 @@ class Net:
         self._build_backward()
         if torch.device(self.dev).type == "cuda":
             self.prepare_filters()
+            if os.environ.get("MBX_TUNE_SAVE"):           # refresh the shipped table of measured tile choices
+                ops.save_tune_cache()
 
     def init_weights(self, seed):
         """slim defaults (un-vendored): Xavier-uniform filters, zero biases/betas, moving mean 0 / variance 1."""

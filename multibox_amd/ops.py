@@ -117,13 +117,36 @@ def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
 
 
 N_TILE_CONFIGS = 14
-_TUNED = {}          # (shape key) -> tile_config: one measurement per distinct conv in a process
+_TUNED = {}          # repr(shape key) -> tile_config: one measurement per distinct conv in a process
+_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")
+
+
+def _load_tune_cache():
+    """Measured choices for the shapes of the shipped configurations (written on an MI355X with MBX_TUNE_SAVE=1).
+    A shape that is not in the file is measured at engine build; MBX_TUNE_CACHE=0 ignores the file."""
+    if os.environ.get("MBX_TUNE_CACHE", "1") != "0" and os.path.exists(_TUNE_FILE):
+        try:
+            import json
+            with open(_TUNE_FILE) as f:
+                _TUNED.update({k: int(v) for k, v in json.load(f).items()})
+        except (OSError, ValueError):
+            pass
+
+
+def save_tune_cache(path=None):
+    import json
+    with open(path or _TUNE_FILE, "w") as f:
+        json.dump(dict(sorted(_TUNED.items())), f, indent=0)
+
+
+_load_tune_cache()
 
 
 def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     """Time mbx_conv(desc) for the library's own pick (0) and the given tile configurations (1-based) on the
     descriptor's real buffers; set desc.tile_config to the fastest and return it.  Results of the convolution do
     not depend on the choice.  Cached per `key` so that equal layers (and later Net instances) agree."""
+    key = repr(key)
     if key in _TUNED:
         desc.tile_config = _TUNED[key]
         return desc.tile_config
@@ -134,6 +157,7 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     l = _lib.lib()
     best, best_t = 0, float("inf")
     s = _stream()
+    iters = int(os.environ.get("MBX_TUNE_ITERS", iters))
     for cfg in candidates:
         desc.tile_config = cfg
         if l.mbx_conv(C.byref(desc), s) != 0:          # e.g. a configuration that does not apply
@@ -155,12 +179,14 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
 def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4), iters=10):
     """The same for mbx_conv_wgrad_scaled: block shape / pixel-split count (mbx.h, tile_config 1..4).  The launches add
     into `dw`: call it where dw is scratch (the engine zeroes its gradient buffer at the start of every step)."""
+    key = repr(key)
     if key in _TUNED:
         desc.tile_config = _TUNED[key]
         return desc.tile_config
     l = _lib.lib()
     s = _stream()
     best, best_t = 0, float("inf")
+    iters = int(os.environ.get("MBX_TUNE_ITERS", iters))
     args = (dy.ptr, dy.img_stride, dy.ld, float(scale), dw.data_ptr(), _p(db), s)
     for cfg in candidates:
         desc.tile_config = cfg
