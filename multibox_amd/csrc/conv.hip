@@ -836,13 +836,16 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     const char* e = getenv("MBX_WGRAD_TARGET"); env_target = e ? atoi(e) : -1;
   }
   // mbx_conv_desc.tile_config selects the block shape for the weight gradient too: 0 library default (eight waves,
-  // 256 blocks: one per CU), 1 eight waves / 256, 2 four waves / 512 (two per CU), 3 eight waves / 192, 4 four waves / 384
+  // 256 blocks: one per CU), 1 eight waves / 256, 2 four waves / 512 (two per CU), 3 eight waves / 192, 4 four waves / 384,
+  // 5 eight waves / 128, 6 eight waves / 224
   int ng = env_ng, target = env_target > 0 ? env_target : (env_ng == 1 ? 512 : 256);
   switch (d->tile_config) {
     case 1: ng = 2; target = 256; break;
     case 2: ng = 1; target = 512; break;
     case 3: ng = 2; target = 192; break;
     case 4: ng = 1; target = 384; break;
+    case 5: ng = 2; target = 128; break;
+    case 6: ng = 2; target = 224; break;
     default: break;
   }
   int splits = target / tiles;                 // floor: all blocks resident in one round

@@ -176,7 +176,7 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     return best
 
 
-def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4), iters=10):
+def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4, 5, 6), iters=10):
     """The same for mbx_conv_wgrad_scaled: block shape / pixel-split count (mbx.h, tile_config 1..4).  The launches add
     into `dw`: call it where dw is scratch (the engine zeroes its gradient buffer at the start of every step)."""
     key = repr(key)
