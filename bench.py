@@ -191,6 +191,7 @@ def main():
         dt = float(t)
     losses = tr.losses()
     status_ok = int(tr.match_status().max()) == 0
+    barrier_timeouts = net.barrier_timeouts()
     out = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -205,7 +206,7 @@ def main():
                                          ", --fine_tune" if args.fine_tune else ""),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
                "final_losses": {"location": round(losses[0], 3), "confidence": round(losses[1], 3), "regularization": round(losses[2], 4)},
-               "matching_ok": status_ok,
+               "matching_ok": status_ok, "grid_barrier_timeouts": barrier_timeouts,
                "algorithmic_tflop_per_step": round(79.9e-3 * B * world, 3)}
         out["model_tflops"] = round(out["algorithmic_tflop_per_step"] / (dt / args.steps), 2)
     if not args.no_roofline and rank == 0:

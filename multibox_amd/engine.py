@@ -682,6 +682,17 @@ class Net:
             f()
         return self.locs, self.logits
 
+    def barrier_timeouts(self):
+        """Number of one-launch BN-backward kernels of the LAST backward pass whose grid barrier gave up (their
+        workgroups were not all resident); 0 in a healthy run.  Host sync."""
+        if self.mode != "train" or self.no_onepass:
+            return 0
+        ws = self.bn_ws.view(torch.int32)
+        idx = [op.bn_ws_off + 4 * 2 * op.K + 1 for op in self.convs if getattr(op, "bn_ws_off", -1) >= 0]
+        if not idx:
+            return 0
+        return int((ws[torch.tensor(idx, device=ws.device)] != 0).sum())
+
     def zero_grads(self):
         self.Wg.zero_()
         self.Btg.zero_()

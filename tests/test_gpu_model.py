@@ -361,6 +361,6 @@ def test_overfits_one_batch(env):
     for _ in range(160):
         tr.step()
     last = tr.losses()
-    assert int(tr.match_status().max()) == 0
+    assert int(tr.match_status().max()) == 0 and net.barrier_timeouts() == 0
     assert np.isfinite(last[3]) and last[3] < first[3] / 8.0, (first, last)
     assert last[0] < first[0] / 8.0 and last[1] < first[1] / 4.0, (first, last)      # both terms of loss.py:100-101
