@@ -145,7 +145,8 @@ typedef struct {
   int32_t tile_config;  /* 0: the library picks the tile; n > 0: use tile configuration n-1 (0..MBX_CONV_TILE_CONFIGS-1)
                            -- for callers that time the candidates on their own shapes.  Results do not depend on
                            it (same K order), only mbx_conv_stats_rows() does.  For mbx_conv_wgrad*: 0 default,
-                           1..6 = {8 waves x 256 blocks, 4 waves x 512, 8 x 192, 4 x 384, 8 x 128, 8 x 224}.      */
+                           1..6 = {8 waves x 256 blocks, 4 waves x 512, 8 x 192, 4 x 384, 8 x 128, 8 x 224}, 7 / 8 =
+                           the narrow tile (64 output channels per block): 8 waves x 256 / 192, 9 / 10 = 4 waves x 512 / 768. */
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 

@@ -613,6 +613,197 @@ conv_wgrad2_kernel(const WgradK2 q) {
   if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
 }
 
+// The NARROW tile: 64 output channels x 128 filter columns per block (dy rows of 128 B in LDS, their own swizzle).
+// Half the tile for the same grid means every block covers twice the pixels: half the fp32 atomics per launch, and
+// channel counts like 32 / 48 / 64 / 160 / 192 / 320 / 1088 stop padding a 128-wide tile.  dy must be pixel-dense.
+template <int NST, int NG, bool LIN, bool BIAS>
+__global__ void __launch_bounds__(kThreads * NG)
+conv_wgrad2n_kernel(const WgradK2 q) {
+  const WgradK& p = q.b;
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];     // [NST][Y 64x8 | X 64x16] slots
+  constexpr int STAGE = 64 * 8 + 64 * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave8 = wave_id();
+  const int grp = NG == 2 ? (wave8 >> 2) : 0, wave = wave8 & 3;
+  const int tid = threadIdx.x & 255;                   // thread index inside its 4-wave group
+  const int wn = wave & 1, wk = wave >> 1;
+  const int ntiles = p.tiles_n * p.tiles_k;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles, split = lid / ntiles;
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  const int n0 = tile_n * 64, k0 = tile_k * 128;
+  const int blk_begin = split * p.m_per_split;
+  const int blk_end = min(p.M, blk_begin + p.m_per_split);
+  // group 0 takes the first half of the block's pixels (rounded up to 64), group 1 the rest
+  const int half = NG == 2 ? ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63) : (blk_end - blk_begin);
+  const int m_begin = blk_begin + grp * half;
+  const int m_end = NG == 2 ? (grp == 0 ? min(blk_end, blk_begin + half) : blk_end) : blk_end;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
+
+  // ---- DMA lane constants
+  const int r4 = lane >> 4;                                   // row within the 4-row piece
+  const int swz = ((r4 & 3) | (((wave >> 1) & 1) << 2)) << 1; // swz(row) for rows 16*i + 4*wave + r4
+  const int lc = (lane & 15) ^ swz;                           // logical chunk this lane fetches
+  const int kcol = k0 + lc * 8;
+  const bool kvalid = kcol < p.Ktot;
+  const int tap = (kvalid ? kcol : 0) / p.C_in, tc = (kvalid ? kcol : 0) - tap * p.C_in;
+  const int tr = kvalid ? tap / p.S : (1 << 24), ts = tap - (tap / p.S) * p.S;
+  const int toff = ((tr * p.W_in + ts) * p.ldx + tc) * 2;
+  // dy rows: a DMA instruction fills 8 rows x 8 chunks; rows 32*i + 8*wave + r8; swz(row) = (bit1 | bit3 << 1) << 1
+  const int r8 = lane >> 3;
+  const int swzy = ((((r8 >> 1) & 1) | ((wave & 1) << 1)) << 1);
+  const int lcy = (lane & 7) ^ swzy;
+  const int ycol = (n0 + lcy * 8 < p.C_out) ? (n0 + lcy * 8) * 2 : -1;
+  const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
+  int my_run = m_begin + wave * 8 + r8;                      // next dy row of this lane (advances by 32 per instruction)
+  // running pixel = next row this lane will fetch (advances by 16 per DMA instruction)
+  int m_run = m_begin + wave * 4 + r4;
+  int img = 0, oh = 0, ow = 0;
+  {
+    const unsigned mm = (unsigned)min(m_run, p.M - 1);
+    img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+    const int pix = (int)mm - img * p.HW_out;
+    oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w);
+    ow = pix - oh * p.W_out;
+  }
+
+  // ---- fragment (transpose-read) lane constants, byte offsets inside a 16 KB tile
+  const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
+  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
+  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
+  const int lby = (8 * g + fq) * 128 + (pp & 1) * 8;          // dy tile: 128-byte rows
+  const int sxy = ((((fq >> 1) & 1) | ((g & 1) << 1)) << 1);
+  int yo[2], xo[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) yo[a] = lby + (((2 * (wn * 2 + a) + (pp >> 1)) ^ sxy) << 4);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) xo[b] = lb + (((2 * (wk * 4 + b) + (pp >> 1)) ^ sx) << 4) + 64 * 128;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = BIAS && p.db != nullptr && tile_k == 0 && tid < 64 && n0 + tid < p.C_out;
+
+  const int nsteps = (half + 63) >> 6;                   // same trip count for both groups (barriers are block-wide)
+  int st_issue = 0, st_comp = 0;
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // DMA of pixel step LT into ring slot st_issue (macro: straight-line call sites, see igemm)
+#define MBX_ISSUE_STEP()                                                                                      \
+  do {                                                                                                        \
+    u32x4* sp = smem + (grp * NST + st_issue) * STAGE + wave * 64;                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+      const bool mv = m_run < m_end;                                                                          \
+      int xoff, yoff;                                                                                         \
+      if (LIN || q.pw) xoff = (mv && kvalid) ? (m_run * ldx2 + kcol * 2) : (int)kOOB;                         \
+      else {                                                                                                  \
+        const int hb = oh * p.stride - p.pad_t + tr, wb = ow * p.stride - p.pad_l + ts;                       \
+        const bool ok = mv && ((unsigned)hb < (unsigned)p.H_in) && ((unsigned)wb < (unsigned)p.W_in);         \
+        xoff = ok ? ((img * p.x_img_stride + ((oh * p.stride - p.pad_t) * p.W_in + ow * p.stride - p.pad_l) * p.ldx) * 2 + toff) \
+                  : (int)kOOB;                                                                                \
+      }                                                                                                       \
+      if (i < 2) {                                                                                            \
+        yoff = (my_run < m_end && ycol >= 0) ? (my_run * ldy2 + ycol) : (int)kOOB;                            \
+        glds16(yr, sp + i * 256, yoff);                                                                       \
+        my_run += 32;                                                                                         \
+      }                                                                                                       \
+      glds16(xr, sp + 512 + i * 256, xoff);                                                                   \
+      m_run += 16;                                                                                            \
+      if (!LIN && !(q.pw && q.ydense)) {                                                                      \
+        ow += 16;                                                                                             \
+        while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                        \
+        while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                       \
+      }                                                                                                       \
+    }                                                                                                         \
+    st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
+  } while (0)
+
+  static_assert(NST == 2, "ring depth 2: one step in flight");
+  if (nsteps > 0) MBX_ISSUE_STEP();
+  wait_vmcnt<0>();
+  raw_barrier();
+  for (int it = 0; it < nsteps; ++it) {
+    if (it + 1 < nsteps) MBX_ISSUE_STEP();
+    {
+      const char* base = reinterpret_cast<const char*>(smem + (grp * NST + st_comp) * STAGE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 yf[2], xf[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096 + 512));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          yf[a] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192 + 1024));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          xf[b] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+      }
+      if (do_bias) {
+        const unsigned short* cY = reinterpret_cast<const unsigned short*>(base);
+        const int ch = tid >> 3, e = tid & 7;
+        for (int r = 0; r < 64; ++r)
+          bsum += bf2f(cY[r * 64 + ((ch ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1)) << 3) + e]);
+      }
+      st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
+    }
+    wait_vmcnt<0>();
+    raw_barrier();
+  }
+#undef MBX_ISSUE_STEP
+  wait_vmcnt<0>();
+  if (NG == 2) {                                        // group 1 -> LDS -> group 0 (rings are idle now)
+    float* xch = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[((a * 4 + b) * 4 + r) * 256 + tid] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (grp == 1) {
+      if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
+      return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += xch[((a * 4 + b) * 4 + r) * 256 + tid];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int nb = n0 + wn * 32 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
+      if (kc >= p.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+    }
+  }
+  if (do_bias) atomicAdd(p.db + n0 + tid, bsum * p.scale);
+}
+
+
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
@@ -825,7 +1016,9 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
   k.M = d->N * k.HW_out;
   k.dw = dw; k.db = db; k.scale = scale;
-  k.tiles_n = (k.C_out + 127) / 128;
+  // tile_config 7 / 8: the narrow tile (64 output channels per block; eight waves, 256 / 192 blocks); needs dense dy
+  const bool narrow = d->tile_config >= 7 && d->tile_config <= 10 && dy_img_stride == (int64_t)d->H_out * d->W_out * ld_dy;
+  k.tiles_n = narrow ? (k.C_out + 63) / 64 : (k.C_out + 127) / 128;
   k.tiles_k = (k.Ktot + 127) / 128;
   const int tiles = k.tiles_n * k.tiles_k;
   // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
@@ -846,6 +1039,10 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     case 4: ng = 1; target = 384; break;
     case 5: ng = 2; target = 128; break;
     case 6: ng = 2; target = 224; break;
+    case 7: ng = 2; target = 256; break;
+    case 8: ng = 2; target = 192; break;
+    case 9: ng = 1; target = 512; break;
+    case 10: ng = 1; target = 768; break;
     default: break;
   }
   int splits = target / tiles;                 // floor: all blocks resident in one round
@@ -875,6 +1072,31 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
     const bool lin = k2.pw && k2.ydense, bias = db != nullptr;
     const dim3 grid(tiles * splits);
+    if (narrow) {
+      static bool attr_n[8] = {false, false, false, false, false, false, false, false};
+      constexpr int kLdsN = 2 * (64 * 8 + 64 * 16) * 16;              // per group: two stages x 24 KB
+#define MBX_WGN(NGV, LINV, BIASV)                                                                                      \
+      do {                                                                                                             \
+        constexpr int slot = (NGV - 1) * 4 + (LINV ? 2 : 0) + (BIASV ? 1 : 0);                                         \
+        if (!attr_n[slot]) {                                                                                           \
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2n_kernel<2, NGV, LINV, BIASV>),          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NGV * kLdsN);                         \
+          attr_n[slot] = true;                                                                                         \
+        }                                                                                                              \
+        hipLaunchKernelGGL((conv_wgrad2n_kernel<2, NGV, LINV, BIASV>), grid, dim3(NGV * kThreads), NGV * kLdsN,        \
+                           mbx_s(stream), k2);                                                                         \
+      } while (0)
+#define MBX_WGN_NG(NGV)                                                                                                \
+      do {                                                                                                             \
+        if (lin) { if (bias) MBX_WGN(NGV, true, true); else MBX_WGN(NGV, true, false); }                               \
+        else { if (bias) MBX_WGN(NGV, false, true); else MBX_WGN(NGV, false, false); }                                 \
+      } while (0)
+      if (ng == 2) MBX_WGN_NG(2); else MBX_WGN_NG(1);
+#undef MBX_WGN_NG
+#undef MBX_WGN
+      MBX_LAUNCH_CHECK();
+      return MBX_OK;
+    }
     static bool attr_set[8] = {false, false, false, false, false, false, false, false};
 #define MBX_WG(NGV, LINV, BIASV)                                                                                       \
     do {                                                                                                               \

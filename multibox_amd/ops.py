@@ -176,7 +176,7 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     return best
 
 
-def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4, 5, 6), iters=10):
+def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 2, 3, 4, 7, 8, 9, 10), iters=10):
     """The same for mbx_conv_wgrad_scaled: block shape / pixel-split count (mbx.h, tile_config 1..4).  The launches add
     into `dw`: call it where dw is scratch (the engine zeroes its gradient buffer at the start of every step)."""
     key = repr(key)
@@ -187,6 +187,8 @@ def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 
     s = _stream()
     best, best_t = 0, float("inf")
     iters = int(os.environ.get("MBX_TUNE_ITERS", iters))
+    if os.environ.get("MBX_AUTOTUNE_WG"):
+        candidates = tuple(int(v) for v in os.environ["MBX_AUTOTUNE_WG"].split(","))
     args = (dy.ptr, dy.img_stride, dy.ld, float(scale), dw.data_ptr(), _p(db), s)
     for cfg in candidates:
         desc.tile_config = cfg

@@ -188,8 +188,8 @@ def test_conv_dgrad_wgrad(T, g):
     assert ok, "wgrad: " + msg
     ok, msg = close(torch, db, dy.reshape(-1, Co).sum(0), f32=True)
     assert ok, "bias grad: " + msg
-    # every selectable block shape / split count (mbx_conv_desc.tile_config 1..6) gives the same sums
-    for cfg in (1, 2, 3, 4, 5, 6):
+    # every selectable block shape / split count (mbx_conv_desc.tile_config 1..10; 7..10 are the narrow tile) gives the same sums
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         d.tile_config = cfg
         dw.zero_(); db.zero_()
         ops.conv_wgrad(d, dyb, dw, db)
