@@ -682,6 +682,15 @@ class Net:
             f()
         return self.locs, self.logits
 
+    def flops_per_image(self, train=True):
+        """Algorithmic FLOPs per image (2 per multiply-add) of the convolutions (SURVEY 8(d) convention): forward
+        only, or a training step counted as 3x forward for trainable layers (dgrad + wgrad) and 1x for frozen ones."""
+        total = 0.0
+        for op in self.convs:
+            f = 2.0 * (op.M // self.B) * op.K * op.Cin * op.R * op.S
+            total += f * (3.0 if (train and op.trainable) else 1.0)
+        return total
+
     def barrier_timeouts(self):
         """Number of one-launch BN-backward kernels of the LAST backward pass whose grid barrier gave up (their
         workgroups were not all resident); 0 in a healthy run.  Host sync."""

@@ -41,6 +41,22 @@ def generate_priors(aspect_ratios, min_scale=0.1, max_scale=0.95, restrict_to_im
     return generate_priors_array(aspect_ratios, min_scale, max_scale, restrict_to_image_bounds, grids).tolist()
 
 
+def priors_for_input_size(aspect_ratios, input_size=299, min_scale=0.1, max_scale=0.95, restrict_to_image_bounds=True):
+    """Priors matching the network's prediction order at any INPUT_SIZE (float64 [P,4]).
+
+    At 299 this is generate_priors (priors.py:185-314: grids 8,6,4,3,2 + one whole-image box).  At other
+    sizes the last head is a g x g map with ONE prior per cell (7x7 at 512): the gridded part
+    keeps the reference's scale ladder, the last head's cells get aspect-ratio-1 boxes at max_scale.
+    """
+    grids, last = head_grids(input_size)
+    if last == 1:
+        return generate_priors_array(aspect_ratios, min_scale, max_scale, restrict_to_image_bounds, grids + [1])
+    g = int(round(last ** 0.5))
+    main = generate_priors_array(aspect_ratios, min_scale, max_scale, restrict_to_image_bounds, grids + [1])[:-1]
+    tail = generate_priors_array([1.0], max_scale, max_scale, restrict_to_image_bounds, [g, 1])[:-1]
+    return np.concatenate([main, tail])
+
+
 def generate_priors_array(aspect_ratios, min_scale=0.1, max_scale=0.95, restrict_to_image_bounds=True, grids=None):
     l = _lib.lib()
     ars = np.ascontiguousarray(aspect_ratios, dtype=np.float64)

@@ -319,14 +319,7 @@ def test_other_baseline_configs_run(env, S, k, B, G):
     from multibox_amd import priors as PR
     from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
     net = Net(batch=B, input_size=S, k=k, mode="train", seed=21)
-    grids, last = PR.head_grids(S)
-    grids = grids + ([1] if last == 1 else [int(round(last ** 0.5))])
-    pri = PR.generate_priors_array(DEFAULT_ASPECT_RATIOS[k], grids=grids) if S == 299 else None
-    if pri is None:
-        # 512: the last head has 7x7 single-prior cells; build [g..., 7 with k=1] by hand
-        main = PR.generate_priors_array(DEFAULT_ASPECT_RATIOS[k], grids=grids[:-1] + [1])[:-1]
-        tail = PR.generate_priors_array([1.0], grids=[grids[-1], 1], min_scale=0.95, max_scale=0.95)[:-1]
-        pri = np.concatenate([main, tail])
+    pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], S)
     assert pri.shape[0] == net.P, (pri.shape, net.P)
     tr = Trainer(net, pri.astype(np.float32), max_num_bboxes=G, use_graph=False)
     images, gt, n = synthetic_batch(B, S, G, seed=3)
