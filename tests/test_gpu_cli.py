@@ -137,3 +137,24 @@ def test_eval_cli(tmp_path):
     assert "Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]" in out["summary"]
     assert all(-1.0 <= v <= 1.0 for v in out["stats"]) and "Step: 1" in r.stdout
     assert out["stats"][0] >= 0.0                      # an untrained net scores ~0, but the metric is defined (4 gt boxes)
+
+
+def test_bench_contract_over_rccl(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, RCCL):
+    on a one-GPU box MBX_FORCE_DIST=1 keeps the process group, the bucketed all-reduce between the backward graph
+    segments and the grid cap of the BN backward in the path.  One JSON line with the contract's keys."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MBX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--batch", "8", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["matching_ok"] and out["grid_barrier_timeouts"] == 0 and out["value"] > 0
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
