@@ -714,7 +714,7 @@ head_scatter_kernel(const float* __restrict__ d_locs, const float* __restrict__ 
 __global__ void __launch_bounds__(kT)
 filter_prepare_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wd,
                       const mbx_filter_entry* __restrict__ table, int n_entries) {
-  __shared__ unsigned short tile[64][33];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][40];     // 80-byte rows: 16-byte aligned chunks
   int lo = 0, hi = n_entries - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -730,6 +730,29 @@ filter_prepare_kernel(const unsigned short* __restrict__ w, unsigned short* __re
   unsigned short* dst = wd + e.dst_off;
   const int k0 = ck * 64, c0 = cc * 32;
   const long long tap_src = ((long long)(e.R - 1 - r) * e.S + (e.S - 1 - s)) * e.C;
+  if (((e.C | e.Kpad) & 7) == 0 && ((e.src_off | e.dst_off) & 7) == 0) {
+    // 16 bytes per lane both ways: one load of 8 channels of one filter, one store of 8 filters of one channel
+    static_assert(kT == 256, "one 16-byte chunk per thread");
+    {
+      const int kk = threadIdx.x >> 2, c = (threadIdx.x & 3) << 3;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (k0 + kk < e.K && c0 + c < e.C)
+        v = *reinterpret_cast<const uint4*>(src + (long long)(k0 + kk) * e.R * e.S * e.C + tap_src + c0 + c);
+      *reinterpret_cast<uint4*>(&tile[kk][c]) = v;
+    }
+    __syncthreads();
+    {
+      const int c = threadIdx.x >> 3, kk = (threadIdx.x & 7) << 3;
+      if (k0 + kk < e.Kpad && c0 + c < e.C) {
+        unsigned q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = (unsigned)tile[kk + 2 * j][c] | ((unsigned)tile[kk + 2 * j + 1][c] << 16);
+        *reinterpret_cast<uint4*>(dst + (((long long)(c0 + c) * e.R + r) * e.S + s) * e.Kpad + k0 + kk) =
+            make_uint4(q[0], q[1], q[2], q[3]);
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 64 * 32; i += kT) {         // read: c fastest
     const int kk = i >> 5, c = i & 31;
     unsigned short v = 0;

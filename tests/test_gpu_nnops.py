@@ -271,7 +271,7 @@ def test_filter_prepare(T):
     from multibox_amd import _lib
     l = _lib.lib()
     gen = torch.Generator().manual_seed(2)
-    shapes = [(32, 3, 3, 8), (25, 1, 1, 96), (160, 1, 7, 128), (96, 2, 2, 128)]
+    shapes = [(32, 3, 3, 8), (25, 1, 1, 96), (160, 1, 7, 128), (96, 2, 2, 128), (70, 3, 1, 40), (16, 1, 1, 12)]   # last: scalar path
     ws = [bfr(torch, torch.randn(*s, generator=gen)) for s in shapes]
     src_off, dst_off, blocks, entries, refs = 0, 0, 0, [], []
     flat = []
