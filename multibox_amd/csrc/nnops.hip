@@ -504,10 +504,14 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
 }
 
 // ------------------------------------------------------------------------------- pooling
+// KK / SS: window and stride fixed at compile time (3 / 2: every max pool of the network) so that the nine loads of
+// a window are independent and in flight together; 0 = run-time values.
+template <int KK, int SS>
 __global__ void __launch_bounds__(kT)
-maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k,
-                   int stride, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo,
+maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, int N, int H, int W, int C, int k_,
+                   int stride_, unsigned short* __restrict__ y, long long ys, int ldy, int Ho, int Wo,
                    unsigned char* __restrict__ argmax) {
+  const int k = KK ? KK : k_, stride = SS ? SS : stride_;
   const int C8 = C >> 3;
   const unsigned total = (unsigned)N * Ho * Wo * C8;            // < 2^31 (checked on the host): 32-bit index math
   for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
@@ -521,16 +525,39 @@ maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
     unsigned arg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
-    for (int r = 0; r < k; ++r)
-      for (int s = 0; s < k; ++s) {
-        const int h = oh * stride + r, w = ow * stride + s;
-        if (h >= H || w >= W) continue;
-        float f[8];
-        unpack8(ld8(x + n * xs + ((long long)h * W + w) * ldx + c), f);
+    if constexpr (KK > 0) {
+      u32x4 v[KK * KK];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (f[j] > best[j]) { best[j] = f[j]; arg[j] = r * k + s; }
-      }
+      for (int r = 0; r < KK; ++r)
+#pragma unroll
+        for (int s = 0; s < KK; ++s) {
+          const int h = oh * stride + r, w = ow * stride + s;
+          v[r * KK + s] = (h < H && w < W) ? ld8(x + n * xs + ((long long)h * W + w) * ldx + c) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+      for (int r = 0; r < KK; ++r)
+#pragma unroll
+        for (int s = 0; s < KK; ++s) {
+          const int h = oh * stride + r, w = ow * stride + s;
+          if (h >= H || w >= W) continue;
+          float f[8];
+          unpack8(v[r * KK + s], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (f[j] > best[j]) { best[j] = f[j]; arg[j] = r * KK + s; }
+        }
+    } else {
+      for (int r = 0; r < k; ++r)
+        for (int s = 0; s < k; ++s) {
+          const int h = oh * stride + r, w = ow * stride + s;
+          if (h >= H || w >= W) continue;
+          float f[8];
+          unpack8(ld8(x + n * xs + ((long long)h * W + w) * ldx + c), f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (f[j] > best[j]) { best[j] = f[j]; arg[j] = r * k + s; }
+        }
+    }
     st8(y + n * ys + ((long long)oh * Wo + ow) * ldy + c, pack8(best));
     if (argmax) {
       u32x2 av;
@@ -541,10 +568,12 @@ maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
   }
 }
 
+template <int KK, int SS>
 __global__ void __launch_bounds__(kT)
 maxpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_dy,
-                   const unsigned char* __restrict__ argmax, int N, int H, int W, int C, int k, int stride, int Ho,
+                   const unsigned char* __restrict__ argmax, int N, int H, int W, int C, int k_, int stride_, int Ho,
                    int Wo, unsigned short* __restrict__ dx, long long dxs, int ld_dx, int accumulate) {
+  const int k = KK ? KK : k_, stride = SS ? SS : stride_;
   const int C8 = C >> 3;
   const unsigned total = (unsigned)N * H * W * C8;              // < 2^31 (checked on the host): 32-bit index math
   for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
@@ -561,24 +590,59 @@ maxpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     }
-    int oh0 = (h - k + stride) / stride;          // ceil((h-k+1)/stride) for h-k+1 > -stride
-    if (h - k + 1 <= 0) oh0 = 0;
-    int ow0 = (w - k + stride) / stride;
-    if (w - k + 1 <= 0) ow0 = 0;
-    const int oh1 = min(h / stride, Ho - 1), ow1 = min(w / stride, Wo - 1);
-    for (int oh = oh0; oh <= oh1; ++oh)
-      for (int ow = ow0; ow <= ow1; ++ow) {
-        const unsigned tap = (h - oh * stride) * k + (w - ow * stride);
-        const long long o = ((long long)n * Ho + oh) * Wo + ow;
-        const u32x2 av = *reinterpret_cast<const u32x2*>(argmax + o * C + c);
-        float g[8];
-        unpack8(ld8(dy + n * dys + ((long long)oh * Wo + ow) * ld_dy + c), g);
+    if constexpr (KK > 0) {
+      // the (at most NW x NW) windows covering (h, w), ascending like the run-time loops: all loads first
+      constexpr int NW = (KK + SS - 1) / SS;
+      const int ohb = h / SS, owb = w / SS;
+      u32x4 gv[NW * NW];
+      u32x2 av[NW * NW];
+      bool ok[NW * NW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned aj = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xffu;
-          if (aj == tap) acc[j] += g[j];
+      for (int a = 0; a < NW; ++a)
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+          const int oh = ohb - (NW - 1 - a), ow = owb - (NW - 1 - b);
+          const bool v = oh >= 0 && oh < Ho && ow >= 0 && ow < Wo && h - oh * SS < KK && w - ow * SS < KK;
+          ok[a * NW + b] = v;
+          const long long o = ((long long)n * Ho + (v ? oh : 0)) * Wo + (v ? ow : 0);
+          av[a * NW + b] = v ? *reinterpret_cast<const u32x2*>(argmax + o * C + c) : u32x2{0u, 0u};
+          gv[a * NW + b] = v ? ld8(dy + n * dys + ((long long)oh * Wo + ow) * ld_dy + c) : u32x4{0u, 0u, 0u, 0u};
         }
-      }
+#pragma unroll
+      for (int a = 0; a < NW; ++a)
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+          if (!ok[a * NW + b]) continue;
+          const int oh = ohb - (NW - 1 - a), ow = owb - (NW - 1 - b);
+          const unsigned tap = (h - oh * SS) * KK + (w - ow * SS);
+          float g[8];
+          unpack8(gv[a * NW + b], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned aj = ((j < 4 ? av[a * NW + b].x : av[a * NW + b].y) >> (8 * (j & 3))) & 0xffu;
+            if (aj == tap) acc[j] += g[j];
+          }
+        }
+    } else {
+      int oh0 = (h - k + stride) / stride;          // ceil((h-k+1)/stride) for h-k+1 > -stride
+      if (h - k + 1 <= 0) oh0 = 0;
+      int ow0 = (w - k + stride) / stride;
+      if (w - k + 1 <= 0) ow0 = 0;
+      const int oh1 = min(h / stride, Ho - 1), ow1 = min(w / stride, Wo - 1);
+      for (int oh = oh0; oh <= oh1; ++oh)
+        for (int ow = ow0; ow <= ow1; ++ow) {
+          const unsigned tap = (h - oh * stride) * k + (w - ow * stride);
+          const long long o = ((long long)n * Ho + oh) * Wo + ow;
+          const u32x2 av = *reinterpret_cast<const u32x2*>(argmax + o * C + c);
+          float g[8];
+          unpack8(ld8(dy + n * dys + ((long long)oh * Wo + ow) * ld_dy + c), g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned aj = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xffu;
+            if (aj == tap) acc[j] += g[j];
+          }
+        }
+    }
     st8(dst, pack8(acc));
   }
 }
@@ -970,8 +1034,12 @@ extern "C" int mbx_maxpool_fwd(const void* x, int64_t xs, int ldx, int N, int H,
   if (!pool_args_ok(x, ldx, y, ldy, N, H, W, C, k, Ho, Wo) || stride < 1) return MBX_ERR_INVALID_ARG;
   if ((Ho - 1) * stride + k > H || (Wo - 1) * stride + k > W) return MBX_ERR_INVALID_ARG;   // VALID only
   MBX_ENTER();
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
-                     (cus)x, (long long)xs, ldx, N, H, W, C, k, stride, (us)y, (long long)ys, ldy, Ho, Wo, argmax);
+  if (k == 3 && stride == 2)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<3, 2>), dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                       (cus)x, (long long)xs, ldx, N, H, W, C, k, stride, (us)y, (long long)ys, ldy, Ho, Wo, argmax);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<0, 0>), dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                       (cus)x, (long long)xs, ldx, N, H, W, C, k, stride, (us)y, (long long)ys, ldy, Ho, Wo, argmax);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -981,9 +1049,14 @@ extern "C" int mbx_maxpool_bwd(const void* dy, int64_t dys, int ld_dy, const uin
                                mbx_stream_t stream) {
   if (!pool_args_ok(dy, ld_dy, dx, ld_dx, N, H, W, C, k, Ho, Wo) || !argmax || stride < 1) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 8))), dim3(kT), 0, mbx_s(stream),
-                     (cus)dy, (long long)dys, ld_dy, argmax, N, H, W, C, k, stride, Ho, Wo, (us)dx, (long long)dxs, ld_dx,
-                     accumulate);
+  if (k == 3 && stride == 2)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2>), dim3(grid_for((long long)N * H * W * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                       (cus)dy, (long long)dys, ld_dy, argmax, N, H, W, C, k, stride, Ho, Wo, (us)dx, (long long)dxs, ld_dx,
+                       accumulate);
+  else
+    hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0>), dim3(grid_for((long long)N * H * W * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                       (cus)dy, (long long)dys, ld_dy, argmax, N, H, W, C, k, stride, Ho, Wo, (us)dx, (long long)dxs, ld_dx,
+                       accumulate);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

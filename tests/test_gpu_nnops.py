@@ -167,32 +167,33 @@ def test_bn_fold(T):
     assert torch.allclose(sc.cpu(), s, rtol=1e-5) and torch.allclose(sh.cpu(), beta - mm * s, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("N,H,W,Cc", [(2, 35, 35, 64), (1, 17, 17, 1088), (3, 9, 9, 8)])
-def test_maxpool(T, N, H, W, Cc):
+@pytest.mark.parametrize("N,H,W,Cc,k,st", [(2, 35, 35, 64, 3, 2), (1, 17, 17, 1088, 3, 2), (3, 9, 9, 8, 3, 2),
+                                            (2, 12, 13, 16, 2, 2), (1, 11, 11, 24, 3, 1)])   # last two: run-time window
+def test_maxpool(T, N, H, W, Cc, k, st):
     torch = T
     import torch.nn.functional as F
     from multibox_amd import _lib, ops
     l = _lib.lib()
     gen = torch.Generator().manual_seed(H)
     x = bfr(torch, torch.relu(torch.randn(N, H, W, Cc, generator=gen)))      # many exact ties at 0
-    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
     xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
-    yr, idx = F.max_pool2d(xr, 3, 2, return_indices=True)
+    yr, idx = F.max_pool2d(xr, k, st, return_indices=True)
     xv = ops.View.alloc(N, H, W, Cc + 8, zero=True).slice(0, Cc)
     xv.tensor().copy_(x.to(torch.bfloat16))
     yv = ops.View.alloc(N, Ho, Wo, Cc + 8, zero=True).slice(8, Cc)
     am = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device="cuda")
-    _lib.check(l.mbx_maxpool_fwd(xv.ptr, xv.img_stride, xv.ld, N, H, W, Cc, 3, 2, yv.ptr, yv.img_stride, yv.ld, Ho, Wo, am.data_ptr(), S()))
+    _lib.check(l.mbx_maxpool_fwd(xv.ptr, xv.img_stride, xv.ld, N, H, W, Cc, k, st, yv.ptr, yv.img_stride, yv.ld, Ho, Wo, am.data_ptr(), S()))
     assert torch.equal(yv.tensor().float().cpu(), yr.detach().permute(0, 2, 3, 1))
     dy = bfr(torch, torch.randn(N, Ho, Wo, Cc, generator=gen))
     yr.backward(dy.permute(0, 3, 1, 2))
     dyv = ops.View.alloc(N, Ho, Wo, Cc)
     dyv.tensor().copy_(dy.to(torch.bfloat16))
     dxv = ops.View.alloc(N, H, W, Cc, zero=True)
-    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, 3, 2, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 0, S()))
+    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, k, st, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 0, S()))
     ok, msg = close_bf16(dxv.tensor(), xr.grad.permute(0, 2, 3, 1))      # first-maximum routing, like torch/TF
     assert ok, msg
-    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, 3, 2, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 1, S()))
+    _lib.check(l.mbx_maxpool_bwd(dyv.ptr, dyv.img_stride, dyv.ld, am.data_ptr(), N, H, W, Cc, k, st, Ho, Wo, dxv.ptr, dxv.img_stride, dxv.ld, 1, S()))
     ok, msg = close_bf16(dxv.tensor(), 2 * xr.grad.permute(0, 2, 3, 1))
     assert ok, "accumulate: " + msg
 
