@@ -21,7 +21,9 @@ SHAPES = [
     ("b8_fused_1x1_2080_384", 8, 8, 2080, 384, 1, 1, 1, (0, 0), 10),
     ("b8_1x3_192_224", 8, 8, 192, 224, 1, 3, 1, (0, 1), 10),
     ("b8_up_1x1_448_2080", 8, 8, 448, 2080, 1, 1, 1, (0, 0), 10),
+    ("stem_3x3_32_32_149", 149, 149, 32, 32, 3, 3, 1, (0, 0), 1),
     ("stem_3x3_32_64_147", 147, 147, 32, 64, 3, 3, 1, (1, 1), 1),
+    ("b35_3x3_32_48", 35, 35, 32, 48, 3, 3, 1, (1, 1), 10),
     ("stem_3x3_80_192_73", 73, 73, 80, 192, 3, 3, 1, (0, 0), 1),
     ("m6a_3x3s2_320_384", 35, 35, 320, 384, 3, 3, 2, (0, 0), 1),
     ("m6a_3x3_256_256", 35, 35, 256, 256, 3, 3, 1, (1, 1), 1),
@@ -59,7 +61,9 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
     wT = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
     flops = 2.0 * B * Ho * Wo * Co * R * S * Ci
+    kb_cfg = int(os.environ.get("KB_CFG", "0"))      # mbx_conv_desc.tile_config of the forward / data-gradient launches
     d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y)
+    d_f.tile_config = kb_cfg
     rows = ops.conv_stats_rows(d_f)
     stats = torch.zeros((rows, Co, 2), device="cuda")
     d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, stats=stats)
@@ -71,6 +75,7 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
         d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=bias, skip=skip, rscale=0.1)
         act = ops.View.alloc(B, H, W, Ci); act.buf.normal_()         # data gradient: accumulate + relu mask
         d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1, accumulate=1, skip=act)
+    d_f.tile_config = kb_cfg; d_d.tile_config = kb_cfg
     tf = timeit(lambda: ops.conv(d_f))
     td = timeit(lambda: ops.conv(d_d))
     tw = timeit(lambda: ops.conv_wgrad(d_w, dy, dw))
