@@ -41,6 +41,10 @@ const char* mbx_status_string(int status);
  * `grids` generalises the hard-coded [8,6,4,3,2,1] (priors.py:196); a grid of 1 gets
  * the single aspect-1 box (priors.py:206-258).  out = [rows,4] x1,y1,x2,y2.          */
 int mbx_priors_count(int k, const int* grids, int n_grids);
+
+/* CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 first): the checksum of TFRecord frames
+ * (inputs.py:225-247 reads them with tf.TFRecordReader) and of TF checkpoint table blocks (train.py:15-90). Host code. */
+uint32_t mbx_crc32c(const void* data, uint64_t n, uint32_t crc);
 int mbx_generate_priors(const double* aspect_ratios, int k, double min_scale, double max_scale,
                         int restrict_to_image_bounds, const int* grids, int n_grids,
                         double* out /*HOST [rows,4]*/);

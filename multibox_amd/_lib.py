@@ -30,6 +30,7 @@ _SIGS = {
     "mbx_version": (I, []),
     "mbx_status_string": (C.c_char_p, [I]),
     "mbx_priors_count": (I, [I, P, I]),
+    "mbx_crc32c": (C.c_uint32, [P, C.c_uint64, C.c_uint32]),
     "mbx_generate_priors": (I, [P, I, D, D, I, P, I, P]),
     "mbx_decode_conf": (I, [P, P, P, I, I, F, P, P, P]),
     "mbx_match_workspace_bytes": (SZ, [I, I, I]),

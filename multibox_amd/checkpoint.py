@@ -2,7 +2,7 @@
 (train.py:282-286) and inference restores the EMA shadows into the live variables
 (detect.py:336-346).  Here: one .pt file `model.ckpt-<global_step>.pt` holding the flat
 buffers (weights, betas, moving statistics, RMSProp slots, EMA shadows, step) plus the
-name index, so a TF checkpoint importer can fill the same structure later."""
+name index; TensorFlow V1 checkpoints are read by multibox_amd/tf_checkpoint.py into the same structure."""
 import glob
 import os
 import re
@@ -32,16 +32,58 @@ def _step_of(path):
 
 
 def latest_checkpoint(path):
-    """tf.train.latest_checkpoint analogue: a file, or the newest model.ckpt-*.pt of a directory."""
+    """tf.train.latest_checkpoint analogue: a file, or the newest model.ckpt-*.pt of a directory -- or, in a directory
+    written by TensorFlow, the file its `checkpoint` state file names (model_checkpoint_path: "...")."""
     if os.path.isdir(path):
         c = sorted(glob.glob(os.path.join(path, "model.ckpt-*.pt")), key=_step_of)
-        return c[-1] if c else None
+        if c:
+            return c[-1]
+        state = os.path.join(path, "checkpoint")
+        if os.path.exists(state):
+            m = re.search(r'^model_checkpoint_path:\s*"([^"]+)"', open(state).read(), re.M)
+            if m:
+                cand = m.group(1) if os.path.isabs(m.group(1)) else os.path.join(path, m.group(1))
+                return cand if os.path.exists(cand) else None
+        return None
     return path if os.path.exists(path) else None
+
+
+def is_tf_checkpoint(path):
+    """A TensorFlow V1 checkpoint table (tf.train.Saver of TF <= 0.11): recognised by the table magic."""
+    from . import tf_checkpoint as TF
+    try:
+        with open(path, "rb") as f:
+            f.seek(-8, os.SEEK_END)
+            return int.from_bytes(f.read(8), "little") == TF.MAGIC
+    except OSError:
+        return False
 
 
 def global_step_of(path):
     """detect.py:383: the global step is parsed from the checkpoint file name."""
-    return _step_of(path)
+    m = re.search(r"-(\d+)(\.pt)?$", path)
+    return int(m.group(1)) if m else -1
+
+
+def restore_pretrained(path, trainer, fine_tune=False, use_moving_averages=False, restore_moving_averages=False):
+    """train.py:15-90 (get_init_function): initialise from --pretrained_model.  A TensorFlow checkpoint goes through
+    multibox_amd.tf_checkpoint with the reference's three switches; one of this build's own .pt files restores
+    everything it holds (variables, slots, shadows)."""
+    ck = latest_checkpoint(path)
+    if ck is None:
+        raise FileNotFoundError("no checkpoint found at %s" % path)
+    if is_tf_checkpoint(ck):
+        from . import tf_checkpoint as TF
+        net = trainer.net
+        TF.restore(ck, net, fine_tune=fine_tune, use_moving_averages=use_moving_averages,
+                   restore_moving_averages=restore_moving_averages, ema=trainer)
+        net.refresh_bf16()
+        if net.fine_tune:
+            net.fold_bn()
+    else:
+        restore_for_training(ck, trainer)
+    trainer.global_step = 0
+    return ck
 
 
 def restore_for_training(path, trainer):
@@ -60,6 +102,12 @@ def restore_for_training(path, trainer):
 
 def restore_for_inference(path, net, use_moving_averages=True):
     """detect.py:336-346: live variables <- EMA shadows."""
+    if is_tf_checkpoint(path):
+        from . import tf_checkpoint as TF
+        step = TF.restore_for_inference(path, net, use_moving_averages=use_moving_averages)
+        net.Wb.copy_(net.W.to(torch.bfloat16))
+        net.fold_bn()
+        return step if step else max(global_step_of(path), 0)
     st = torch.load(path, map_location="cpu")
     assert st["W"].numel() == net.nW and st["k"] == net.k, "checkpoint does not match the network"
     sfx = "ema" if use_moving_averages else ""

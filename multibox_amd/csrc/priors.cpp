@@ -1,5 +1,6 @@
 // HOST: prior box generation, float64, bit-exact with priors.generate_priors
 // (reference priors.py:185-314).  Build with -ffp-contract=off.
+#include <cstdint>
 #include <cmath>
 #include <algorithm>
 #include "../../include/mbx.h"
@@ -54,6 +55,33 @@ extern "C" int mbx_generate_priors(const double* ars, int k, double min_scale, d
       }
   }
   return MBX_OK;
+}
+
+// CRC-32C (Castagnoli), slice-by-8: the checksum of TFRecord frames and of TensorFlow checkpoint table blocks
+// (multibox_amd/tfrecord.py, tf_checkpoint.py).  Host code; `crc` chains calls (0 for the first).
+extern "C" uint32_t mbx_crc32c(const void* data, uint64_t n, uint32_t crc) {
+  static uint32_t T[8][256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+    init = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    const uint32_t lo = c ^ ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+    c = T[7][lo & 0xff] ^ T[6][(lo >> 8) & 0xff] ^ T[5][(lo >> 16) & 0xff] ^ T[4][lo >> 24] ^
+        T[3][p[4]] ^ T[2][p[5]] ^ T[1][p[6]] ^ T[0][p[7]];
+    p += 8; n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return ~c;
 }
 
 extern "C" int mbx_version(void) { return 100; }

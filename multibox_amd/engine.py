@@ -13,7 +13,7 @@ Design (MI355X-first, not a tracing compiler):
     handful of contiguous buckets.
 
 Variable names follow the slim scopes of the reference (model.py:87,142,202,207) so that a
-TF checkpoint can be mapped later.
+TF checkpoint maps onto them (multibox_amd/tf_checkpoint.py).
 """
 from __future__ import annotations
 

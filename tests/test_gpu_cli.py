@@ -63,6 +63,28 @@ def test_train_then_detect(tmp_path):
         per_image.setdefault(x["image_id"], []).append(x["score"])
     assert len(per_image) == 8 and all(len(v) <= 200 for v in per_image.values())
     assert all(v == sorted(v, reverse=True) for v in per_image.values())    # detect.py:423 sort by confidence
+    # the same checkpoint as a TensorFlow V1 table (slim names, HWIO filters, EMA shadows) gives the same
+    # detections through detect.py (detect.py:336-346 restores the shadows), and initialises train.py
+    # --pretrained_model --fine_tune (train.py:15-90)
+    tfck = tmp_path / "tf" / "model.ckpt-4"
+    os.makedirs(tmp_path / "tf")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_checkpoint.py"), str(logdir), str(tfck)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    (tmp_path / "tf" / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-4"\nall_model_checkpoint_paths: "model.ckpt-4"\n')
+    out2 = tmp_path / "out_tf"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "detect.py"), "--priors", str(pri), "--checkpoint_path", str(tmp_path / "tf"),
+                        "--config", str(cfg), "--save_dir", str(out2), "--synthetic", "8", "--max_iterations", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.load(open(out2 / "results-dense-4.json")) == res
+    log2 = tmp_path / "log_ft"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(log2),
+                        "--config", str(cfg), "--max_number_of_steps", "1", "--synthetic", "--fine_tune",
+                        "--pretrained_model", str(tfck), "--use_moving_averages", "--restore_moving_averages"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "Initialised from" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(log2 / "model.ckpt-1.pt")
 
 
 def test_detect_from_tfrecords(tmp_path):

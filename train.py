@@ -6,7 +6,7 @@ for data parallelism).
 `--tfrecords` reads the reference's TFRecords (inputs.py:225-247) through multibox_amd/inputs.py WITHOUT the
 random augmentations (set DO_RANDOM_BBOX_SHIFT / DO_RANDOM_CROP / DO_COLOR_DISTORTION to 0; the seeded flip is
 supported) -- SURVEY 8f F1, first cut; `--synthetic` feeds seeded synthetic batches of the same input contract
-(inputs.py:340-351).  Not yet wired: --pretrained_model import of TF checkpoints (F2)."""
+(inputs.py:340-351).  --pretrained_model takes one of this build's .pt files or a TensorFlow V1 checkpoint (multibox_amd/tf_checkpoint.py, F2)."""
 import argparse
 import json
 import os
@@ -83,13 +83,16 @@ def main():
                  rmsprop_decay=cfg.RMSPROP_DECAY, rmsprop_momentum=float(cfg.RMSPROP_MOMENTUM), rmsprop_epsilon=cfg.RMSPROP_EPSILON,
                  moving_average_decay=cfg.MOVING_AVERAGE_DECAY, process_group=pg)
     latest = CK.latest_checkpoint(args.logdir)                    # slim.learning.train resumes from logdir
-    if latest:
+    if latest and latest.endswith(".pt"):
         CK.restore_for_training(latest, tr)
         if rank == 0:
             print("Resumed from %s (step %d)" % (latest, tr.global_step))
     elif args.pretrained_model:
-        CK.restore_for_training(CK.latest_checkpoint(args.pretrained_model), tr)
-        tr.global_step = 0
+        ck = CK.restore_pretrained(args.pretrained_model, tr, fine_tune=args.fine_tune,            # train.py:15-90
+                                   use_moving_averages=args.use_moving_averages,
+                                   restore_moving_averages=args.restore_moving_averages)
+        if rank == 0:
+            print("Initialised from %s" % ck)
     t_save = t_log = time.time()
     log = open(os.path.join(args.logdir, "train_log.jsonl"), "a") if rank == 0 and (os.makedirs(args.logdir, exist_ok=True) or True) else None
     step0 = tr.global_step
