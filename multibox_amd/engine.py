@@ -76,6 +76,7 @@ class Net:
         self.repeats = tuple(repeats)
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
+        self.tune_registry = []                    # (key, descriptor, fwd | dgrad | wgrad) of every tunable conv launch
         self.no_onepass = bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
@@ -455,9 +456,10 @@ class Net:
 
     def _tune(self, op, d, what):
         """Pick the tile configuration of one conv launch by measurement (ops.autotune); a no-op on CPU."""
+        key = (what, op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, d.C_out, d.C_in,
+               d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip), d.relu)
+        self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
-            key = (what, op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, d.C_out, d.C_in,
-                   d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip), d.relu)
             ops.autotune(d, key)
         return d
 
@@ -639,10 +641,11 @@ class Net:
                                       rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None))
                 self._tune(op, ddesc, "dgrad")
 
+            wkey = ("wgrad", op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
+                    dyv.ld, db is not None)
+            self.tune_registry.append((repr(wkey), wdesc, "wgrad"))
             if self.autotune and int(os.environ.get("MBX_AUTOTUNE_WGRAD", "1")):
-                ops.autotune_wgrad(wdesc, dyv, scale, dw, db,
-                                   ("wgrad", op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
-                                    dyv.ld, db is not None))
+                ops.autotune_wgrad(wdesc, dyv, scale, dw, db, wkey)
 
             def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
                 s = st()
