@@ -7,7 +7,7 @@ eager step (forward + loss + backward, Trainer.run_eager_once) once per candidat
 every launch -- the GPU parked behind a spin kernel while the host queues the step, as in bench.py -- and keeps, per
 distinct layer shape (the cache key), the configuration with the smallest summed time.
 
-usage: python tools/tune_in_situ.py [--batch 64] [--input-size 299] [--k 5] [--fine-tune] [--repeats 5] [--out FILE]
+usage: python tools/tune_in_situ.py [--batch 64] [--input-size 299] [--k 5] [--fine-tune] [--repeats 5] [--all] [--out FILE]
 """
 import argparse
 import ctypes as C
@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--fine-tune", action="store_true")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--threshold", type=float, default=0.02, help="a challenger must beat the current choice by this fraction")
+    ap.add_argument("--all", action="store_true", help="try every tile configuration, not only the ones that won before")
     ap.add_argument("--out", default=None, help="cache file to write (default: the package's tune_cache.json)")
     args = ap.parse_args()
     import numpy as np
@@ -50,6 +51,8 @@ def main():
         tr.step()
     torch.cuda.synchronize()
 
+    conv_cands = tuple(range(1, ops.N_TILE_CONFIGS + 1)) if args.all else CONV_CANDIDATES
+    wgrad_cands = tuple(range(1, 11)) if args.all else WGRAD_CANDIDATES
     l = _lib.lib()
     by_addr = {C.addressof(d): (key, d, what) for key, d, what in net.tune_registry}
     tuned = {C.addressof(d): d.tile_config for _, d, _ in net.tune_registry}
@@ -109,9 +112,9 @@ def main():
     try:
         for rep in range(args.repeats):
             one_pass(None, None)                              # the current choices (every launch)
-            for c in CONV_CANDIDATES:
+            for c in conv_cands:
                 one_pass("conv", c)
-            for c in WGRAD_CANDIDATES:
+            for c in wgrad_cands:
                 one_pass("wgrad", c)
     finally:
         l.mbx_conv, l.mbx_conv_wgrad_scaled, l.mbx_bn_apply_fused = orig_conv, orig_wg, orig_bn
@@ -122,7 +125,7 @@ def main():
     changed, gain = 0, 0.0
     for key, per_cfg in times.items():
         cur = cur_of[key]
-        allowed = WGRAD_CANDIDATES if what_of[key] == "wgrad" else CONV_CANDIDATES
+        allowed = wgrad_cands if what_of[key] == "wgrad" else conv_cands
         # passes of the OTHER kind also ran this launch with its current choice: they all count for `cur`
         t_cur = med(per_cfg[cur])
         best, t_best = cur, t_cur
