@@ -7,7 +7,7 @@ eager step (forward + loss + backward, Trainer.run_eager_once) once per candidat
 every launch -- the GPU parked behind a spin kernel while the host queues the step, as in bench.py -- and keeps, per
 distinct layer shape (the cache key), the configuration with the smallest summed time.
 
-usage: python tools/tune_in_situ.py [--batch 64] [--input-size 299] [--k 5] [--fine-tune] [--repeats 5] [--all] [--out FILE]
+usage: python tools/tune_in_situ.py [--batch 64] [--input-size 299] [--k 5] [--fine-tune | --infer] [--repeats 5] [--all] [--out FILE]
 """
 import argparse
 import ctypes as C
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--max-num-bboxes", type=int, default=13)
     ap.add_argument("--fine-tune", action="store_true")
+    ap.add_argument("--infer", action="store_true", help="the detect path: inference-mode forward only (BATCH_SIZE patches)")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--threshold", type=float, default=0.02, help="a challenger must beat the current choice by this fraction")
     ap.add_argument("--all", action="store_true", help="try every tile configuration, not only the ones that won before")
@@ -42,13 +43,21 @@ def main():
     from multibox_amd.trainer import Trainer
     from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
 
-    net = Net(batch=args.batch, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2)
-    pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[args.k], args.input_size).astype(np.float32)
-    tr = Trainer(net, pri, max_num_bboxes=args.max_num_bboxes, location_loss_alpha=1000.0, use_graph=False)
-    images, gt, n = synthetic_batch(args.batch, args.input_size, args.max_num_bboxes, seed=0)
-    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
-    for _ in range(2):
-        tr.step()
+    if args.infer:
+        net = Net(batch=args.batch, input_size=args.input_size, k=args.k, mode="infer")
+        net.fold_bn()
+        net.set_input(torch.rand(args.batch, args.input_size, args.input_size, 3, device="cuda") * 2 - 1)
+        run_step = net.forward
+    else:
+        net = Net(batch=args.batch, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2)
+        pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[args.k], args.input_size).astype(np.float32)
+        tr = Trainer(net, pri, max_num_bboxes=args.max_num_bboxes, location_loss_alpha=1000.0, use_graph=False)
+        images, gt, n = synthetic_batch(args.batch, args.input_size, args.max_num_bboxes, seed=0)
+        tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+        for _ in range(2):
+            tr.step()
+        run_step = tr.run_eager_once
+    run_step()
     torch.cuda.synchronize()
 
     conv_cands = tuple(range(1, ops.N_TILE_CONFIGS + 1)) if args.all else CONV_CANDIDATES
@@ -100,7 +109,7 @@ def main():
         state.update(cand=cand, kind=kind, rows=None, recs=[])
         torch.cuda.synchronize()
         torch.cuda._sleep(int(100e-3 * 2.0e9))
-        tr.run_eager_once()
+        run_step()
         torch.cuda.synchronize()
         acc = {}
         for key, cfg, a, b in state["recs"]:
