@@ -148,7 +148,7 @@ class Net:
         self.conv([(P + "Conv2d_2b_3x3", 64)], a2, a3, 3, 3, 1, "SAME")
         s3, _ = _valid(s2, 3, 2)
         p3 = self.alloc(s3, s3, 64)
-        self.pool("max", a3, p3, 3, 2)
+        self.pool("max", a3, p3, 3, 2, scope=P + "MaxPool_3a_3x3")
         a4 = self.alloc(s3, s3, 80)
         self.conv([(P + "Conv2d_3b_1x1", 80)], p3, a4, 1, 1, 1, "VALID")
         s4 = s3 - 2
@@ -156,7 +156,7 @@ class Net:
         self.conv([(P + "Conv2d_4a_3x3", 192)], a4, a5, 3, 3, 1, "VALID")
         s5, _ = _valid(s4, 3, 2)
         t5 = self.alloc(s5, s5, 192)
-        self.pool("max", a5, t5, 3, 2)
+        self.pool("max", a5, t5, 3, 2, scope=P + "MaxPool_5a_3x3")
 
         # ---- Mixed_5b (model.py:120-141): [t1 48 | t2 64 | b0 96 | b1 64 | b2 96 | b3 64 | t2b 96]
         Q = P + "Mixed_5b/"
@@ -167,7 +167,7 @@ class Net:
         self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 96)], z.slice(48, 64), z.slice(432, 96), 3, 3)
         self.conv([(Q + "Branch_2/Conv2d_0c_3x3", 96)], z.slice(432, 96), z.slice(272, 96), 3, 3)
         p5 = self.alloc(s5, s5, 192)
-        self.pool("avg", t5, p5, 3, 1, pad=1)
+        self.pool("avg", t5, p5, 3, 1, pad=1, scope=Q + "Branch_3/AvgPool_0a_3x3")
         self.conv([(Q + "Branch_3/Conv2d_0b_1x1", 64)], p5, z.slice(368, 64), 1, 1)
         net = z.slice(112, 320)
         self.endpoints = {"MaxPool_5a_3x3": t5, "Mixed_5b": net}
@@ -201,7 +201,7 @@ class Net:
         t6b = self.alloc(s5, s5, 256)
         self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 256)], t6a, t6b, 3, 3)
         self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 384)], t6b, o6.slice(384, 384), 3, 3, 2, "VALID")
-        self.pool("max", net, o6.slice(768, 320), 3, 2)
+        self.pool("max", net, o6.slice(768, 320), 3, 2, scope=Q + "Branch_2/MaxPool_1a_3x3")
         self.endpoints["block35_10"] = net
         net = o6
         self.endpoints["Mixed_6a"] = net
@@ -233,7 +233,7 @@ class Net:
         self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 288)], t7.slice(256, 256), o7.slice(384, 288), 3, 3, 2, "VALID")
         self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 288)], t7.slice(512, 256), t7.slice(768, 288), 3, 3)
         self.conv([(Q + "Branch_2/Conv2d_1a_3x3", 320)], t7.slice(768, 288), o7.slice(672, 320), 3, 3, 2, "VALID")
-        self.pool("max", net, o7.slice(992, 1088), 3, 2)
+        self.pool("max", net, o7.slice(992, 1088), 3, 2, scope=Q + "Branch_3/MaxPool_1a_3x3")
         self.endpoints["block17_20"] = net
         net = o7
         self.endpoints["Mixed_7a"] = net
@@ -288,7 +288,7 @@ class Net:
         grids.append((H + "2x2/", h2, f4 - 2, k))
         f1 = f - 7
         g1 = self.alloc(f1, f1, 1536)
-        self.pool("avg", feat, g1, 8, 1, pad=0)
+        self.pool("avg", feat, g1, 8, 1, pad=0, scope=H + "1x1/AvgPool2D")
         grids.append((H + "1x1/", g1, f1, 1))
         # prediction index: off_g + (i*g + j)*k + a  (model.py:296-319)
         self.head_ld = max(8, (5 * k + 7) // 8 * 8)       # 5k head channels padded to 8 (k=5: 32, k=7: 40)
@@ -318,8 +318,10 @@ class Net:
         op.trunk0 = trunk0
         return op
 
-    def pool(self, kind, x, out, ksz, stride, pad=0):
-        self.fwd.append(PoolOp(self, kind, x, out, ksz, stride, pad))
+    def pool(self, kind, x, out, ksz, stride, pad=0, scope=None):
+        op = PoolOp(self, kind, x, out, ksz, stride, pad)
+        op.scope = scope          # slim scope of the pooling layer (model.py), for the layer-table parity test
+        self.fwd.append(op)
 
     # ------------------------------------------------------------- parameters
     def _finalize(self, seed):
@@ -684,6 +686,48 @@ class Net:
         for f in self.fwd_launches:
             f()
         return self.locs, self.logits
+
+    def layer_table(self):
+        """The network as the reference states it (model.py:6-337): one entry per slim.conv2d / pool in forward
+        order, fused sibling launches expanded into their members, inputs resolved to the scopes that produced the
+        channels read.  tests/test_model_graph.py compares it with the table generated from the reference's source."""
+        writers = {}                       # id(buffer) -> [(ch_lo, ch_hi, scope)] latest writer per channel range
+
+        def record(v: View, scope):
+            lst = [w for w in writers.get(id(v.buf), []) if w[1] <= v.ch_off or w[0] >= v.ch_off + v.C]
+            lst.append((v.ch_off, v.ch_off + v.C, scope))
+            writers[id(v.buf)] = lst
+
+        def producers(v: View):
+            if v.buf is self.images.buf:
+                return ["inputs"]
+            inside = sorted(w for w in writers.get(id(v.buf), []) if w[0] >= v.ch_off and w[1] <= v.ch_off + v.C)
+            assert inside and inside[0][0] == v.ch_off and inside[-1][1] == v.ch_off + v.C and \
+                all(a[1] == b[0] for a, b in zip(inside, inside[1:])), "input view is not tiled by earlier outputs"
+            return [w[2] for w in inside]
+
+        table = []
+        for op in self.fwd:
+            if isinstance(op, PoolOp):
+                table.append({"scope": op.scope, "op": op.kind + "_pool2d", "in_channels": op.x.C, "out_channels": op.out.C,
+                              "kernel": [op.k, op.k], "stride": op.stride, "pad": [op.pad, op.pad],
+                              "out_hw": [op.out.H, op.out.W], "inputs": producers(op.x)})
+                record(op.out, op.scope)
+                continue
+            ins = producers(op.x)
+            off = 0
+            for m in op.members:
+                e = {"scope": m.scope, "op": "conv2d", "in_channels": 3 if op.x.buf is self.images.buf else op.Cin,
+                     "out_channels": m.K, "kernel": [op.R, op.S], "stride": op.stride, "pad": [op.pad_t, op.pad_l],
+                     "out_hw": [op.out.H, op.out.W], "inputs": ins, "bn": op.kind in ("bn", "frozen"),
+                     "bias": op.kind == "residual", "activation": "relu" if (op.relu and op.kind != "residual") else None}
+                if op.kind == "residual":
+                    e["residual"] = {"scale": op.rscale, "skip": producers(op.skip), "activation": "relu" if op.relu else None}
+                table.append(e)
+                if op.kind != "head":
+                    record(op.out.slice(off, m.K), m.scope)
+                off += m.K
+        return table
 
     def flops_per_image(self, train=True):
         """Algorithmic FLOPs per image (2 per multiply-add) of the convolutions (SURVEY 8(d) convention): forward

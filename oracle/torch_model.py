@@ -4,8 +4,11 @@ Follows /root/reference/model.py:6-337 layer by layer (block35/17/8, inception_r
 build_detection_heads) with the slim/TF-0.11 semantics the reference relies on but does not
 vendor: 'SAME' padding puts the odd pixel at the bottom/right, avg_pool SAME divides by the
 number of valid taps, batch_norm has beta only (scale=False), epsilon 0.001, biased batch
-variance (train.py:94-99).  "parity unpinned" against TF itself (TF 0.11 cannot run here);
-pinned structurally: 646/904 predictions, parameter counts, head flatten order.
+variance (train.py:94-99).  The GRAPH is pinned: tests/golden/model_graph.json is generated from the reference's
+model.py by tools/gen_model_graph.py (AST walk) and tests/test_model_graph.py checks this model's execution trace
+against it layer by layer (scope, channels, kernel, stride, padding, BN / bias / activation, residual scale,
+input tensors, head flatten order).  The NUMERICS of conv / BN / pool are TF-0.11's (un-vendored, cannot run
+here): "parity unpinned" against TF itself for those.
 
 Parameters come in a dict keyed by the slim variable names (".../weights" KRSC float32,
 ".../biases", ".../BatchNorm/beta|moving_mean|moving_variance").  ``q`` optionally rounds
@@ -22,6 +25,16 @@ BN_EPS = 0.001
 def q_bf16(t):
     """Round to bf16 with a straight-through gradient."""
     return t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+
+
+def _tag(t, prov):
+    """Provenance for the layer-table parity test: which layer scopes produced the channels of t, in order."""
+    t._prov = list(prov)
+    return t
+
+
+def _prov(t):
+    return list(getattr(t, "_prov", ["?"]))
 
 
 def _same(n, k, s):
@@ -41,12 +54,17 @@ class Model:
         self.new_moving = {}
         self.endpoints = {}
         self._in_heads = False
+        self.trace = []                     # one entry per conv / pool executed, in order (tests/test_model_graph.py)
 
     # slim.conv2d (+ batch_norm + relu)
     def conv(self, x, scope, ksize, stride=1, padding="SAME", bn=True, relu=True, bias=False):
         w = self.P[scope + "/weights"]                       # [K,R,S,C]
         kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
         assert w.shape[1:3] == (kh, kw), (scope, w.shape)
+        entry = {"scope": scope, "op": "conv2d", "in_channels": int(x.shape[1]), "out_channels": int(w.shape[0]),
+                 "kernel": [kh, kw], "stride": stride, "padding": padding, "inputs": _prov(x), "bn": bool(bn),
+                 "bias": bool(bias), "activation": "relu" if relu else None}
+        self.trace.append(entry)
         if padding == "SAME":
             pt, pb = _same(x.shape[2], kh, stride)
             pl, pr = _same(x.shape[3], kw, stride)
@@ -71,7 +89,29 @@ class Model:
             y = torch.relu(y)
         if bn:
             y = self.q(y)
-        return y
+        entry["out_hw"] = [int(y.shape[2]), int(y.shape[3])]
+        return _tag(y, [scope])
+
+    def cat(self, ts):
+        """tf.concat(3, ...) of model.py (channel axis)."""
+        return _tag(torch.cat(ts, 1), sum((_prov(t) for t in ts), []))
+
+    def max_pool(self, x, scope, k=3, stride=2):
+        """slim.max_pool2d(k, stride, VALID)."""
+        y = F.max_pool2d(x, k, stride)
+        self.trace.append({"scope": scope, "op": "max_pool2d", "in_channels": int(x.shape[1]), "out_channels": int(y.shape[1]),
+                           "kernel": [k, k], "stride": stride, "padding": "VALID", "inputs": _prov(x),
+                           "out_hw": [int(y.shape[2]), int(y.shape[3])]})
+        return _tag(y, [scope])
+
+    def avg_pool(self, x, scope, k, padding):
+        """slim.avg_pool2d(k, stride 1): SAME divides by the number of valid taps (model.py:134), VALID model.py:285."""
+        y = F.avg_pool2d(x, k, 1, k // 2, count_include_pad=False) if padding == "SAME" else F.avg_pool2d(x, k, 1)
+        y = self.q(y)
+        self.trace.append({"scope": scope, "op": "avg_pool2d", "in_channels": int(x.shape[1]), "out_channels": int(y.shape[1]),
+                           "kernel": [k, k], "stride": 1, "padding": padding, "inputs": _prov(x),
+                           "out_hw": [int(y.shape[2]), int(y.shape[3])]})
+        return _tag(y, [scope])
 
     def block(self, net, s, scale, relu, kind):
         """model.py:6-63."""
@@ -80,26 +120,21 @@ class Model:
             b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
             b1 = c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_3x3", 3)
             b2 = c(c(c(net, s + "Branch_2/Conv2d_0a_1x1", 1), s + "Branch_2/Conv2d_0b_3x3", 3), s + "Branch_2/Conv2d_0c_3x3", 3)
-            mixed = torch.cat([b0, b1, b2], 1)
+            mixed = self.cat([b0, b1, b2])
         elif kind == 17:
             b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
             b1 = c(c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_1x7", (1, 7)), s + "Branch_1/Conv2d_0c_7x1", (7, 1))
-            mixed = torch.cat([b0, b1], 1)
+            mixed = self.cat([b0, b1])
         else:
             b0 = c(net, s + "Branch_0/Conv2d_1x1", 1)
             b1 = c(c(c(net, s + "Branch_1/Conv2d_0a_1x1", 1), s + "Branch_1/Conv2d_0b_1x3", (1, 3)), s + "Branch_1/Conv2d_0c_3x1", (3, 1))
-            mixed = torch.cat([b0, b1], 1)
+            mixed = self.cat([b0, b1])
         up = c(mixed, s + "Conv2d_1x1", 1, bn=False, relu=False, bias=True)
+        self.trace[-1]["residual"] = {"scale": scale, "skip": _prov(net), "activation": "relu" if relu else None}
         net = net + scale * up
         if relu:
             net = torch.relu(net)
-        return self.q(net)
-
-    @staticmethod
-    def avg_pool_same3(x):
-        """slim.avg_pool2d(3, stride 1, SAME): divisor = valid taps (model.py:134)."""
-        s = F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
-        return s
+        return _tag(self.q(net), [s + "Conv2d_1x1"])
 
     # The backbone in four stages (each also callable on its own for stage-wise gradient tests).
     def stem(self, x):
@@ -108,10 +143,10 @@ class Model:
         net = c(x, P + "Conv2d_1a_3x3", 3, 2, "VALID")
         net = c(net, P + "Conv2d_2a_3x3", 3, 1, "VALID")
         net = c(net, P + "Conv2d_2b_3x3", 3)
-        net = F.max_pool2d(net, 3, 2)
+        net = self.max_pool(net, P + "MaxPool_3a_3x3")
         net = c(net, P + "Conv2d_3b_1x1", 1, 1, "VALID")
         net = c(net, P + "Conv2d_4a_3x3", 3, 1, "VALID")
-        return F.max_pool2d(net, 3, 2)
+        return self.max_pool(net, P + "MaxPool_5a_3x3")
 
     def stage35(self, net):
         """model.py:120-142: Mixed_5b + block35 x repeats[0]."""
@@ -120,8 +155,8 @@ class Model:
         b0 = c(net, Q + "Branch_0/Conv2d_1x1", 1)
         b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_5x5", 5)
         b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_0c_3x3", 3)
-        b3 = c(self.q(self.avg_pool_same3(net)), Q + "Branch_3/Conv2d_0b_1x1", 1)
-        net = torch.cat([b0, b1, b2, b3], 1)
+        b3 = c(self.avg_pool(net, Q + "Branch_3/AvgPool_0a_3x3", 3, "SAME"), Q + "Branch_3/Conv2d_0b_1x1", 1)
+        net = self.cat([b0, b1, b2, b3])
         self.endpoints["Mixed_5b"] = net
         for i in range(1, self.repeats[0] + 1):
             net = self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)
@@ -133,7 +168,7 @@ class Model:
         Q = P + "Mixed_6a/"
         b0 = c(net, Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
         b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
-        net = torch.cat([b0, b1, F.max_pool2d(net, 3, 2)], 1)
+        net = self.cat([b0, b1, self.max_pool(net, Q + "Branch_2/MaxPool_1a_3x3")])
         self.endpoints["Mixed_6a"] = net
         for i in range(1, self.repeats[1] + 1):
             net = self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)
@@ -146,7 +181,7 @@ class Model:
         b0 = c(c(net, Q + "Branch_0/Conv2d_0a_1x1", 1), Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
         b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
         b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_1a_3x3", 3, 2, "VALID")
-        net = torch.cat([b0, b1, b2, F.max_pool2d(net, 3, 2)], 1)
+        net = self.cat([b0, b1, b2, self.max_pool(net, Q + "Branch_3/MaxPool_1a_3x3")])
         self.endpoints["Mixed_7a"] = net
         for i in range(1, self.repeats[2] + 1):
             net = self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)
@@ -183,7 +218,7 @@ class Model:
         locs.append(nhwc(out(b, H + "3x3/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "3x3/Conv_3", k)))
         b = c(c(net, H + "2x2/Conv", 1), H + "2x2/Conv_1", 3, 1, "VALID")
         locs.append(nhwc(out(b, H + "2x2/Conv_2", 4 * k))); confs.append(nhwc(out(b, H + "2x2/Conv_3", k)))
-        b = self.q(F.avg_pool2d(feat, 8, 1))
+        b = self.avg_pool(feat, H + "1x1/AvgPool2D", 8, "VALID")
         locs.append(nhwc(out(b, H + "1x1/Conv", 4))); confs.append(nhwc(out(b, H + "1x1/Conv_1", 1)))
         self._in_heads = False
         B = feat.shape[0]
@@ -191,7 +226,7 @@ class Model:
 
     def build(self, images_nhwc):
         """model.py:326-337: images [B,S,S,3] in [-1,1] -> (locations, logits); confidences = sigmoid(logits)."""
-        x = self.q(images_nhwc).permute(0, 3, 1, 2)
+        x = _tag(self.q(images_nhwc).permute(0, 3, 1, 2), ["inputs"])
         return self.heads(self.backbone(x))
 
 
