@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-detect", action="store_true", help="skip the detect leg (BASELINE config 4)")
+    ap.add_argument("--detect-batch", type=int, default=256)
+    ap.add_argument("--detect-steps", type=int, default=10)
     ap.add_argument("--log-losses", action="store_true", help="print the loss after every step to stderr (adds host syncs)")
     return ap.parse_args()
 
@@ -76,36 +79,61 @@ def cpu_baseline(net, priors, seconds):
                       "(oracle/cpu_train.py; TF 0.11 cannot run here)" % steps}
 
 
-def conv_roofline(tr):
-    """HIP events around every mbx_conv launch (forward + dgrad) of one eager step."""
+def _conv_flops(d):
+    if d.transposed:
+        return 2.0 * d.N * d.H_in * d.W_in * d.C_in * d.R * d.S * d.C_out
+    return 2.0 * d.N * d.H_out * d.W_out * d.C_out * d.R * d.S * d.C_in
+
+
+# entry point -> (kernel class, algorithmic work of one call).  MFMA classes count FLOPs, HBM classes bytes
+# (SURVEY 8d / DESIGN 4: bn apply reads y and writes a = 4 B per element; the one-launch bn backward reads da, y and
+# writes dy = 6 B; the three-launch form reads da, y twice = 10 B).
+def _work_table():
+    W = {}
+    W["mbx_conv"] = ("igemm", "mfma", lambda a: _conv_flops(a[0]._obj))
+    W["mbx_conv_wgrad_scaled"] = ("wgrad", "mfma", lambda a: _conv_flops(a[0]._obj))
+    W["mbx_conv_wgrad_grouped"] = ("wgrad", "mfma", lambda a: float(a[-1]))            # wrapped with its flops appended
+    W["mbx_bn_apply_fused"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[6] * a[7])
+    W["mbx_bn_bwd_onepass"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[4] * a[5])
+    W["mbx_bn_bwd_reduce"] = ("bn_bwd", "hbm", lambda a: 4.0 * a[6] * a[7])
+    W["mbx_bn_bwd_apply"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[6] * a[7])
+    W["mbx_bn_bwd_finalize"] = ("bn_bwd", "hbm", lambda a: 0.0)
+    return W
+
+
+def timed_eager_pass(run, entry_points=None):
+    """HIP events around every call of the listed libmbx entry points during run() (an eager pass on the current
+    stream), the GPU parked behind a spin kernel while the host queues ahead, the interval of an EMPTY event pair
+    subtracted.  Returns {class: dict(ms, work, calls, bound)}."""
     import torch
     from multibox_amd import _lib
     l = _lib.lib()
-    orig = l.mbx_conv
+    table = _work_table()
+    names = [n for n in (entry_points or table) if hasattr(l, n)]
     recs = []
+    orig = {n: getattr(l, n) for n in names}
 
-    def wrapped(desc_ref, stream):
-        d = desc_ref._obj
-        if d.transposed:
-            flops = 2.0 * d.N * d.H_in * d.W_in * d.C_in * d.R * d.S * d.C_out
-        else:
-            flops = 2.0 * d.N * d.H_out * d.W_out * d.C_out * d.R * d.S * d.C_in
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        r = orig(desc_ref, stream)
-        b.record()
-        recs.append((a, b, flops))
-        return r
-    l.mbx_conv = wrapped
+    def wrap(name):
+        cls, bound, work = table[name]
+        fn = orig[name]
+
+        def wrapped(*a):
+            a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            r = fn(*a)
+            b0.record()
+            recs.append((cls, bound, float(work(a)), a0, b0))
+            return r
+        return wrapped
+    for n in names:
+        setattr(l, n, wrap(n))
     try:
-        # Park the GPU behind a ~40 ms spin kernel while the host enqueues the step: otherwise the GPU idles inside every
+        # Park the GPU behind a ~40 ms spin kernel while the host enqueues the pass: otherwise the GPU idles inside every
         # event pair waiting for the next eager launch (host launch latency ~5 us per kernel) and the intervals read
         # 20-30 % longer than the kernels run (rocprofv3 kernel trace of the same step).
         torch.cuda.synchronize()
         torch.cuda._sleep(int(40e-3 * 2.0e9))
-        tr.run_eager_once()
-        # what an event pair reads with NOTHING between its two records, in the same queued-ahead regime (marker
-        # packets are not free): subtracted from every interval below
+        run()
         empty = []
         for _ in range(200):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -113,24 +141,146 @@ def conv_roofline(tr):
             empty.append((a, b))
         torch.cuda.synchronize()
     finally:
-        l.mbx_conv = orig
+        for n in names:
+            setattr(l, n, orig[n])
     pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
-    total_ms = sum(max(a.elapsed_time(b) - pair_ms, 0.0) for a, b, _ in recs)
-    total_flops = sum(f for _, _, f in recs)
-    n = len(recs)
-    achieved = total_flops / (total_ms * 1e-3) / 1e12
-    traffic, traffic_src = None, None
-    try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-        pj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
-        traffic = json.load(open(pj))["conv_igemm3_kernel"]["MB_per_launch"] * 1e6
-        traffic_src = "profiles/r01_hbm_traffic_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
-    except Exception:
-        pass
-    return {"bound": "mfma", "kernel": "conv_igemm3_kernel (forward + data-gradient launches)",
-            "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "launches_per_step": n, "avg_launch_us": round(1e3 * total_ms / n, 2), "event_pair_overhead_us": round(1e3 * pair_ms, 2),
-            "algorithmic_gflop_per_launch": round(total_flops / n / 1e9, 3)}
+    out = {}
+    for cls, bound, work, a, b in recs:
+        o = out.setdefault(cls, dict(ms=0.0, work=0.0, calls=0, bound=bound))
+        o["ms"] += max(a.elapsed_time(b) - pair_ms, 0.0)
+        o["work"] += work
+        o["calls"] += 1
+    return out, pair_ms
+
+
+def _file_sha(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- only if that profile
+    was taken on THIS kernel source (the file stamps the sha256 of csrc/conv.hip); a stale profile prints null."""
+    import glob
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(pj))
+            if j.get("conv_hip_sha") != _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", "conv.hip")):
+                continue
+            return j[kernel]["MB_per_launch"] * 1e6, os.path.relpath(pj, ROOT) + \
+                " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes; conv.hip sha matches)"
+        except Exception:
+            continue
+    return None, "no committed PMC profile matches the current csrc/conv.hip (sha %s)" % _file_sha(
+        os.path.join(ROOT, "multibox_amd", "csrc", "conv.hip"))
+
+
+def roofline_objects(classes, pair_ms, dominant="igemm"):
+    """(roofline of the dominant kernel, list of per-class rooflines) from timed_eager_pass()."""
+    kernels = []
+    for cls, o in sorted(classes.items()):
+        if o["ms"] <= 0 or o["work"] <= 0:
+            continue
+        if o["bound"] == "mfma":
+            ach, peak, unit = o["work"] / (o["ms"] * 1e-3) / 1e12, MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = o["work"] / (o["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        kernels.append({"kernel": cls, "bound": o["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "launches": o["calls"], "ms_per_step": round(o["ms"], 3),
+                        "avg_launch_us": round(1e3 * o["ms"] / o["calls"], 2)})
+    d = classes[dominant]
+    ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+    traffic, src = committed_traffic("conv_igemm3_kernel")
+    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (forward + data-gradient launches)",
+            "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
+            "event_pair_overhead_us": round(1e3 * pair_ms, 2),
+            "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 3)}
+    return main, kernels
+
+
+def detect_leg(args, world, rank, pg):
+    """BASELINE config 4: the detect.py path -- inference-mode forward (frozen BN, bf16) + sigmoid + decode / clip /
+    filter / top-K / convert at BATCH_SIZE=256 patches per GPU, k=7 (P=904), whole-image restrictions, max_to_keep
+    200.  Patches shard over ranks with no collective; value = all ranks' patches / max-over-ranks time."""
+    import numpy as np
+    import torch
+    from multibox_amd.engine import Net
+    from multibox_amd import priors as PR, detect as D, _lib
+    from multibox_amd.synth import DEFAULT_ASPECT_RATIOS
+    B, k, S = args.detect_batch, 7, 299
+    priors = np.array(PR.generate_priors(DEFAULT_ASPECT_RATIOS[k]), np.float32)
+    net = Net(batch=B, input_size=S, k=k, mode="infer", seed=2)
+    net.fold_bn()
+    gen = torch.Generator().manual_seed(1000 + rank)
+    images = (torch.rand(B, S, S, 3, generator=gen) * 2 - 1).cuda()
+    meta = D.make_patch_meta(np.zeros((B, 2), np.int32), np.tile([[S, S]], (B, 1)), np.zeros((B, 1), np.int32),
+                             np.tile([[0., 0., 1., 1.]], (B, 1)), np.full((B, 1), 200), np.tile([[S, S]], (B, 1)))
+    pp = D.DetectPostprocess(priors, B, k_max=200)
+    conf = torch.empty((B, net.P), device="cuda")
+    l = _lib.lib()
+
+    def one():
+        net.set_input(images)
+        net.forward()
+        _lib.check(l.mbx_decode_conf(None, net.logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "sigmoid")
+        pp(net.locs, conf, meta)
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        one()
+    for _ in range(3):
+        gr.replay()
+
+    def sync():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    n = args.detect_steps
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gr.replay()
+    sync()
+    dt = time.perf_counter() - t0
+    if pg is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    count_ok = bool((pp.count == 200).all())
+    out = {"metric": "images/sec detect (299x299 patches, 7-AR priors, P=%d): forward + decode/clip/filter/top-K/convert" % net.P,
+           "value": round(B * world * n / dt, 1), "unit": "images/sec", "ms_per_batch": round(1e3 * dt / n, 3), "steps": n,
+           "config": {"workload": "detect.py path, BASELINE config 4: BATCH_SIZE=%d patches/GPU, k=7 (P=%d), restrictions "
+                                  "[0,0,1,1], max_to_keep 200, inference BN, bf16 storage" % (B, net.P),
+                      "global_batch": B * world, "parallelism": "dp%d (patches sharded, no collective)" % world},
+           "all_patches_kept_200": count_ok}
+    if rank == 0 and not args.no_roofline:
+        try:
+            classes, pair_ms = timed_eager_pass(one, ["mbx_conv"])
+            d = classes["igemm"]
+            ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
+                               "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                               "traffic": None, "launches_per_batch": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2)}
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                pp(net.locs, conf, meta)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / 20 * 1e3
+            alg = B * (20.0 * net.P + 24.0 * 200)                       # SURVEY 8d: 20 B x P read + 24 B x K written per patch
+            out["postprocess"] = {"kernel": "decode_filter_topk_kernel", "bound": "hbm (launch-latency in practice)",
+                                  "us_per_batch": round(us, 1), "achieved": round(alg / us / 1e3, 2), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 5)}
+        except Exception as e:
+            out["roofline"] = {"error": repr(e)}
+    del gr
+    return out
 
 
 def main():
@@ -149,10 +299,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
     import __graft_entry__ as g
-    if rank == 0:
+    if local_rank == 0:
         g.build()
     if pg is not None:
         torch.distributed.barrier()
+    # evidence that the process group is RCCL and really spans `world` ranks: an all-reduce of ones
+    rccl = {"backend": None, "ranks": 1, "allreduce_of_ones": 1}
+    if pg is not None:
+        ones = torch.ones(1, device="cuda")
+        torch.distributed.all_reduce(ones)
+        rccl = {"backend": torch.distributed.get_backend(pg), "ranks": torch.distributed.get_world_size(pg),
+                "allreduce_of_ones": int(ones)}
     from multibox_amd.engine import Net
     from multibox_amd.trainer import Trainer, decay_steps
     from multibox_amd import priors as PR
@@ -190,8 +347,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = tr.losses()
-    status_ok = int(tr.match_status().max()) == 0
-    barrier_timeouts = net.barrier_timeouts()
+    # health over ALL ranks: matching status and grid-barrier timeouts of the last step (summed)
+    health = torch.tensor([int(tr.match_status().max() != 0), net.barrier_timeouts()], dtype=torch.int32, device="cuda")
+    if pg is not None:
+        torch.distributed.all_reduce(health)
+    status_ok, barrier_timeouts = int(health[0]) == 0, int(health[1])
     out = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -209,22 +369,37 @@ def main():
                                          ", --fine_tune" if args.fine_tune else ""),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
                "final_losses": {"location": round(losses[0], 3), "confidence": round(losses[1], 3), "regularization": round(losses[2], 4)},
-               "matching_ok": status_ok, "grid_barrier_timeouts": barrier_timeouts,
+               "matching_ok": status_ok, "grid_barrier_timeouts": barrier_timeouts, "rccl": rccl,
                "algorithmic_tflop_per_step": round(per_image_gflop * 1e-3 * B * world, 3)}
         out["model_tflops"] = round(out["algorithmic_tflop_per_step"] / (dt / args.steps), 2)
     if not args.no_roofline and rank == 0:
         try:
-            out["roofline"] = conv_roofline(tr)
+            classes, pair_ms = timed_eager_pass(tr.run_eager_once)
+            out["roofline"], out["roofline_kernels"] = roofline_objects(classes, pair_ms)
         except Exception as e:      # evidence only; never fail the benchmark line on it
             out["roofline"] = {"error": repr(e)}
     if pg is not None:
         torch.distributed.barrier()
+    cpu_base = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(net, priors, args.cpu_seconds)
+            cpu_base = cpu_baseline(net, priors, args.cpu_seconds)
         except Exception as e:
-            out["cpu_baseline"] = {"error": repr(e)}
+            cpu_base = {"error": repr(e)}
+    if not args.no_detect:
+        del tr, net                 # free the training buffers before the detect network is built
+        torch.cuda.empty_cache()
+        try:
+            dleg = detect_leg(args, world, rank, pg)
+        except Exception as e:
+            dleg = {"error": repr(e)}
+        if rank == 0:
+            out["detect"] = dleg
+        if pg is not None:
+            torch.distributed.barrier()
     if rank == 0:
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if pg is not None:
         torch.distributed.destroy_process_group()

@@ -40,12 +40,22 @@ def main():
     from multibox_amd import priors as PR, checkpoint as CK, detect as D, _lib
     from multibox_amd.engine import Net
     import __graft_entry__ as g
-    print("Command line arguments:")
-    pprint.pprint(vars(args))
+    # one process per GPU under torch.distributed.run: ranks take disjoint batches, rank 0 writes the one JSON
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        print("Command line arguments:")
+        pprint.pprint(vars(args))
     cfg = with_defaults(parse_config_file(args.config_file))
     if not args.tfrecords and not args.synthetic:
         raise SystemExit("give --tfrecords FILE... or --synthetic N")
-    g.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:       # results are gathered as host objects: gloo is enough, no GPU collective on this path
+        torch.distributed.init_process_group("gloo")
+    if local_rank == 0:
+        g.build()
+    if world > 1:
+        torch.distributed.barrier()
     bbox_priors = PR.load_priors(args.priors)
     ckpt = CK.latest_checkpoint(args.checkpoint_path)
     if ckpt is None:
@@ -77,7 +87,7 @@ def main():
         batches = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch)
     else:
         batches = synthetic_batches()
-    for batch in batches:
+    for bi, batch in D.shard_batches(batches, rank, world):
         meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
                                  batch["max_to_keep"], batch["image_hw"])
         t = time.time()
@@ -92,16 +102,20 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.time() - t2
         ids = [int(i) if str(i).lstrip("-").isdigit() else i for i in batch["image_ids"]]     # detect.py:410 int(image_id)
-        results += D.results_to_json_records(boxes, scores, count, ids)
+        results.append((bi, D.results_to_json_records(boxes, scores, count, ids)))
         step += 1
         print("Step: %d, Time/image (ms): %.1f, Post-process/image (ms): %.3f" % (step, dt / B * 1000, dt2 / B * 1000))
         if args.max_iterations > 0 and step == args.max_iterations:
             break
-    os.makedirs(args.save_dir, exist_ok=True)
-    save_path = os.path.join(args.save_dir, "results-dense-%d.json" % global_step)
-    with open(save_path, "w") as f:
-        json.dump(results, f)
-    print("wrote", save_path, len(results), "detections")
+    results = D.gather_results(results)
+    if rank == 0:
+        os.makedirs(args.save_dir, exist_ok=True)
+        save_path = os.path.join(args.save_dir, "results-dense-%d.json" % global_step)
+        with open(save_path, "w") as f:
+            json.dump(results, f)
+        print("wrote", save_path, len(results), "detections")
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

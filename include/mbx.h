@@ -95,7 +95,9 @@ int mbx_loss_fwd_bwd(const float* decoded /*[B,P,4]*/, const float* conf_in /*[B
  * (412-413), filter_proposals (74-104, strict inequalities), sort by confidence
  * descending and keep max_to_keep (423-427), convert_proposals to image coordinates in
  * float64 incl. the flip (106-131).  Ties in confidence: higher prediction index first
- * (the reference's order among ties is undefined).                                   */
+ * (the reference's order among ties is undefined).  `conf` may hold ANY float (the sort key is an order-
+ * preserving image of the float bits): negative values, values >= 1 and infinities order as numpy's
+ * argsort does; a NaN sorts first, as argsort(...)[::-1] (detect.py:423) places it.            */
 typedef struct {
   int32_t offset_y, offset_x; /* batched_offsets  (detect.py:190-281) */
   int32_t patch_h, patch_w;   /* batched_dims */
@@ -150,7 +152,9 @@ typedef struct {
                            -- for callers that time the candidates on their own shapes.  Results do not depend on
                            it (same K order), only mbx_conv_stats_rows() does.  For mbx_conv_wgrad*: 0 default,
                            1..6 = {8 waves x 256 blocks, 4 waves x 512, 8 x 192, 4 x 384, 8 x 128, 8 x 224}, 7 / 8 =
-                           the narrow tile (64 output channels per block): 8 waves x 256 / 192, 9 / 10 = 4 waves x 512 / 768. */
+                           the narrow tile (64 output channels per block): 8 waves x 256 / 192, 9 / 10 = 4 waves x 512 / 768;
+                           11 = un-split (one block per output tile: every dw element is added to once, so the
+                           result is bit-reproducible from run to run -- the MBX_DETERMINISTIC debug mode). */
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 
@@ -215,7 +219,9 @@ int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int rel
  * one resident workgroup per CU (mbx_bn_bwd_onepass_supported; everything but the 5 stem layers at
  * BATCH_SIZE 64); otherwise MBX_ERR_UNSUPPORTED and the caller uses the three launches above.
  * `ws` (mbx_bn_bwd_onepass_workspace_bytes(C), 16-byte aligned) must be ZERO at launch; after the launch word
- * [4*2*C] holds the grid size and word [4*2*C + 1] a barrier-timeout flag (0 unless the grid was not resident).  dbeta [C] += sum g (may be NULL).  max_workgroups: 0 = one
+ * [4*2*C] holds the grid size and word [4*2*C + 1] a barrier-timeout flag (0 unless the grid was not resident);
+ * a workgroup that timed out also writes NaN into its part of dy (and dbeta), so a step cannot continue silently on
+ * partial totals.  dbeta [C] += sum g (may be NULL).  max_workgroups: 0 = one
  * workgroup per CU; a smaller positive number leaves CUs free for a concurrent stream (e.g. an RCCL
  * all-reduce in flight), whose kernels would otherwise delay the barrier until they finish.              */
 size_t mbx_bn_bwd_onepass_workspace_bytes(int C);

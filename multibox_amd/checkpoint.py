@@ -19,7 +19,11 @@ def save(logdir, trainer, max_to_keep=3):
                  W=net.W.cpu(), Bt=net.Bt.cpu(), MM=net.MM.cpu(), MV=net.MV.cpu(),
                  Wms=trainer.Wms.cpu(), Btms=trainer.Btms.cpu(),
                  Wema=trainer.Wema.cpu(), Btema=trainer.Btema.cpu(), MMema=trainer.MMema.cpu(), MVema=trainer.MVema.cpu())
-    torch.save(state, path)
+    if trainer.Wmom is not None:                    # RMSPROP_MOMENTUM != 0: the momentum slots are optimiser state too
+        state.update(Wmom=trainer.Wmom.cpu(), Btmom=trainer.Btmom.cpu())
+    tmp = path + ".tmp"                             # a kill in mid-save must not leave a truncated newest checkpoint
+    torch.save(state, tmp)
+    os.replace(tmp, path)
     olds = sorted(glob.glob(os.path.join(logdir, "model.ckpt-*.pt")), key=_step_of)
     for p in olds[:-max_to_keep]:
         os.remove(p)
@@ -83,6 +87,7 @@ def restore_pretrained(path, trainer, fine_tune=False, use_moving_averages=False
     else:
         restore_for_training(ck, trainer)
     trainer.global_step = 0
+    trainer.refresh_frozen_reg()
     return ck
 
 
@@ -94,10 +99,14 @@ def restore_for_training(path, trainer):
         t.copy_(st[name])
     for name in ("Wms", "Btms", "Wema", "Btema", "MMema", "MVema"):
         getattr(trainer, name).copy_(st[name])
+    if trainer.Wmom is not None and "Wmom" in st:
+        trainer.Wmom.copy_(st["Wmom"])
+        trainer.Btmom.copy_(st["Btmom"])
     trainer.global_step = int(st["global_step"])
     net.refresh_bf16()
     if net.fine_tune:
         net.fold_bn()
+    trainer.refresh_frozen_reg()
 
 
 def restore_for_inference(path, net, use_moving_averages=True):

@@ -1043,6 +1043,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
     case 8: ng = 2; target = 192; break;
     case 9: ng = 1; target = 512; break;
     case 10: ng = 1; target = 768; break;
+    case 11: ng = 2; target = 1; break;      // un-split: one block per tile, every dw element has ONE adder (bit-reproducible)
     default: break;
   }
   int splits = target / tiles;                 // floor: all blocks resident in one round

@@ -2,6 +2,7 @@
 // filter preparation and the fused RMSProp+L2+EMA step.  All HBM-bound: 16-byte (8 x bf16)
 // accesses per lane along the NHWC channel axis, grid-stride loops capped at 2048 blocks.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -356,8 +357,9 @@ __global__ void __launch_bounds__(kObT)
 bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ y,
                       long long M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ beta, float* __restrict__ dbeta, unsigned short* __restrict__ dy,
-                      float* __restrict__ ws, int rpi, int rpb, float inv_M) {
+                      float* __restrict__ ws, int rpi, int rpb, float inv_M, unsigned spin_limit, int fault) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16] partial sums, then [2C] totals
+  __shared__ int s_timeout;                                      // this workgroup gave up on the grid barrier
   const int C8 = C >> 3;
   const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
   const bool active = rr < rpi;
@@ -451,7 +453,9 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
   if (threadIdx.x == 0) {
     const unsigned G = gridDim.x, b = blockIdx.x;
     const unsigned sub = b % kObSub, n_sub = (G - sub + kObSub - 1) / kObSub, n_top = G < kObSub ? G : kObSub;
-    bool last = atomicAdd(ctl + kObLine * (1 + sub), 1u) == n_sub - 1;
+    s_timeout = 0;
+    // fault injection (tests only, MBX_DEBUG_BARRIER_FAULT=1): workgroup 0 never arrives, everyone else times out
+    bool last = (fault && b == 0) ? false : atomicAdd(ctl + kObLine * (1 + sub), 1u) == n_sub - 1;
     if (last) last = atomicAdd(ctl + kObLine * (1 + kObSub), 1u) == n_top - 1;
     if (last) {
       for (int r = 0; r < kObRel; ++r)
@@ -461,7 +465,10 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
       unsigned spins = 0;
       while (ld_agent(rel) == 0u) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 22)) { ctl[1] = 1u; break; }         // cannot happen when the grid is resident
+        // cannot happen when the grid is resident.  If it does (CUs taken by another stream's kernels), the totals
+        // below are partial: raise the flag AND poison this workgroup's outputs with NaN, so that the step cannot
+        // silently train on a wrong gradient (the host also checks the flag: Trainer.check_health)
+        if (++spins > spin_limit) { ctl[1] = 1u; s_timeout = 1; break; }
       }
     }
     if (b == 0) ctl[0] = G;
@@ -477,9 +484,10 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
   }
   __syncthreads();
   float m1[8], m2[8];
+  const float poison = s_timeout ? __builtin_nanf("") : 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float t1 = active ? sred[c + j] : 0.f;
+    const float t1 = (active ? sred[c + j] : 0.f) + poison;
     m1[j] = t1 * inv_M;
     m2[j] = (active ? sred[C + c + j] : 0.f) * inv_M;
     if (blockIdx.x == 0 && rr == 0 && dbeta) dbeta[c + j] += t1;
@@ -1006,10 +1014,13 @@ extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const voi
   if (g.nv > kObMaxNV) return MBX_ERR_UNSUPPORTED;
   MBX_ENTER();
   const size_t lds = ((size_t)g.rpi * g.C8 * 16 + (size_t)2 * C) * sizeof(float);
+  static int fault = -1;
+  if (fault < 0) { const char* e = getenv("MBX_DEBUG_BARRIER_FAULT"); fault = (e && e[0] == '1') ? 1 : 0; }
+  const unsigned spin_limit = fault ? (1u << 10) : (1u << 22);
 #define MBX_OB(NV, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_bwd_onepass_kernel<NV, RELU>), dim3(g.G), dim3(kObT), lds, mbx_s(stream), (cus)da, ld_da,      \
                      (cus)y, (long long)M, C, mean, rstd, beta, dbeta, (us)dy, (float*)ws, g.rpi, g.rpb,               \
-                     (float)(1.0 / (double)M))
+                     (float)(1.0 / (double)M), spin_limit, fault)
 #define MBX_OB_NV(NV) do { if (relu) MBX_OB(NV, true); else MBX_OB(NV, false); } while (0)
   if (g.nv <= 2) MBX_OB_NV(2);
   else if (g.nv <= 4) MBX_OB_NV(4);

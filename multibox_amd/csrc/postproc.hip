@@ -252,7 +252,10 @@ __global__ void loss_final_kernel(const double* __restrict__ partial, int B, flo
 }
 
 // ------------------------------------------------------- decode + filter + top-K
-// Key: kept flag | confidence bits | prediction index; bitonic sort, descending.
+// Key: kept flag (bit 63) | order-preserving image of the confidence's float bits (32 bits) | prediction index
+// (31 bits); bitonic sort, descending.  The float image (flip the sign bit of non-negative values, all bits of
+// negative ones) orders ANY float like a comparison sort does -- negative scores and scores >= 2 included; a NaN
+// sorts above everything, where numpy's argsort(...)[::-1] (detect.py:423) puts it.
 __global__ void __launch_bounds__(kThreads)
 decode_filter_topk_kernel(const float4* __restrict__ raw, const float* __restrict__ conf,
                           const float4* __restrict__ priors, const mbx_patch_meta* __restrict__ meta,
@@ -276,7 +279,10 @@ decode_filter_topk_kernel(const float4* __restrict__ raw, const float* __restric
       // detect.py:92-99 (strict)
       const bool drop = (x1 < m.restrictions[0]) || (y1 < m.restrictions[1]) || (x2 > m.restrictions[2]) || (y2 > m.restrictions[3]);
       if (!drop) {
-        key = (1ull << 62) | ((unsigned long long)__float_as_uint(c[j]) << 32) | (unsigned)j;
+        const float cj = c[j];
+        unsigned u = __float_as_uint(cj);
+        u = (cj != cj) ? 0xffffffffu : (cj == 0.f) ? 0x80000000u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // -0 == +0
+        key = (1ull << 63) | ((unsigned long long)u << 31) | (unsigned long long)j;
         ++kept;
       }
     }
@@ -311,7 +317,7 @@ decode_filter_topk_kernel(const float4* __restrict__ raw, const float* __restric
     double* ob = out_boxes + ((size_t)b * k_max + t) * 4;
     if (t < count) {
       const unsigned long long key = keys[t];
-      const int j = (int)(key & 0xffffffffu);
+      const int j = (int)(key & 0x7fffffffull);
       const float4 a = r[j], p = priors[j];
       const float x1 = fminf(fmaxf(__fadd_rn(a.x, p.x), 0.f), 1.f), y1 = fminf(fmaxf(__fadd_rn(a.y, p.y), 0.f), 1.f);
       const float x2 = fminf(fmaxf(__fadd_rn(a.z, p.z), 0.f), 1.f), y2 = fminf(fmaxf(__fadd_rn(a.w, p.w), 0.f), 1.f);

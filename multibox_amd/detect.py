@@ -86,3 +86,36 @@ def results_to_json_records(boxes, scores, count, image_ids):
         for k in range(int(count[b])):
             out.append({"image_id": image_ids[b], "bbox": boxes[b, k].tolist(), "score": float(scores[b, k])})
     return out
+
+
+# ----------------------------------------------------------------------------- multi-GPU detect
+# Patches are independent (per-patch loop, detect.py:408): ranks take disjoint batches, NO collective on the data
+# path; at the end rank 0 concatenates the per-rank result lists into the one JSON of detect.py:458-460.
+def shard_batches(batches, rank, world):
+    """Yield (global batch index, batch) for the batches this rank owns: batch i goes to rank i % world, so every
+    rank keeps the single-process batching (tf.train.batch order, detect.py:283-292) and the merge below can
+    restore the single-process order of the results."""
+    for i, b in enumerate(batches):
+        if i % world == rank:
+            yield i, b
+
+
+def merge_results(per_rank):
+    """per_rank: one list per rank of (global batch index, [records]).  Returns the records in batch order --
+    exactly what one process would have written."""
+    tagged = [t for part in per_rank for t in part]
+    tagged.sort(key=lambda t: t[0])
+    assert [t[0] for t in tagged] == sorted(set(t[0] for t in tagged)), "a batch was processed by two ranks"
+    return [r for _, recs in tagged for r in recs]
+
+
+def gather_results(local, group=None):
+    """Rank 0 gets merge_results() of every rank's [(batch index, records)]; other ranks get None.  Host-side
+    object gather (gloo or RCCL-backed group both work); single process: just the merge."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return merge_results([local])
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(local, parts, dst=0, group=group)
+    return merge_results(parts) if rank == 0 else None

@@ -77,7 +77,10 @@ class Net:
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
         self.tune_registry = []                    # (key, descriptor, fwd | dgrad | wgrad) of every tunable conv launch
-        self.no_onepass = bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
+        # MBX_DETERMINISTIC=1: bit-reproducible gradients for bisecting parity bugs -- three-launch batch-norm backward
+        # (no atomics) and un-split weight-gradient tiles (one adder per element); slower, same mathematics
+        self.deterministic = bool(int(os.environ.get("MBX_DETERMINISTIC", "0")))
+        self.no_onepass = self.deterministic or bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
@@ -646,7 +649,9 @@ class Net:
             wkey = ("wgrad", op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
                     dyv.ld, db is not None)
             self.tune_registry.append((repr(wkey), wdesc, "wgrad"))
-            if self.autotune and int(os.environ.get("MBX_AUTOTUNE_WGRAD", "1")):
+            if self.deterministic:
+                wdesc.tile_config = 11
+            elif self.autotune and int(os.environ.get("MBX_AUTOTUNE_WGRAD", "1")):
                 ops.autotune_wgrad(wdesc, dyv, scale, dw, db, wkey)
 
             def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):

@@ -12,6 +12,7 @@ every step.
 from __future__ import annotations
 
 import math
+import re
 
 import torch
 
@@ -38,9 +39,10 @@ class Trainer:
     def __init__(self, net: Net, bbox_priors, max_num_bboxes=13, location_loss_alpha=1000.0, initial_learning_rate=0.01,
                  decay_steps_=7116, learning_rate_decay_factor=0.94, staircase=True, rmsprop_decay=0.9,
                  rmsprop_momentum=0.0, rmsprop_epsilon=1.0, moving_average_decay=0.9999, use_graph=True,
-                 n_segments=None, process_group=None):
+                 n_segments=None, process_group=None, trainable_scopes=None):
         assert net.mode == "train"
         self.net = net
+        self.pg = process_group
         self.loss = MultiboxLoss(bbox_priors, net.B, max_num_bboxes, location_loss_alpha, device=net.dev)
         assert self.loss.P == net.P, "priors (%d) do not match the network's predictions (%d)" % (self.loss.P, net.P)
         self.loss.d_locs, self.loss.d_logits = net.d_locs, net.d_logits
@@ -60,8 +62,10 @@ class Trainer:
         self.Wema, self.Btema = net.W.clone(), net.Bt.clone()
         self.MMema, self.MVema = net.MM.clone(), net.MV.clone()
         self.frozen_reg = 0.0
-        if self.w_lo > 0:       # regulariser of frozen variables is a constant (train.py:246 still adds it)
-            self.frozen_reg = float(0.5 * WEIGHT_DECAY * (net.W[:self.w_lo].double() ** 2).sum())
+        self.refresh_frozen_reg()
+        # --trainable_scopes (train.py:152-171): only variables under the given scopes are updated; everything else in
+        # the trainable range still gets its EMA / regulariser / bf16 refresh (it stays a model variable)
+        self.opt_ranges = self._optimizer_ranges(trainable_scopes)
         self.gt = torch.zeros((net.B, max_num_bboxes, 4), **f32)
         self.n_gt = torch.zeros((net.B,), dtype=torch.int32, device=net.dev)
         self.images = torch.zeros((net.B, net.S, net.S, 3), **f32)
@@ -75,6 +79,90 @@ class Trainer:
         if n_segments is None:
             n_segments = 6 if self.reducer.enabled else 4
         self._segments = self._make_segments(n_segments)
+
+    def refresh_frozen_reg(self):
+        """Regulariser of the frozen backbone under --fine_tune: a constant that train.py:246 still adds to the total
+        loss.  Recomputed after every restore (the weights it is taken from change there)."""
+        self.frozen_reg = 0.0
+        if self.w_lo > 0:
+            self.frozen_reg = float(0.5 * WEIGHT_DECAY * (self.net.W[:self.w_lo].double() ** 2).sum())
+
+    def _optimizer_ranges(self, scopes):
+        """[(buffer 'W' | 'Bt', lo, hi, trainable)] covering the trainable part of both flat buffers, adjacent ranges of
+        equal status merged.  scopes=None: everything trainable (train.py:160-161).  A scope selects the variables
+        whose name it matches from the start, like tf.get_collection(TRAINABLE_VARIABLES, scope) (train.py:168)."""
+        net = self.net
+        if scopes is None:
+            return [("W", self.w_lo, net.nW, 1), ("Bt", self.bt_lo, net.nBt, 1)]
+        pats = [re.compile(s.strip()) for s in scopes]
+        marks = {"W": [], "Bt": []}
+        self.trainable_names = []
+        for name, (buf, off, shape, cpad) in net.param_index.items():
+            if buf not in marks:
+                continue                                         # moving statistics are not trainable variables
+            n = 1
+            for d in (shape[:-1] + (cpad,) if cpad is not None else shape):
+                n *= d
+            lo_buf = self.w_lo if buf == "W" else self.bt_lo
+            if off < lo_buf:
+                continue                                         # frozen by --fine_tune
+            on = int(any(p.match(name) for p in pats))
+            if on:
+                self.trainable_names.append(name)
+            marks[buf].append((off, off + n, on))
+        out = []
+        for buf, lo_buf, hi_buf in (("W", self.w_lo, net.nW), ("Bt", self.bt_lo, net.nBt)):
+            cur_lo, cur_on = lo_buf, None
+            pos = lo_buf
+            for lo, hi, on in sorted(marks[buf]):
+                # alignment gaps between variables ride with the range before them (their gradient is zero)
+                if cur_on is None:
+                    cur_on = on
+                elif on != cur_on:
+                    out.append((buf, cur_lo, lo, cur_on))
+                    cur_lo, cur_on = lo, on
+                pos = hi
+            if cur_on is not None:
+                out.append((buf, cur_lo, hi_buf, cur_on))
+        return out
+
+    def broadcast_parameters(self, src=0):
+        """Data-parallel start: every rank takes rank `src`'s variables, optimiser slots and EMA shadows (after a
+        restore only rank 0's files need to exist; identical seeds are not relied upon)."""
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        net = self.net
+        for t in (net.W, net.Bt, net.MM, net.MV, self.Wms, self.Btms, self.Wmom, self.Btmom, self.Wema, self.Btema,
+                  self.MMema, self.MVema):
+            if t is not None:
+                dist.broadcast(t, src=src, group=self.pg)
+        step = torch.tensor([self.global_step], dtype=torch.int64, device=net.W.device)
+        dist.broadcast(step, src=src, group=self.pg)
+        self.global_step = int(step)
+        if net.W.is_cuda:
+            net.refresh_bf16()
+            if net.fine_tune:
+                net.fold_bn()
+        self.refresh_frozen_reg()
+
+    def check_health(self):
+        """Raise if the last step cannot be trusted, on ANY rank: a grid barrier of the one-launch batch-norm backward
+        timed out (its outputs were poisoned with NaN) or the matching failed (non-finite predictions / more boxes than
+        predictions -- the reference's py_func raises there, loss.py:82).  Host sync; call it at logging intervals."""
+        bad = torch.tensor([self.net.barrier_timeouts(), int(self.match_status().max() != 0)], dtype=torch.int32,
+                           device=self.net.W.device)
+        if self.pg is not None:
+            import torch.distributed as dist
+            if dist.get_world_size(self.pg) > 1:
+                dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.pg)
+        t, m = int(bad[0]), int(bad[1])
+        if t:
+            raise RuntimeError("batch-norm backward: %d grid-barrier timeout(s) (workgroups not co-resident); "
+                               "gradients of this step are poisoned -- lower MBX_BN_MAX_WG or set MBX_NO_BN_ONEPASS=1" % t)
+        if m:
+            raise RuntimeError("bipartite matching failed on %d rank(s) (non-finite predictions or n_gt > P)" % m)
+        return True
 
     # ------------------------------------------------------------------ segments / buckets
     def _make_segments(self, n):
@@ -180,13 +268,18 @@ class Trainer:
         self.lr = lr
         net.reg_loss.zero_()
         P = lambda t_, off=0: None if t_ is None else t_.data_ptr() + 4 * off
-        lo, n = self.w_lo, net.nW - self.w_lo
-        _lib.check(l.mbx_rmsprop_ema_step(P(net.W, lo), P(net.Wg, lo), P(self.Wms, lo), P(self.Wmom, lo), P(self.Wema, lo),
-                                          net.Wb.data_ptr() + 2 * lo, n, lr, self.rms_decay, self.momentum, self.eps,
-                                          WEIGHT_DECAY, d, 1, net.reg_loss.data_ptr(), s), "rmsprop W")
+        for buf, lo, hi, on in self.opt_ranges:
+            n = hi - lo
+            if n <= 0:
+                continue
+            if buf == "W":
+                _lib.check(l.mbx_rmsprop_ema_step(P(net.W, lo), P(net.Wg, lo), P(self.Wms, lo), P(self.Wmom, lo), P(self.Wema, lo),
+                                                  net.Wb.data_ptr() + 2 * lo, n, lr, self.rms_decay, self.momentum, self.eps,
+                                                  WEIGHT_DECAY, d, on, net.reg_loss.data_ptr(), s), "rmsprop W")
+            else:
+                _lib.check(l.mbx_rmsprop_ema_step(P(net.Bt, lo), P(net.Btg, lo), P(self.Btms, lo), P(self.Btmom, lo), P(self.Btema, lo),
+                                                  None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, on, None, s), "rmsprop beta")
         lo, n = self.bt_lo, net.nBt - self.bt_lo
-        _lib.check(l.mbx_rmsprop_ema_step(P(net.Bt, lo), P(net.Btg, lo), P(self.Btms, lo), P(self.Btmom, lo), P(self.Btema, lo),
-                                          None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, 1, None, s), "rmsprop beta")
         _lib.check(l.mbx_ema_update(P(self.MMema, lo), P(net.MM, lo), n, d, s), "ema moving_mean")
         _lib.check(l.mbx_ema_update(P(self.MVema, lo), P(net.MV, lo), n, d, s), "ema moving_var")
         net.prepare_filters()

@@ -54,3 +54,86 @@ def test_bucketed_allreduce_world2(fine_tune):
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _detect_worker(rank, world, port, q):
+    """Rank-sharded detect: disjoint batches per rank, rank 0 concatenates in single-process order."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multibox_amd import detect as D
+    batches = [dict(ids=list(range(4 * i, 4 * i + 4))) for i in range(7)]          # 7 batches of 4 patches
+    local = []
+    for bi, b in D.shard_batches(iter(batches), rank, world):
+        local.append((bi, [{"image_id": i, "bbox": [0.0, 0.0, 1.0, 1.0], "score": 1.0 / (1 + i)} for i in b["ids"]]))
+    merged = D.gather_results(local)
+    if rank == 0:
+        single = D.merge_results([[(bi, [{"image_id": i, "bbox": [0.0, 0.0, 1.0, 1.0], "score": 1.0 / (1 + i)} for i in b["ids"]])
+                                   for bi, b in enumerate(batches)]])
+        q.put((rank, merged == single and [r["image_id"] for r in merged] == list(range(28)), len(local)))
+    else:
+        q.put((rank, merged is None, len(local)))
+    dist.destroy_process_group()
+
+
+def test_detect_sharding_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_detect_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, 4), (1, True, 3)]
+
+
+def _bcast_worker(rank, world, port, q):
+    """Trainer.broadcast_parameters: every rank ends with rank 0's variables / slots / shadows / step;
+    Trainer.check_health: a failure flag on ONE rank raises on EVERY rank."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    net = Net(batch=1, input_size=299, k=5, mode="train", device="cpu", seed=2 + rank)      # DIFFERENT weights per rank
+    tr = Trainer.__new__(Trainer)
+    tr.net, tr.pg, tr.w_lo, tr.bt_lo, tr.global_step = net, dist.group.WORLD, 0, 0, 10 * (rank + 1)
+    f = lambda n, v: torch.full((n,), float(v))
+    tr.Wms, tr.Btms, tr.Wmom, tr.Btmom = f(net.nW, rank + 1), f(net.nBt, rank + 1), None, None
+    tr.Wema, tr.Btema, tr.MMema, tr.MVema = net.W.clone(), net.Bt.clone(), net.MM.clone(), net.MV.clone()
+    w_before = net.W.clone()
+    tr.broadcast_parameters(src=0)
+    ref = Net(batch=1, input_size=299, k=5, mode="train", device="cpu", seed=2)
+    ok = torch.equal(net.W, ref.W) and torch.equal(tr.Wema, ref.W) and float(tr.Wms[0]) == 1.0 and tr.global_step == 10
+    ok = ok and (rank == 0 or not torch.equal(w_before, ref.W))
+    # health: rank 1 reports a failed matching, both ranks must raise
+    class FakeLoss:
+        status = torch.tensor([0, 2 if rank == 1 else 0], dtype=torch.int32)
+    tr.loss = FakeLoss()
+    net.no_onepass = True                          # barrier_timeouts() -> 0 on CPU
+    try:
+        tr.check_health()
+        raised = False
+    except RuntimeError as e:
+        raised = "matching failed" in str(e)
+    q.put((rank, bool(ok), raised))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_health_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, True), (1, True, True)]

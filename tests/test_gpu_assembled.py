@@ -1,0 +1,199 @@
+"""The ASSEMBLED hot path at BASELINE sizes, through the C-ABI (round-2 additions):
+
+  * the whole training step at BATCH_SIZE 64 (299x299 k=5 G=13 and 512x512 k=7 G=100): size-independent properties
+    (every gt matched exactly once, matching status 0, no grid-barrier timeout, finite losses, exact-zero location
+    loss on a batch without boxes -- model_tests.py:207);
+  * the full 10/20/9 network in inference mode (frozen BN: the non-chaotic regime) at batch 8 against the
+    bf16-emulating torch oracle with a STATED tolerance;
+  * MBX_DETERMINISTIC=1: two runs of the same step give bit-identical gradients;
+  * failure is loud: a grid-barrier timeout poisons the gradients and Trainer.check_health raises; the detect top-K
+    orders ANY float score like numpy's argsort (negative, > 1, inf, NaN).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("S,k,G", [(299, 5, 13), (512, 7, 100)])
+def test_assembled_step_b64(torch_cuda, S, k, G):
+    torch = torch_cuda
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    from multibox_amd import priors as PR
+    from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+    B = 64
+    net = Net(batch=B, input_size=S, k=k, mode="train", seed=2)
+    pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], S).astype(np.float32)
+    assert pri.shape[0] == net.P
+    tr = Trainer(net, pri, max_num_bboxes=G, use_graph=True)
+    images, gt, n = synthetic_batch(B, S, G, seed=0)
+    n[0], n[1] = G, 0                                   # a full image and an empty one
+    rng = np.random.RandomState(7)
+    xy = rng.uniform(0, .7, (G, 2)); wh = rng.uniform(.05, .3, (G, 2))
+    gt[0, :, :2] = xy; gt[0, :, 2:] = xy + wh
+    gt[1] = 0
+    T = lambda a: torch.from_numpy(a).cuda()
+    tr.set_batch(T(images), T(gt), T(n))
+    w0 = net.W.clone()
+    for _ in range(2):
+        tr.step()
+    torch.cuda.synchronize()
+    assert tr.check_health()                                         # status 0 and no barrier timeout, or it raises
+    assert int(tr.match_status().max()) == 0 and net.barrier_timeouts() == 0
+    m = tr.loss.match.cpu().numpy()
+    for b in range(B):
+        assert sorted(m[b][m[b] >= 0].tolist()) == list(range(n[b])), b     # every gt matched exactly once
+    loc, conf, reg, total = tr.losses()
+    assert all(np.isfinite(x) for x in (loc, conf, reg, total)) and loc > 0 and conf > 0 and reg > 0
+    assert abs(total - (loc + conf + reg)) <= 1e-5 * abs(total)              # model_tests.py:154-156
+    assert bool(torch.isfinite(net.Wg).all()) and bool(torch.isfinite(net.W).all()) and not torch.equal(w0, net.W)
+    # no boxes anywhere: location loss exactly 0 (model_tests.py:207), no location gradient, confidence loss > 0
+    tr.set_batch(T(images), T(np.zeros_like(gt)), T(np.zeros_like(n)))
+    tr.step()
+    torch.cuda.synchronize()
+    loc, conf, _, _ = tr.losses()
+    assert loc == 0.0 and conf > 0 and int((tr.loss.match >= 0).sum()) == 0
+    assert float(net.d_locs.abs().max()) == 0.0
+
+
+def test_inference_forward_fixed_tolerance(torch_cuda):
+    """Full-depth network, every BN frozen (detect.py:313-334), batch 8: engine vs the bf16-emulating torch oracle
+    on the same bf16 weights.  Stated tolerance (this regime does not amplify rounding chaotically):
+    rel-L2 <= 1e-2 on locations and logits, max error <= 2e-2 of the largest magnitude."""
+    torch = torch_cuda
+    from multibox_amd.engine import Net
+    from oracle.torch_model import Model, q_bf16
+    B = 8
+    net = Net(batch=B, input_size=299, k=5, mode="infer", seed=11)
+    gen = torch.Generator().manual_seed(4)
+    net.Bt.copy_((torch.randn(net.nBt, generator=gen) * 0.1).cuda())
+    net.MM.copy_((torch.randn(net.nBt, generator=gen) * 0.1).cuda())
+    net.MV.copy_((torch.rand(net.nBt, generator=gen) + 0.5).cuda())
+    net.fold_bn()
+    images = torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1
+    net.set_input(images.cuda())
+    locs, logits = net.forward()
+    torch.cuda.synchronize()
+    P = {}
+    for name in net.param_index:
+        v = net.get_param(name).detach().float().cpu().clone()
+        P[name] = v.to(torch.bfloat16).float() if name.endswith("/weights") else v
+    with torch.no_grad():
+        rl, rz = Model(P, k=5, bn_training=False, q=q_bf16).build(images)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e_l, e_z = rel(locs.cpu(), rl), rel(logits.cpu(), rz)
+    m_l = float((locs.cpu() - rl).abs().max() / rl.abs().max())
+    m_z = float((logits.cpu() - rz).abs().max() / rz.abs().max())
+    print("inference forward B=8: rel-L2 locs %.2e logits %.2e; max/absmax locs %.2e logits %.2e" % (e_l, e_z, m_l, m_z))
+    assert e_l <= 1e-2 and e_z <= 1e-2, (e_l, e_z)
+    assert m_l <= 2e-2 and m_z <= 2e-2, (m_l, m_z)
+
+
+_DET_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from multibox_amd.engine import Net
+from multibox_amd.trainer import Trainer
+from multibox_amd import priors as PR
+from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+B = 8
+pri = np.array(PR.generate_priors(DEFAULT_ASPECT_RATIOS[5]), np.float32)
+images, gt, n = synthetic_batch(B, 299, 13, seed=3)
+outs = []
+for run in range(2):
+    net = Net(batch=B, input_size=299, k=5, mode="train", seed=2)
+    tr = Trainer(net, pri, max_num_bboxes=13, use_graph=False)
+    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    tr.run_eager_once()
+    torch.cuda.synchronize()
+    outs.append((net.Wg.clone(), net.Btg.clone()))
+same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+print("IDENTICAL" if same else "DIFFERENT", float(outs[0][0].abs().sum()))
+"""
+
+
+def test_deterministic_mode_bit_identical(torch_cuda):
+    """MBX_DETERMINISTIC=1 (three-launch batch-norm backward, un-split weight-gradient tiles: no fp32 atomics with
+    more than one adder): two fresh networks, same seeds, same batch -> bit-identical Wg / Btg."""
+    env = dict(os.environ, MBX_DETERMINISTIC="1")
+    r = subprocess.run([sys.executable, "-c", _DET_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "IDENTICAL" in r.stdout, r.stdout[-500:]
+
+
+_FAULT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from multibox_amd.engine import Net
+from multibox_amd.trainer import Trainer
+from multibox_amd import priors as PR
+from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+B = 2
+pri = np.array(PR.generate_priors(DEFAULT_ASPECT_RATIOS[5]), np.float32)
+net = Net(batch=B, input_size=299, k=5, mode="train", seed=2, repeats=(1, 1, 1))
+tr = Trainer(net, pri, max_num_bboxes=13, use_graph=False)
+images, gt, n = synthetic_batch(B, 299, 13, seed=3)
+tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+tr.step()
+torch.cuda.synchronize()
+print("TIMEOUTS", net.barrier_timeouts(), "NAN_IN_GRAD", bool(torch.isnan(net.Wg).any()))
+try:
+    tr.check_health()
+    print("NO_RAISE")
+except RuntimeError as e:
+    print("RAISED", "grid-barrier" in str(e))
+"""
+
+
+def test_barrier_timeout_is_loud(torch_cuda):
+    """MBX_DEBUG_BARRIER_FAULT=1 makes workgroup 0 of every one-launch BN backward skip its arrival: all others time
+    out (bounded spin), set the flag and poison their outputs; the host check raises."""
+    env = dict(os.environ, MBX_DEBUG_BARRIER_FAULT="1", MBX_AUTOTUNE="0")
+    r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert "RAISED True" in out and "NAN_IN_GRAD True" in out, out[-500:]
+    assert int(out.split("TIMEOUTS")[1].split()[0]) > 0
+
+
+def test_topk_orders_any_float_score(torch_cuda):
+    """mbx_decode_filter_topk must order like numpy's argsort for ANY float (the r1 key packing needed 0 <= c < 2)."""
+    torch = torch_cuda
+    from multibox_amd import detect as D
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(2)
+    P = 646
+    priors = rng.uniform(0.2, 0.6, (P, 4)).astype(np.float32)
+    priors[:, 2:] = priors[:, :2] + 0.1
+    raw = (rng.randn(3, P, 4) * 0.01).astype(np.float32)
+    confs = (rng.randn(3, P) * 3).astype(np.float32)               # negative, > 1, > 2
+    confs[1, 5], confs[1, 9], confs[1, 11] = np.inf, -np.inf, -0.0
+    confs[2, 100] = np.nan
+    B = 3
+    offs = np.zeros((B, 2), np.int32); dims = np.tile([[299, 299]], (B, 1)); flips = np.zeros((B,), np.int32)
+    res = np.tile([[0, 0, 1, 1]], (B, 1)).astype(np.float32); mtk = np.full((B,), 200, np.int32)
+    meta = D.make_patch_meta(offs, dims, flips, res, mtk, dims)
+    pp = D.DetectPostprocess(priors, B, k_max=200)
+    boxes, scores, index, count = [t.cpu().numpy() for t in pp(torch.from_numpy(raw).cuda(), torch.from_numpy(confs).cuda(), meta)]
+    for b in range(B):
+        rb, rs, ridx = R.detect_postprocess(raw[b], confs[b], priors, res[b], mtk[b], offs[b], dims[b], dims[b], flips[b])
+        assert count[b] == len(ridx) == 200
+        assert np.array_equal(index[b, :200], ridx), b             # NaN first (argsort puts it last, [::-1] first)
+        assert scores[b, :200].tobytes() == rs.tobytes()
+        assert boxes[b, :200].tobytes() == rb.tobytes()
+    assert np.isnan(scores[2, 0]) and scores[1, 0] == np.inf

@@ -96,3 +96,62 @@ def test_two_rank_step_equals_summed_gradient_step(tmp_path):
     assert cos(r0["W"] - w0.cpu(), net.W.cpu() - w0.cpu()) > 0.9999
     assert cos(r0["Bt"], net.Bt.cpu()) > 0.9999
     assert float((r0["W"] - net.W.cpu()).abs().max()) < 2e-3 * float((net.W.cpu() - w0.cpu()).abs().max()) + 1e-7
+
+
+def _worker_shipped(rank, world, port, out_dir):
+    """The SHIPPED data-parallel configuration: one-launch batch-norm backward with a capped grid, measured tile table,
+    hipGraph segments, bucketed async all-reduce.  Two ranks share this box's one GPU, so each caps its grid-barrier
+    kernels at 96 workgroups (two concurrent 192-workgroup grids cannot both be resident on 256 CUs; on the 8-GPU
+    node each rank owns a GPU and runs 192)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop("MBX_NO_BN_ONEPASS", None)
+    os.environ.pop("MBX_AUTOTUNE", None)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    from multibox_amd import priors as PR
+    from multibox_amd.synth import DEFAULT_ASPECT_RATIOS
+    pri = np.array(PR.generate_priors(DEFAULT_ASPECT_RATIOS[5]), np.float32)
+    net = Net(batch=4, input_size=299, k=5, mode="train", seed=13 + rank, bn_max_workgroups=96)   # different seeds:
+    tr = Trainer(net, pri, max_num_bboxes=13, use_graph=True, process_group=dist.group.WORLD)      # broadcast fixes it
+    tr.broadcast_parameters(src=0)
+    n_onepass = sum(1 for op in net.convs if getattr(op, "bn_ws_off", -1) >= 0)
+    tr.set_batch(*_batch(torch, rank))
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    healthy = True
+    try:
+        tr.check_health()
+    except RuntimeError:
+        healthy = False
+    torch.save({"W": net.W.cpu(), "Bt": net.Bt.cpu(), "Wg": net.Wg.cpu(), "loss": tr.losses(), "healthy": healthy,
+                "timeouts": net.barrier_timeouts(), "onepass_layers": n_onepass}, os.path.join(out_dir, "s_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shipped_configuration(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    g.build()
+    ctx = mp.get_context("spawn")
+    port = 30700 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker_shipped, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(900)
+        assert p.exitcode == 0
+    r0, r1 = torch.load(tmp_path / "s_rank0.pt"), torch.load(tmp_path / "s_rank1.pt")
+    assert r0["onepass_layers"] > 100                                   # the one-launch BN backward really ran
+    assert r0["healthy"] and r1["healthy"] and r0["timeouts"] == 0 and r1["timeouts"] == 0
+    # three steps on: all-reduced gradients and weights identical on both ranks, bit for bit
+    assert torch.equal(r0["Wg"], r1["Wg"]) and torch.equal(r0["W"], r1["W"]) and torch.equal(r0["Bt"], r1["Bt"])
+    assert bool(torch.isfinite(r0["W"]).all()) and all(np.isfinite(x) for x in r0["loss"])
+    assert r0["loss"][:2] != r1["loss"][:2]

@@ -116,3 +116,35 @@ def test_generate_aspect_ratios_matches_reference_golden():
         assert np.allclose(out, g[key], rtol=1e-6), (out, g[key])      # same order: membership count, largest first
     # the warped clusters are the ones the dataset was built from
     assert np.allclose(sorted(g["expected_warp"]), [0.5, 1.0, 2.0, 3.5], rtol=0.01)
+
+
+def test_trainable_scopes_ranges():
+    """--trainable_scopes (train.py:152-171): variables are selected by re.match of the scope on their name; the
+    optimiser ranges cover the whole trainable part of the flat buffers exactly once."""
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer
+    net = Net(batch=1, input_size=299, k=5, mode="train", device="cpu")
+    tr = Trainer.__new__(Trainer)
+    tr.net, tr.w_lo, tr.bt_lo = net, 0, 0
+    assert tr._optimizer_ranges(None) == [("W", 0, net.nW, 1), ("Bt", 0, net.nBt, 1)]
+    r = tr._optimizer_ranges(["Multibox", "InceptionResnetV2/Repeat_2/block8_9"])
+    for buf, n in (("W", net.nW), ("Bt", net.nBt)):
+        rr = [x for x in r if x[0] == buf]
+        assert rr[0][1] == 0 and rr[-1][2] == n and all(a[2] == b[1] for a, b in zip(rr, rr[1:]))
+        assert all(a[3] != b[3] for a, b in zip(rr, rr[1:]))                       # merged
+    names = set(tr.trainable_names)
+    assert all(n.startswith("Multibox") or n.startswith("InceptionResnetV2/Repeat_2/block8_9") for n in names)
+    assert "Multibox/8x8/Conv/weights" in names and "InceptionResnetV2/Repeat_2/block8_9/Conv2d_1x1/biases" in names
+    assert "Multibox/8x8/Conv/BatchNorm/moving_mean" not in names                 # not a trainable variable
+    # every selected variable lies in an 'on' range, every other one in an 'off' range
+    for name, (buf, off, shape, cpad) in net.param_index.items():
+        if buf not in ("W", "Bt"):
+            continue
+        on = [x[3] for x in r if x[0] == buf and x[1] <= off < x[2]]
+        assert on == [int(name in names)], name
+    # --fine_tune restricts the candidates to the detection heads first (train.py:229-232)
+    tr.w_lo, tr.bt_lo = net.head_w_start, net.head_bt_start
+    r = tr._optimizer_ranges(["InceptionResnetV2"])
+    assert all(x[3] == 0 for x in r) and tr.trainable_names == []

@@ -3,10 +3,11 @@
 same priors.pkl; the step runs on libmbx (one process per GPU; launch with torch.distributed.run
 for data parallelism).
 
-`--tfrecords` reads the reference's TFRecords (inputs.py:225-247) through multibox_amd/inputs.py WITHOUT the
-random augmentations (set DO_RANDOM_BBOX_SHIFT / DO_RANDOM_CROP / DO_COLOR_DISTORTION to 0; the seeded flip is
-supported) -- SURVEY 8f F1, first cut; `--synthetic` feeds seeded synthetic batches of the same input contract
-(inputs.py:340-351).  --pretrained_model takes one of this build's .pt files or a TensorFlow V1 checkpoint (multibox_amd/tf_checkpoint.py, F2)."""
+`--tfrecords` reads the reference's TFRecords (inputs.py:225-247) through multibox_amd/inputs.py, augmentations
+included (bbox shift, distorted crop, random resize method, colour distortion, flip: inputs.py:44-203) -- SURVEY 8f F1;
+`--synthetic` feeds seeded synthetic batches of the same input contract (inputs.py:340-351).  Under
+torch.distributed.run BATCH_SIZE is the per-GPU batch: gradients are summed over ranks (the reference loss is a batch
+sum), so the learning-rate schedule counts BATCH_SIZE * world images per step.  --pretrained_model takes one of this build's .pt files or a TensorFlow V1 checkpoint (multibox_amd/tf_checkpoint.py, F2)."""
 import argparse
 import json
 import os
@@ -61,14 +62,12 @@ def main():
         raise SystemExit("give --tfrecords FILE... or --synthetic")
     if args.pretrained_model and not os.path.exists(args.pretrained_model):
         raise SystemExit("pretrained model not found: %s" % args.pretrained_model)
-    if args.trainable_scopes:
-        raise SystemExit("--trainable_scopes is not supported yet (train.py:152-171)")
     torch.cuda.set_device(local_rank)
     pg = None
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = torch.distributed.group.WORLD
-    if rank == 0:
+    if local_rank == 0:                       # one build per node (the .so lives in the node's copy of the tree)
         g.build()
     if world > 1:
         torch.distributed.barrier()
@@ -78,10 +77,14 @@ def main():
               bn_max_workgroups=192 if world > 1 else 0)
     tr = Trainer(net, bbox_priors, max_num_bboxes=cfg.MAX_NUM_BBOXES, location_loss_alpha=cfg.LOCATION_LOSS_ALPHA,
                  initial_learning_rate=cfg.INITIAL_LEARNING_RATE,
-                 decay_steps_=decay_steps(cfg.NUM_TRAIN_EXAMPLES, cfg.BATCH_SIZE, cfg.NUM_EPOCHS_PER_DELAY),
+                 decay_steps_=decay_steps(cfg.NUM_TRAIN_EXAMPLES, cfg.BATCH_SIZE * world, cfg.NUM_EPOCHS_PER_DELAY),
                  learning_rate_decay_factor=cfg.LEARNING_RATE_DECAY_FACTOR, staircase=cfg.LEARNING_RATE_STAIRCASE,
                  rmsprop_decay=cfg.RMSPROP_DECAY, rmsprop_momentum=float(cfg.RMSPROP_MOMENTUM), rmsprop_epsilon=cfg.RMSPROP_EPSILON,
-                 moving_average_decay=cfg.MOVING_AVERAGE_DECAY, process_group=pg)
+                 moving_average_decay=cfg.MOVING_AVERAGE_DECAY, process_group=pg, trainable_scopes=args.trainable_scopes)
+    if args.trainable_scopes and rank == 0:       # train.py:166-169
+        print("Trainable Variables")
+        for name in tr.trainable_names:
+            print(name)
     latest = CK.latest_checkpoint(args.logdir)                    # slim.learning.train resumes from logdir
     if latest and latest.endswith(".pt"):
         CK.restore_for_training(latest, tr)
@@ -93,6 +96,7 @@ def main():
                                    restore_moving_averages=args.restore_moving_averages)
         if rank == 0:
             print("Initialised from %s" % ck)
+    tr.broadcast_parameters(src=0)                # every rank starts from rank 0's variables, slots and shadows
     t_save = t_log = time.time()
     log = open(os.path.join(args.logdir, "train_log.jsonl"), "a") if rank == 0 and (os.makedirs(args.logdir, exist_ok=True) or True) else None
     step0 = tr.global_step
@@ -103,17 +107,32 @@ def main():
         real = train_batches(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_epochs=None,
                              seed=int(cfg.get("RANDOM_SEED", 1)) + rank, shuffle=True,                   # train.py:214-225
                              capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)))
+    def next_real():
+        # an exhausted / empty file shard on ONE rank must stop every rank, not leave the others in all_reduce
+        try:
+            b = next(real)
+        except StopIteration:
+            b = None
+        if world > 1:
+            ok = torch.tensor([int(b is not None)], dtype=torch.int32, device="cuda")
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok) == 0:
+                b = None
+        if b is None:
+            raise SystemExit("input exhausted on at least one rank at step %d" % tr.global_step)
+        return b
+
     while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
         if real is not None:
-            images, gt, n, _ = next(real)
+            images, gt, n, _ = next_real()
         else:
             images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
         tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
         tr.step()
+        if tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
+            tr.check_health()        # every rank: matching status (py_func error -> abort, loss.py:82) + barrier timeouts
         if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
             loc, conf, reg, total = tr.losses()
-            if int(tr.match_status().max()) != 0:
-                raise RuntimeError("bipartite matching failed (non-finite predictions)")     # py_func error -> abort, loss.py:82
             now = time.time()
             ips = cfg.BATCH_SIZE * world * (tr.global_step - step0) / (now - t_log) if now > t_log else 0.0
             rec = dict(global_step=tr.global_step, total_loss=total, location_loss=loc, confidence_loss=conf,
