@@ -155,6 +155,10 @@ typedef struct {
                            the narrow tile (64 output channels per block): 8 waves x 256 / 192, 9 / 10 = 4 waves x 512 / 768;
                            11 = un-split (one block per output tile: every dw element is added to once, so the
                            result is bit-reproducible from run to run -- the MBX_DETERMINISTIC debug mode). */
+  /* accumulate != 0: y = result + OLD, where OLD is read from acc_src (same shape as y) if it is not NULL, else
+     from y itself.  Lets the residual trunk gradient of model.py:21 be built out of place, G[i-1] = G[i] + dgrad,
+     so that G[i] survives for the deferred weight gradient of block i's 1x1 "up" convolution.          */
+  const void* acc_src; int64_t acc_img_stride; int32_t ld_acc;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 
@@ -168,6 +172,31 @@ int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
  * may be NULL) accumulates sum dy for a bias gradient.                                     */
 int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const void* dy,
                    int64_t dy_img_stride, int32_t ld_dy, float* dw, float* db, mbx_stream_t stream);
+
+/* GROUPED weight gradient: the weight gradients of many layers (a whole backward segment) in ONE launch.  dW is
+ * only consumed by the optimiser, so the caller keeps each layer's dy alive and defers the weight gradients to the
+ * end of a segment: the launch walks a table of work items (layer, output tile, pixel range) built once by
+ * mbx_wgrad_plan.  With hundreds of tiles in flight a tile's pixel reduction is split across blocks only when it
+ * is longer than a fair share of one CU's work, so most dw elements have a single adder; flag
+ * MBX_WGRAD_DETERMINISTIC forbids every split (bit-reproducible dw).  Semantics per job = mbx_conv_wgrad_scaled.
+ * mbx_wgrad_plan writes a HOST image of mbx_wgrad_plan_bytes() bytes; copy it to 16-byte aligned device memory
+ * once and pass that pointer to every launch.  The image embeds the jobs' device pointers.                    */
+typedef struct {
+  mbx_conv_desc desc;      /* x, geometry, C_out as for mbx_conv_wgrad */
+  const void* dy; int64_t dy_img_stride; int32_t ld_dy;
+  float scale;             /* multiplies this job's dw / db contributions */
+  float* dw; float* db;    /* float32, ACCUMULATED (zero first); db may be NULL */
+} mbx_wgrad_job;
+typedef struct {
+  int32_t n_layers, n_items;
+  int64_t layers_off, items_off;   /* byte offsets of the two tables inside the image */
+  double flops;                    /* 2 * M * C_out * R*S*C_in summed over the jobs */
+} mbx_wgrad_plan_info;
+#define MBX_WGRAD_DETERMINISTIC 1
+size_t mbx_wgrad_plan_bytes(const mbx_wgrad_job* jobs /*HOST*/, int n_jobs, int flags);
+int mbx_wgrad_plan(const mbx_wgrad_job* jobs /*HOST*/, int n_jobs, int flags, void* host_image, size_t bytes,
+                   mbx_wgrad_plan_info* info /*HOST, out*/);
+int mbx_conv_wgrad_grouped(const void* device_image, const mbx_wgrad_plan_info* info /*HOST*/, mbx_stream_t stream);
 
 /* Scalars on the dgrad/wgrad path: mbx_conv multiplies the accumulator by `rscale` when
  * epilogue == MBX_EPI_STORE and rscale != 0 (the residual branch scale of model.py:21 on the

@@ -42,6 +42,9 @@ _SIGS = {
     "mbx_conv": (I, [P, P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
     "mbx_conv_wgrad_scaled": (I, [P, P, C.c_int64, I, F, P, P, P]),
+    "mbx_wgrad_plan_bytes": (SZ, [P, I, I]),
+    "mbx_wgrad_plan": (I, [P, I, I, P, SZ, P]),
+    "mbx_conv_wgrad_grouped": (I, [P, P, P]),
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),

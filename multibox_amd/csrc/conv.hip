@@ -12,6 +12,7 @@
 // by LDS-DMA, one barrier per 64-deep K step, two tiles of global latency in flight.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct ConvK {
   int epi, relu, accumulate;
   const float* scale; const float* shiftv;
   const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
+  const unsigned short* acc_src; int acc_img_stride, ld_acc;      // accumulate: OLD value read from here (may alias y)
   float* stats;
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
@@ -344,7 +346,7 @@ conv_igemm3_kernel(const ConvK p) {
         }
         if constexpr (EV == 2) {
           if (p.accumulate) {
-            const u32x4 old = *reinterpret_cast<const u32x4*>(yp);
+            const u32x4 old = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
             const unsigned w[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
@@ -435,24 +437,19 @@ struct WgradK2 {
 // LIN: x and dy rows are both contiguous in the pixel index (1x1 convs on dense views): offsets are m * ld, no
 // (image, row, column) bookkeeping -- compile-time, like the pointwise mode of the igemm kernel.
 // BIAS: the bias gradient (column sums of dy) rides along -- only the residual "up" convs have a bias.
+// The block's work is given by the caller: output tile (tile_n, tile_k) and pixel range [blk_begin, blk_end) -- from
+// blockIdx for the one-layer launch, from a work-item table for the grouped launch (conv_wgrad_grouped_kernel).
 template <int NST, int NG, bool LIN, bool BIAS>
-__global__ void __launch_bounds__(kThreads * NG)
-conv_wgrad2_kernel(const WgradK2 q) {
+__device__ __forceinline__ void wgrad_wide_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
+                                                const int blk_begin, const int blk_end) {
   const WgradK& p = q.b;
-  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];     // [NST][Y 64x16 | X 64x16] slots
-  constexpr int STAGE = 2 * 64 * 16;
+  constexpr int STAGE = 2 * 64 * 16;                              // smem: [NST][Y 64x16 | X 64x16] slots
   const int lane = threadIdx.x & 63;
   const int wave8 = wave_id();
   const int grp = NG == 2 ? (wave8 >> 2) : 0, wave = wave8 & 3;
   const int tid = threadIdx.x & 255;                   // thread index inside its 4-wave group
   const int wn = wave & 1, wk = wave >> 1;
-  const int ntiles = p.tiles_n * p.tiles_k;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = lid % ntiles, split = lid / ntiles;
-  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
-  const int blk_begin = split * p.m_per_split;
-  const int blk_end = min(p.M, blk_begin + p.m_per_split);
   // group 0 takes the first half of the block's pixels (rounded up to 64), group 1 the rest
   const int half = NG == 2 ? ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63) : (blk_end - blk_begin);
   const int m_begin = blk_begin + grp * half;
@@ -617,23 +614,16 @@ conv_wgrad2_kernel(const WgradK2 q) {
 // Half the tile for the same grid means every block covers twice the pixels: half the fp32 atomics per launch, and
 // channel counts like 32 / 48 / 64 / 160 / 192 / 320 / 1088 stop padding a 128-wide tile.  dy must be pixel-dense.
 template <int NST, int NG, bool LIN, bool BIAS>
-__global__ void __launch_bounds__(kThreads * NG)
-conv_wgrad2n_kernel(const WgradK2 q) {
+__device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
+                                                  const int blk_begin, const int blk_end) {
   const WgradK& p = q.b;
-  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];     // [NST][Y 64x8 | X 64x16] slots
-  constexpr int STAGE = 64 * 8 + 64 * 16;
+  constexpr int STAGE = 64 * 8 + 64 * 16;                         // smem: [NST][Y 64x8 | X 64x16] slots
   const int lane = threadIdx.x & 63;
   const int wave8 = wave_id();
   const int grp = NG == 2 ? (wave8 >> 2) : 0, wave = wave8 & 3;
   const int tid = threadIdx.x & 255;                   // thread index inside its 4-wave group
   const int wn = wave & 1, wk = wave >> 1;
-  const int ntiles = p.tiles_n * p.tiles_k;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = lid % ntiles, split = lid / ntiles;
-  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
   const int n0 = tile_n * 64, k0 = tile_k * 128;
-  const int blk_begin = split * p.m_per_split;
-  const int blk_end = min(p.M, blk_begin + p.m_per_split);
   // group 0 takes the first half of the block's pixels (rounded up to 64), group 1 the rest
   const int half = NG == 2 ? ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63) : (blk_end - blk_begin);
   const int m_begin = blk_begin + grp * half;
@@ -804,6 +794,56 @@ conv_wgrad2n_kernel(const WgradK2 q) {
 }
 
 
+template <int NST, int NG, bool LIN, bool BIAS>
+__global__ void __launch_bounds__(kThreads * NG)
+conv_wgrad2_kernel(const WgradK2 q) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  const WgradK& p = q.b;
+  const int ntiles = p.tiles_n * p.tiles_k;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles, split = lid / ntiles;
+  const int blk_begin = split * p.m_per_split;
+  wgrad_wide_body<NST, NG, LIN, BIAS>(q, smem, tile % p.tiles_n, tile / p.tiles_n, blk_begin, min(p.M, blk_begin + p.m_per_split));
+}
+
+template <int NST, int NG, bool LIN, bool BIAS>
+__global__ void __launch_bounds__(kThreads * NG)
+conv_wgrad2n_kernel(const WgradK2 q) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  const WgradK& p = q.b;
+  const int ntiles = p.tiles_n * p.tiles_k;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles, split = lid / ntiles;
+  const int blk_begin = split * p.m_per_split;
+  wgrad_narrow_body<NST, NG, LIN, BIAS>(q, smem, tile % p.tiles_n, tile / p.tiles_n, blk_begin, min(p.M, blk_begin + p.m_per_split));
+}
+
+// ------------------------------------------------------------------------------------------
+// GROUPED weight gradient: ONE launch for the weight gradients of many layers (a whole backward segment).
+// The weight gradient is off the critical path of the backward pass (only the optimiser consumes dW), so the engine
+// keeps every layer's dy and runs them together: the grid is a table of work items (layer, output tile, pixel
+// range), longest first.  With hundreds of tiles from dozens of layers in flight, a tile's pixel reduction is
+// split across blocks only when it is longer than a fair share of one CU's work: most tiles have ONE adder
+// (no atomic traffic to speak of, bit-reproducible), loops run for hundreds of steps instead of a dozen, and
+// there is one launch tail per segment instead of one per layer.
+struct WgradLayer { WgradK2 q; int narrow, lin, pad0, pad1; };
+struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, pad0, pad1, pad2; };
+
+__global__ void __launch_bounds__(kThreads * 2)
+conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem* __restrict__ items) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  const WgradItem it = items[blockIdx.x];              // block-uniform: scalar loads
+  const WgradLayer& L = layers[it.layer];
+  const WgradK2 q = L.q;
+  if (L.narrow) {
+    if (L.lin) wgrad_narrow_body<2, 2, true, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+    else wgrad_narrow_body<2, 2, false, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+  } else {
+    if (L.lin) wgrad_wide_body<2, 2, true, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+    else wgrad_wide_body<2, 2, false, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
@@ -961,6 +1001,13 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   k.skip = reinterpret_cast<const unsigned short*>(d->skip);
   k.skip_img_stride = (int)d->skip_img_stride; k.ld_skip = d->ld_skip; k.rscale = d->rscale;
   k.stats = d->stats_partial;
+  if (d->accumulate && d->acc_src) {
+    if (d->ld_acc % 8 || (reinterpret_cast<uintptr_t>(d->acc_src) & 15) || (long long)d->N * d->acc_img_stride >= (1LL << 31))
+      return MBX_ERR_INVALID_ARG;
+    k.acc_src = reinterpret_cast<const unsigned short*>(d->acc_src); k.acc_img_stride = (int)d->acc_img_stride; k.ld_acc = d->ld_acc;
+  } else {
+    k.acc_src = reinterpret_cast<const unsigned short*>(d->y); k.acc_img_stride = (int)d->y_img_stride; k.ld_acc = d->ldy;
+  }
   set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
@@ -1000,15 +1047,15 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   }
 }
 
-extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
-                                     float scale, float* dw, float* db, mbx_stream_t stream) {
+// Geometry / pointers of one layer's weight gradient (shared by the one-layer launch and the grouped plan).
+static int fill_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy, float scale,
+                      float* dw, float* db, WgradK2& k2) {
   int st = check_desc(d);
   if (st != MBX_OK) return st;
   if (!dy || !dw || d->transposed) return MBX_ERR_INVALID_ARG;
   if (ld_dy % 8 || ld_dy < ((d->C_out + 7) / 8) * 8 || (reinterpret_cast<uintptr_t>(dy) & 15)) return MBX_ERR_INVALID_ARG;
   if ((long long)d->N * dy_img_stride >= (1LL << 30)) return MBX_ERR_UNSUPPORTED;
-  MBX_ENTER();
-  WgradK k;
+  WgradK& k = k2.b;
   k.x = reinterpret_cast<const unsigned short*>(d->x);
   k.x_img_stride = (int)d->x_img_stride; k.ldx = d->ldx; k.H_in = d->H_in; k.W_in = d->W_in; k.C_in = d->C_in;
   k.dy = reinterpret_cast<const unsigned short*>(dy); k.dy_img_stride = (int)dy_img_stride; k.ld_dy = ld_dy;
@@ -1016,10 +1063,30 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l; k.W_out = d->W_out; k.HW_out = d->H_out * d->W_out;
   k.M = d->N * k.HW_out;
   k.dw = dw; k.db = db; k.scale = scale;
-  // tile_config 7 / 8: the narrow tile (64 output channels per block; eight waves, 256 / 192 blocks); needs dense dy
-  const bool narrow = d->tile_config >= 7 && d->tile_config <= 10 && dy_img_stride == (int64_t)d->H_out * d->W_out * ld_dy;
-  k.tiles_n = narrow ? (k.C_out + 63) / 64 : (k.C_out + 127) / 128;
+  set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
+  set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
+  k.H_out = d->H_out;
+  k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
+  k.dy_bytes = (unsigned)(2 * ((long long)(d->N - 1) * dy_img_stride + ((long long)k.HW_out - 1) * ld_dy + ((d->C_out + 7) / 8) * 8));
+  k.tiles_n = (k.C_out + 127) / 128;
   k.tiles_k = (k.Ktot + 127) / 128;
+  k.m_per_split = k.M;
+  k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
+           d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
+  k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
+  return MBX_OK;
+}
+
+extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int64_t dy_img_stride, int32_t ld_dy,
+                                     float scale, float* dw, float* db, mbx_stream_t stream) {
+  WgradK2 k2;
+  int st = fill_wgrad(d, dy, dy_img_stride, ld_dy, scale, dw, db, k2);
+  if (st != MBX_OK) return st;
+  MBX_ENTER();
+  WgradK& k = k2.b;
+  // tile_config 7 / 8: the narrow tile (64 output channels per block; eight waves, 256 / 192 blocks); needs dense dy
+  const bool narrow = d->tile_config >= 7 && d->tile_config <= 10 && k2.ydense;
+  k.tiles_n = narrow ? (k.C_out + 63) / 64 : (k.C_out + 127) / 128;
   const int tiles = k.tiles_n * k.tiles_k;
   // split the pixel reduction so that ~2 blocks per CU exist, at least 256 pixels per split
   static int env_ng = 0, env_target = 0;
@@ -1054,23 +1121,7 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
   mps = ((mps + 63) / 64) * 64;
   splits = (k.M + mps - 1) / mps;
   k.m_per_split = mps;
-  auto magic = [](unsigned d, unsigned& mg, unsigned& sh) {
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    sh = 31 + l;
-    mg = (unsigned)((1ull << sh) / d + 1);
-  };
-  magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
-  magic((unsigned)k.W_out, k.mg_w, k.sh_w);
-  k.H_out = d->H_out;
-  k.x_bytes = (unsigned)(2 * ((long long)(d->N - 1) * d->x_img_stride + ((long long)d->H_in * d->W_in - 1) * d->ldx + d->C_in));
-  k.dy_bytes = (unsigned)(2 * ((long long)(d->N - 1) * dy_img_stride + ((long long)k.HW_out - 1) * ld_dy + ((d->C_out + 7) / 8) * 8));
   {
-    WgradK2 k2;
-    k2.b = k;
-    k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
-             d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
-    k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
     const bool lin = k2.pw && k2.ydense, bias = db != nullptr;
     const dim3 grid(tiles * splits);
     if (narrow) {
@@ -1119,6 +1170,146 @@ extern "C" int mbx_conv_wgrad_scaled(const mbx_conv_desc* d, const void* dy, int
 #undef MBX_WG_NG
 #undef MBX_WG
   }
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+// ------------------------------------------------------------------------------------ grouped weight gradient
+// Host-side plan: [WgradLayer x n_jobs | WgradItem x n_items] image that the caller copies to device memory once.
+static int plan_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n;
+    else
+      ncu = 256;                       // no device visible (planning on a CPU-only host): MI355X
+  }
+  return ncu;
+}
+
+struct PlanJob { int narrow, tiles_n, tiles_k, steps, splits; };
+
+static int plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, PlanJob* pj, long long* n_items_out) {
+  // work unit: one 64-pixel step of one tile.  A tile is split only when it is longer than a quarter of a CU's fair
+  // share of the whole group (and never below 16 steps per piece): most tiles keep a single adder.
+  double total = 0.0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const mbx_conv_desc& d = jobs[j].desc;
+    const long long M = (long long)d.N * d.H_out * d.W_out;
+    const int Ktot = d.R * d.S * d.C_in;
+    const bool dense = jobs[j].dy_img_stride == (int64_t)d.H_out * d.W_out * jobs[j].ld_dy;
+    // narrow (64-channel) tile only where the 128-wide one would be at least half padding: per 64-pixel step a wide
+    // tile stages 128 + 128 rows, a narrow one 64 + 128, so ceil(C/128) * 256 <= ceil(C/64) * 192 unless C_out <= 64
+    pj[j].narrow = (d.C_out <= 64 && dense) ? 1 : 0;
+    pj[j].tiles_n = pj[j].narrow ? (d.C_out + 63) / 64 : (d.C_out + 127) / 128;
+    pj[j].tiles_k = (Ktot + 127) / 128;
+    pj[j].steps = (int)((M + 63) / 64);
+    total += (double)pj[j].tiles_n * pj[j].tiles_k * pj[j].steps;
+  }
+  const double share = total / plan_cus();
+  double wmax = share / 4.0;
+  if (wmax < 16.0) wmax = 16.0;
+  long long n_items = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    int splits = (flags & MBX_WGRAD_DETERMINISTIC) ? 1 : (int)((pj[j].steps + wmax - 1) / wmax);
+    const int max_splits = (pj[j].steps + 15) / 16;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    pj[j].splits = splits;
+    n_items += (long long)pj[j].tiles_n * pj[j].tiles_k * splits;
+  }
+  *n_items_out = n_items;
+  return MBX_OK;
+}
+
+extern "C" size_t mbx_wgrad_plan_bytes(const mbx_wgrad_job* jobs, int n_jobs, int flags) {
+  if (!jobs || n_jobs <= 0) return 0;
+  PlanJob* pj = (PlanJob*)malloc(sizeof(PlanJob) * n_jobs);
+  if (!pj) return 0;
+  long long n_items = 0;
+  plan_jobs(jobs, n_jobs, flags, pj, &n_items);
+  free(pj);
+  return sizeof(WgradLayer) * (size_t)n_jobs + sizeof(WgradItem) * (size_t)n_items;
+}
+
+extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, void* host_image, size_t bytes,
+                              mbx_wgrad_plan_info* info) {
+  if (!jobs || n_jobs <= 0 || !host_image || !info) return MBX_ERR_INVALID_ARG;
+  PlanJob* pj = (PlanJob*)malloc(sizeof(PlanJob) * n_jobs);
+  if (!pj) return MBX_ERR_WORKSPACE;
+  long long n_items = 0;
+  plan_jobs(jobs, n_jobs, flags, pj, &n_items);
+  const size_t need = sizeof(WgradLayer) * (size_t)n_jobs + sizeof(WgradItem) * (size_t)n_items;
+  if (bytes < need || n_items >= (1LL << 31)) { free(pj); return MBX_ERR_WORKSPACE; }
+  WgradLayer* layers = reinterpret_cast<WgradLayer*>(host_image);
+  WgradItem* items = reinterpret_cast<WgradItem*>(layers + n_jobs);
+  double flops = 0.0;
+  // jobs ordered longest tile first, so that the long items are dispatched first and the short ones fill the tail
+  int* order = (int*)malloc(sizeof(int) * n_jobs);
+  if (!order) { free(pj); return MBX_ERR_WORKSPACE; }
+  for (int j = 0; j < n_jobs; ++j) order[j] = j;
+  for (int a = 1; a < n_jobs; ++a) {               // insertion sort, descending steps per piece (stable)
+    const int v = order[a];
+    const double wv = (double)pj[v].steps / pj[v].splits;
+    int b = a - 1;
+    while (b >= 0 && (double)pj[order[b]].steps / pj[order[b]].splits < wv) { order[b + 1] = order[b]; --b; }
+    order[b + 1] = v;
+  }
+  long long it = 0;
+  int status = MBX_OK;
+  for (int j = 0; j < n_jobs && status == MBX_OK; ++j) {
+    const mbx_wgrad_job& J = jobs[j];
+    WgradLayer& L = layers[j];
+    memset(&L, 0, sizeof(L));
+    status = fill_wgrad(&J.desc, J.dy, J.dy_img_stride, J.ld_dy, J.scale, J.dw, J.db, L.q);
+    if (status != MBX_OK) break;
+    L.narrow = pj[j].narrow;
+    L.lin = (L.q.pw && L.q.ydense) ? 1 : 0;
+    L.q.b.tiles_n = pj[j].tiles_n;
+    flops += 2.0 * L.q.b.M * (double)L.q.b.C_out * L.q.b.Ktot;
+  }
+  for (int o = 0; o < n_jobs && status == MBX_OK; ++o) {
+    const int j = order[o];
+    const int M = layers[j].q.b.M;
+    int mps = (M + pj[j].splits - 1) / pj[j].splits;
+    mps = ((mps + 63) / 64) * 64;
+    for (int sp = 0; sp * (long long)mps < M; ++sp)
+      for (int tk = 0; tk < pj[j].tiles_k; ++tk)
+        for (int tn = 0; tn < pj[j].tiles_n; ++tn) {
+          WgradItem& I = items[it++];
+          memset(&I, 0, sizeof(I));
+          I.layer = j; I.tile_n = tn; I.tile_k = tk;
+          I.m_begin = sp * mps;
+          I.m_end = (sp + 1) * (long long)mps < M ? (sp + 1) * mps : M;
+        }
+  }
+  free(order);
+  free(pj);
+  if (status != MBX_OK) return status;
+  info->n_layers = n_jobs;
+  info->n_items = (int32_t)it;                       // <= the bound used for the byte count
+  info->layers_off = 0;
+  info->items_off = (int64_t)(sizeof(WgradLayer) * (size_t)n_jobs);
+  info->flops = flops;
+  return MBX_OK;
+}
+
+extern "C" int mbx_conv_wgrad_grouped(const void* device_image, const mbx_wgrad_plan_info* info, mbx_stream_t stream) {
+  if (!device_image || !info || info->n_items <= 0 || info->n_layers <= 0) return MBX_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(device_image) & 15) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  static bool attr = false;
+  constexpr int kLds = 2 * 2 * 32768;                 // two wave groups x two stages x (16 KB dy + 16 KB x)
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_grouped_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    attr = true;
+  }
+  const char* base = reinterpret_cast<const char*>(device_image);
+  hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3(info->n_items), dim3(2 * kThreads), kLds, mbx_s(stream),
+                     reinterpret_cast<const WgradLayer*>(base + info->layers_off),
+                     reinterpret_cast<const WgradItem*>(base + info->items_off));
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

@@ -29,7 +29,20 @@ class ConvDesc(C.Structure):
         ("skip", C.c_void_p), ("skip_img_stride", C.c_int64), ("ld_skip", C.c_int32), ("rscale", C.c_float),
         ("stats_partial", C.c_void_p),
         ("tile_config", C.c_int32),
+        ("acc_src", C.c_void_p), ("acc_img_stride", C.c_int64), ("ld_acc", C.c_int32),
     ]
+
+
+class WgradJob(C.Structure):
+    """mbx_wgrad_job (include/mbx.h)."""
+    _fields_ = [("desc", ConvDesc), ("dy", C.c_void_p), ("dy_img_stride", C.c_int64), ("ld_dy", C.c_int32),
+                ("scale", C.c_float), ("dw", C.c_void_p), ("db", C.c_void_p)]
+
+
+class WgradPlanInfo(C.Structure):
+    """mbx_wgrad_plan_info (include/mbx.h)."""
+    _fields_ = [("n_layers", C.c_int32), ("n_items", C.c_int32), ("layers_off", C.c_int64), ("items_off", C.c_int64),
+                ("flops", C.c_double)]
 
 
 class View:
@@ -83,7 +96,7 @@ def _p(t):
 
 
 def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed=0, epilogue=EPI_STORE, relu=0,
-              accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None):
+              accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None, acc_src: View = None):
     d = ConvDesc()
     d.x, d.x_img_stride, d.ldx = x.ptr, x.img_stride, x.ld
     d.N, d.H_in, d.W_in, d.C_in = x.N, x.H, x.W, x.C
@@ -97,6 +110,8 @@ def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed
         d.skip, d.skip_img_stride, d.ld_skip = skip.ptr, skip.img_stride, skip.ld
     d.rscale = float(rscale)
     d.stats_partial = _p(stats)
+    if acc_src is not None:
+        d.acc_src, d.acc_img_stride, d.ld_acc = acc_src.ptr, acc_src.img_stride, acc_src.ld
     return d
 
 
@@ -206,3 +221,27 @@ def autotune_wgrad(desc: ConvDesc, dy: View, scale, dw, db, key, candidates=(0, 
     desc.tile_config = best
     _TUNED[key] = best
     return best
+
+
+class WgradGroup:
+    """One grouped weight-gradient launch (mbx_conv_wgrad_grouped): plan built once from the jobs' descriptors,
+    table image kept in device memory."""
+
+    def __init__(self, jobs, deterministic=False, device="cuda"):
+        l = _lib.lib()
+        self.n = len(jobs)
+        arr = (WgradJob * self.n)(*jobs)
+        flags = 1 if deterministic else 0
+        nbytes = l.mbx_wgrad_plan_bytes(arr, self.n, flags)
+        assert nbytes > 0
+        host = (C.c_uint8 * nbytes)()
+        self.info = WgradPlanInfo()
+        _lib.check(l.mbx_wgrad_plan(arr, self.n, flags, host, nbytes, C.byref(self.info)), "mbx_wgrad_plan")
+        import numpy as np
+        self.host_image = np.frombuffer(host, dtype=np.uint8).copy()
+        self.image = torch.from_numpy(self.host_image).to(device)
+        self.flops = float(self.info.flops)
+
+    def launch(self):
+        _lib.check(_lib.lib().mbx_conv_wgrad_grouped(self.image.data_ptr(), C.byref(self.info), _stream()),
+                   "mbx_conv_wgrad_grouped")
