@@ -92,7 +92,7 @@ def _work_table():
     W = {}
     W["mbx_conv"] = ("igemm", "mfma", lambda a: _conv_flops(a[0]._obj))
     W["mbx_conv_wgrad_scaled"] = ("wgrad", "mfma", lambda a: _conv_flops(a[0]._obj))
-    W["mbx_conv_wgrad_grouped"] = ("wgrad", "mfma", lambda a: float(a[-1]))            # wrapped with its flops appended
+    W["mbx_conv_wgrad_grouped"] = ("wgrad", "mfma", lambda a: float(a[1]._obj.flops))  # mbx_wgrad_plan_info.flops
     W["mbx_bn_apply_fused"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[6] * a[7])
     W["mbx_bn_bwd_onepass"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[4] * a[5])
     W["mbx_bn_bwd_reduce"] = ("bn_bwd", "hbm", lambda a: 4.0 * a[6] * a[7])

@@ -329,14 +329,6 @@ class Net:
     # ------------------------------------------------------------- parameters
     def _finalize(self, seed):
         dev = self.dev
-        # resolve trunk gradient aliases (all trunk tensors of a stage share trunk0's gradient view)
-        self.trunk_grad = {}
-        for op in self.convs:
-            if op.kind == "residual":
-                for v in (op.skip, op.out):
-                    if v.buf is not op.trunk0.buf:
-                        self.trunk_grad[id(v.buf)] = op.trunk0
-
         # flat parameter layout: W = all filters (+ biases), 8-element aligned; Bt = betas; stats
         w_off = bt_off = 0
         self.param_index = {}
@@ -433,7 +425,10 @@ class Net:
                 d = self._desc(op, View(op.y, op.out.N, op.out.H, op.out.W, op.K))
                 max_stats = max(max_stats, max(ops.conv_stats_rows(d), (op.M + 63) // 64) * op.K * 2)     # any tile height
                 if op.trainable:
-                    max_y = max(max_y, op.M * op.K)
+                    # dy of EVERY layer stays alive until the grouped weight-gradient launch at the end of its backward
+                    # segment (3.2 GB at BATCH_SIZE 64: sized for 288 GB of HBM, not for reuse)
+                    op.dy = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)
+                    self._bufs.append(op.dy)
                     max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, op.K) * op.K * 2)
         # one-launch BN backward: per-layer accumulators + arrival counter, zeroed with the gradients every step
         ws_floats = 0
@@ -444,7 +439,6 @@ class Net:
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
-        self.dy_scratch = torch.zeros(max(max_y, 8), dtype=torch.bfloat16, device=dev)
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
         self.m12 = torch.zeros(2 * 2048, dtype=torch.float32, device=dev)
         self.reg_loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -516,24 +510,27 @@ class Net:
 
     # ------------------------------------------------------------------- backward
     def _gview(self, v: View) -> View:
-        """Gradient view for an activation view (trunk tensors of a residual stage share one)."""
-        t0 = self.trunk_grad.get(id(v.buf))
-        if t0 is not None:
-            g = self.grad_of(t0)
-            return View(g.buf, v.N, v.H, v.W, v.C, g.ld, g.ch_off + v.ch_off, 2)
+        """Gradient view for an activation view.  Every trunk tensor of a residual stage has its OWN gradient buffer
+        (G[i-1] = G[i] + dgrad is built out of place, acc_src below), so that G[i] is still intact when the deferred
+        weight gradient of block i's "up" convolution reads it at the end of the segment."""
         return self.grad_of(v)
 
     def _claim(self, g: View):
-        """Build-time bookkeeping: returns accumulate flag for a write into gradient region g."""
+        """Build-time bookkeeping for a write into gradient region g: returns (accumulate flag, acc_src view).  The
+        first writer of a residual block's INPUT gradient adds the block's output gradient (identity path of
+        model.py:21) by reading it from that other buffer."""
         key = (id(g.buf), g.ch_off, g.C)
-        acc = key in self.written
+        if key in self.written:
+            return 1, None
         self.written.add(key)
-        return int(acc)
+        src = self.pending_acc.pop(key, None)
+        return (1, src) if src is not None else (0, None)
 
     def _build_backward(self):
         if self.mode != "train":
             self.fwd_launches = self._build_forward_launches()
             self.bwd_launches = []
+            self.bwd_jobs = []
             return
         l = _lib.lib()
         st = lambda: torch.cuda.current_stream().cuda_stream
@@ -568,22 +565,24 @@ class Net:
                         break
                     if isinstance(c, PoolOp) and c.x.buf is r.out.buf:
                         break
+        self.pending_acc = {}      # gradient region of a residual block's input -> gradient view of its output
         L = []
         self.bwd_ops = []          # the forward op each backward launch belongs to (same order as L)
+        self.bwd_jobs = []         # the deferred weight-gradient job of each backward launch (None for pools)
         for op in reversed(self.fwd):
             if isinstance(op, PoolOp):
                 if op.needs_backward():
                     gx = self._gview(op.x)
-                    acc = self._claim(gx)
+                    acc, src = self._claim(gx)
+                    assert src is None, "a pooling layer cannot be the first writer of a residual block's input gradient"
                     L.append(op.make_backward(self._gview(op.out), gx, acc))
                     self.bwd_ops.append(op)
+                    self.bwd_jobs.append(None)
                 continue
             if not op.trainable:
                 continue
             K, M = op.K, op.M
             dw = self._sl(self.Wg, op.w_off, K * op.R * op.S * op.Cin)
-            wdesc = ops.make_desc(op.x, None, K, op.R, op.S, op.stride, op.pad_t, op.pad_l, View(self.dy_scratch, op.out.N, op.out.H, op.out.W, 8))
-            wdesc.C_out = K
             if op.kind == "head":
                 cells, kk, off = op.head
                 g = View(torch.zeros((M, self.head_ld), dtype=torch.bfloat16, device=self.dev), op.out.N, op.out.H, op.out.W, self.head_ld)
@@ -592,10 +591,10 @@ class Net:
                 pre = lambda s, g=g, cells=cells, kk=kk, off=off: _lib.check(
                     l.mbx_head_scatter(self.d_locs.data_ptr(), self.d_logits.data_ptr(), self.B, cells, kk, self.P, off,
                                        g.buf.data_ptr(), self.head_ld, s), "head_scatter")
-                dy_C = op.kpad if op.need_dx else self.head_ld
             elif op.kind == "residual":
-                gout = self._gview(op.out)          # == gradient of skip (same trunk buffer, in place)
-                self._claim(self._gview(op.skip))
+                gout = self._gview(op.out)          # G[i]: complete (and relu-masked) when this op's backward runs
+                gs = self._gview(op.skip)           # G[i-1] lives in its own buffer: first writer adds G[i] (acc_src)
+                self.pending_acc[(id(gs.buf), gs.ch_off, gs.C)] = gout
                 zb = id(self.grad_of(op.x).buf)     # per-stage branch gradient buffer is reused by every block
                 self.written = {k for k in self.written if k[0] != zb}
                 dyv, scale, db = gout, op.rscale, self._sl(self.Wg, op.b_off, K)
@@ -604,14 +603,13 @@ class Net:
                         l.mbx_relu_mask(gout.ptr, gout.ld, op.out.ptr, op.out.ld, op.M, op.K, s), "relu_mask")
                 else:
                     pre = None
-                dy_C = K
             else:   # bn
                 da = self._gview(op.out)
-                dyv = View(self.dy_scratch, op.out.N, op.out.H, op.out.W, K)
+                dyv = View(op.dy, op.out.N, op.out.H, op.out.W, K)
                 mean, rstd = self._sl(self.bn_mean, op.beta_off, K), self._sl(self.bn_rstd, op.beta_off, K)
                 dbeta = self._sl(self.Btg, op.beta_off, K)
                 rows = l.mbx_bn_bwd_rows(M, K)
-                scale, db, dy_C = 1.0, None, K
+                scale, db = 1.0, None
 
                 beta = self._sl(self.Bt, op.beta_off, K)
 
@@ -619,7 +617,7 @@ class Net:
                     # da and y are read once: the slice stays in registers across a grid barrier
                     _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, int(op.relu), op.y.data_ptr(), M, K, mean.data_ptr(),
                                                     rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
-                                                    self.dy_scratch.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
+                                                    op.dy.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
                                                     self.bn_max_wg, s),
                                "bn_bwd_onepass")
 
@@ -632,40 +630,48 @@ class Net:
                                                      self.m12.data_ptr(), s), "bn_bwd_finalize")
                     _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
-                                                  self.dy_scratch.data_ptr(), s), "bn_bwd_apply")
+                                                  op.dy.data_ptr(), s), "bn_bwd_apply")
                 if op.bn_ws_off >= 0 and not self.no_onepass:
                     pre = pre_onepass
             ddesc = None
             if op.need_dx:
                 gx = self._gview(op.x)
-                acc = self._claim(gx)
+                acc, acc_src = self._claim(gx)
                 dyin = View(dyv.buf, dyv.N, dyv.H, dyv.W, op.kpad, dyv.ld, dyv.ch_off, 2)
                 mr = mask_of.get(id(op))
                 ddesc = ops.make_desc(dyin, self.Wd[op.dgrad_off:], op.Cin, op.R, op.S, op.stride,
                                       op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
-                                      rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None))
+                                      rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None),
+                                      acc_src=acc_src)
                 self._tune(op, ddesc, "dgrad")
 
-            wkey = ("wgrad", op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
-                    dyv.ld, db is not None)
-            self.tune_registry.append((repr(wkey), wdesc, "wgrad"))
-            if self.deterministic:
-                wdesc.tile_config = 11
-            elif self.autotune and int(os.environ.get("MBX_AUTOTUNE_WGRAD", "1")):
-                ops.autotune_wgrad(wdesc, dyv, scale, dw, db, wkey)
+            # the weight gradient is DEFERRED: one grouped launch per backward segment (make_wgrad_groups)
+            job = ops.WgradJob()
+            job.desc = ops.make_desc(op.x, None, K, op.R, op.S, op.stride, op.pad_t, op.pad_l,
+                                     View(dyv.buf, op.out.N, op.out.H, op.out.W, 8, dyv.ld, dyv.ch_off, 2))
+            job.desc.C_out = K
+            job.dy, job.dy_img_stride, job.ld_dy = dyv.ptr, dyv.img_stride, dyv.ld
+            job.scale = float(scale)
+            job.dw, job.db = dw.data_ptr(), (None if db is None else db.data_ptr())
 
-            def run(op=op, pre=pre, wdesc=wdesc, dyv=dyv, scale=scale, dw=dw, db=db, ddesc=ddesc):
+            def run(op=op, pre=pre, ddesc=ddesc):
                 s = st()
                 if pre is not None:
                     pre(s)
-                _lib.check(l.mbx_conv_wgrad_scaled(C.byref(wdesc), dyv.ptr, dyv.img_stride, dyv.ld, float(scale),
-                                                   dw.data_ptr(), None if db is None else db.data_ptr(), s), "wgrad " + op.name)
                 if ddesc is not None:
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
             L.append(run)
             self.bwd_ops.append(op)
+            self.bwd_jobs.append(job)
+        assert not self.pending_acc, "a residual block's input gradient was never written"
         self.bwd_launches = L
         self.fwd_launches = self._build_forward_launches()
+        self._default_groups = None
+
+    def make_wgrad_groups(self, job_lists):
+        """One grouped weight-gradient launch (ops.WgradGroup) per list of jobs; the caller runs each after the
+        backward launches its jobs belong to (Trainer: at the end of every backward segment)."""
+        return [ops.WgradGroup(jobs, deterministic=self.deterministic, device=self.dev) for jobs in job_lists if jobs]
 
     # --------------------------------------------------------------------- running
     def prepare_filters(self):
@@ -760,9 +766,16 @@ class Net:
         self.bn_ws.zero_()          # accumulators / arrival counters of the one-launch BN backward
 
     def backward(self):
-        """d_locs / d_logits must hold the loss gradients; fills Wg / Btg."""
+        """d_locs / d_logits must hold the loss gradients; fills Wg / Btg.  (Eager form: all data-gradient launches,
+        then the deferred weight gradients in four grouped launches; the Trainer interleaves them per segment.)"""
         for f in self.bwd_launches:
             f()
+        if self._default_groups is None:
+            jobs = [j for j in self.bwd_jobs if j is not None]
+            n = max(1, (len(jobs) + 3) // 4)
+            self._default_groups = self.make_wgrad_groups([jobs[i:i + n] for i in range(0, len(jobs), n)])
+        for g in self._default_groups:
+            g.launch()
 
 
 class PoolOp:

@@ -167,34 +167,37 @@ class Trainer:
     # ------------------------------------------------------------------ segments / buckets
     def _make_segments(self, n):
         """Split the backward launch list into n runs of roughly equal parameter count; each run's
-        gradients are one contiguous bucket of Wg (backward order = reverse parameter order)."""
+        gradients are one contiguous bucket of Wg (backward order = reverse parameter order).  Every run ends with
+        ONE grouped weight-gradient launch for its layers (the weight gradients are deferred: ops.WgradGroup)."""
         net = self.net
-        ops_rev = [op for op in reversed(net.fwd)]
-        launches = net.bwd_launches
-        # map launches to ops: bwd_launches was built over reversed(net.fwd) skipping some ops
-        tagged = []
-        it = iter(launches)
+        tagged = list(zip(net.bwd_launches, net.bwd_ops, net.bwd_jobs))
         from .engine import PoolOp
-        for op in ops_rev:
-            if isinstance(op, PoolOp):
-                if op.needs_backward():
-                    tagged.append((next(it), None))
-            elif op.trainable:
-                tagged.append((next(it), op))
         total = net.nW - self.w_lo
         target = max(total // max(n, 1), 1)
-        segs, cur, hi = [], [], net.nW
+        segs, cur, jobs, hi = [], [], [], net.nW
         lo = hi
-        for fn, op in tagged:
+        for fn, op, job in tagged:
             cur.append(fn)
-            if op is not None:
+            if job is not None:
+                jobs.append(job)
+            if not isinstance(op, PoolOp):
                 lo = min(lo, op.w_off)
                 if hi - lo >= target and len(segs) < n - 1:
-                    segs.append((cur, lo, hi))
-                    cur, hi = [], lo
+                    segs.append((cur, lo, hi, jobs))
+                    cur, jobs, hi = [], [], lo
         if cur:
-            segs.append((cur, self.w_lo, hi))
-        return segs
+            segs.append((cur, self.w_lo, hi, jobs))
+        out = []
+        on_gpu = torch.device(net.dev).type == "cuda"
+        groups = net.make_wgrad_groups([j for _, _, _, j in segs]) if on_gpu else []
+        self.wgrad_groups = groups
+        gi = 0
+        for fns, lo, hi, jobs in segs:
+            if jobs and on_gpu:
+                fns = fns + [groups[gi].launch]
+                gi += 1
+            out.append((fns, lo, hi))
+        return out
 
     # ---------------------------------------------------------------------------- step
     def _front(self):

@@ -289,3 +289,63 @@ def test_conv_full_size_b64(T, g):
     ops.conv_wgrad(ops.make_desc(xb, None, Co, R, S, st, pads[0], pads[1], yb), dyb, dw)
     ok, msg = close(torch, dw, wr.grad, f32=True)
     assert ok, "wgrad: " + msg
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_wgrad_grouped_matches_reference_and_single_layer_api(T, deterministic):
+    """mbx_conv_wgrad_grouped: the weight gradients of MANY layers in one launch (every geometry above + a 25-channel
+    head with padded dy + scaled jobs with a bias) against the float32 torch reference; the deterministic plan
+    (no split pixel reductions) must give bit-identical results on a second launch."""
+    torch = T
+    import torch.nn.functional as F
+    from multibox_amd import ops
+    jobs, checks, keep = [], [], []
+    geoms = [g for g in GEOMS if g[0] != "1x1_2080_1536_m4096"] + [("head_25", 4, 6, 6, 96, 25, 1, 1, 1, (0, 0, 0, 0))]
+    for i, g in enumerate(geoms):
+        name, N, H, W, Ci, Co, R, S, st, pads = g
+        gen = torch.Generator().manual_seed(100 + i)
+        x = bf16_round(torch, torch.randn(N, H, W, Ci, generator=gen))
+        Ho, Wo = out_hw(H, W, R, S, st, pads)
+        dy = bf16_round(torch, torch.randn(N, Ho, Wo, Co, generator=gen))
+        scale = 1.0 if i % 3 else 0.17
+        use_bias = (i % 3 == 0)
+        wr = torch.zeros(Co, R, S, Ci, requires_grad=True)
+        xt = F.pad(x.permute(0, 3, 1, 2), (pads[1], pads[3], pads[0], pads[2]))
+        y = F.conv2d(xt, wr.permute(0, 3, 1, 2), stride=st).permute(0, 2, 3, 1)
+        (y * dy).sum().backward()
+        xb = ops.View.alloc(N, H, W, Ci + 8, zero=True).slice(8, Ci) if i % 2 else ops.View.alloc(N, H, W, Ci)
+        xb.tensor().copy_(x.to(torch.bfloat16))
+        ld = (Co + 7) // 8 * 8
+        dyb = ops.View.alloc(N, Ho, Wo, Co, ld=ld, zero=True)
+        dyb.tensor().copy_(dy.to(torch.bfloat16))
+        dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
+        db = torch.zeros((Co,), dtype=torch.float32, device="cuda") if use_bias else None
+        j = ops.WgradJob()
+        j.desc = ops.make_desc(xb, None, Co, R, S, st, pads[0], pads[1], ops.View(dyb.buf, N, Ho, Wo, 8, ld, 0, 2))
+        j.desc.C_out = Co
+        j.dy, j.dy_img_stride, j.ld_dy, j.scale = dyb.ptr, dyb.img_stride, dyb.ld, scale
+        j.dw, j.db = dw.data_ptr(), (None if db is None else db.data_ptr())
+        jobs.append(j)
+        keep.append((xb, dyb))
+        checks.append((name, dw, db, wr.grad * scale, dy.reshape(-1, Co).sum(0) * scale))
+    grp = ops.WgradGroup(jobs, deterministic=deterministic)
+    assert grp.info.n_layers == len(jobs) and grp.info.n_items >= len(jobs)
+    grp.launch()
+    torch.cuda.synchronize()
+    for name, dw, db, ref_w, ref_b in checks:
+        ok, msg = close(torch, dw, ref_w, f32=True)
+        assert ok, "grouped wgrad %s: %s" % (name, msg)
+        if db is not None:
+            ok, msg = close(torch, db, ref_b, f32=True)
+            assert ok, "grouped bias grad %s: %s" % (name, msg)
+    if deterministic:
+        first = [(dw.clone(), None if db is None else db.clone()) for _, dw, db, _, _ in checks]
+        for _, dw, db, _, _ in checks:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        grp.launch()
+        torch.cuda.synchronize()
+        for (name, dw, db, _, _), (dw0, db0) in zip(checks, first):
+            assert torch.equal(dw, dw0), "deterministic plan not bit-reproducible: " + name
+            assert db is None or torch.equal(db, db0)
