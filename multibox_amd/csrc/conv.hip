@@ -794,6 +794,170 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem,
 }
 
 
+// ------------------------------------------------------------------------------------------
+// wgrad3: the body of the grouped launch for C_out > 64.  Eight waves share ONE pipeline: a 128 (channels) x 256
+// (filter columns) output tile, 64 pixels per step, tiles staged by LDS-DMA into a THREE-deep ring (two steps of
+// global latency in flight, counted vmcnt: in the grouped launch dy and x come cold from HBM, and the loops run for
+// hundreds of steps).  A stage is three [64 pixels][128 channels] images in the layout of wgrad2 (dy, x columns
+// 0..127, x columns 128..255): 48 KB for 4.2 MFLOP (87 FLOP per staged byte, against 64 for wgrad2's two
+// independent 128 x 128 pipelines), 6 DMA instructions per wave and step instead of 8.
+template <bool LIN>
+__device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
+                                            const int blk_begin, const int blk_end) {
+  const WgradK& p = q.b;
+  constexpr int SUB = 64 * 16, STAGE = 3 * SUB, NST = 3;          // 16-byte slots
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();                                     // 0..7
+  const int wn = wave & 1, wk = wave >> 1;                        // 64-channel half, 64-column quarter
+  const int n0 = tile_n * 128, k0 = tile_k * 256;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
+
+  // ---- DMA lane constants: one instruction fills rows 32 i + 4 wave + r4 (i = 0, 1), 16 chunks each
+  const int r4 = lane >> 4;
+  const int swz = ((r4 & 3) | (((wave >> 1) & 1) << 2)) << 1;     // swz(row): row & 3 = r4, row bit 3 = wave bit 1
+  const int lc = (lane & 15) ^ swz;                               // logical chunk this lane fetches
+  int toff[2], tr[2], ts[2];
+  bool kvalid[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kcol = k0 + j * 128 + lc * 8;
+    kvalid[j] = kcol < p.Ktot;
+    const int kc = kvalid[j] ? kcol : 0;
+    const int tap = kc / p.C_in, tc = kc - tap * p.C_in;
+    tr[j] = kvalid[j] ? tap / p.S : (1 << 24);
+    ts[j] = tap - (tap / p.S) * p.S;
+    toff[j] = LIN ? kcol * 2 : ((tr[j] * p.W_in + ts[j]) * p.ldx + tc) * 2;
+  }
+  const int ycol = (n0 + lc * 8 < p.C_out) ? (n0 + lc * 8) * 2 : -1;
+  const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
+  int m_run = blk_begin + wave * 4 + r4;                          // next row this lane fetches (+32 per instruction)
+  int img = 0, oh = 0, ow = 0;
+  if (!LIN) {
+    const unsigned mm = (unsigned)min(m_run, p.M - 1);
+    img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+    const int pix = (int)mm - img * p.HW_out;
+    oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w);
+    ow = pix - oh * p.W_out;
+  }
+
+  // ---- fragment (transpose-read) lane constants, byte offsets inside a stage
+  const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
+  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
+  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
+  int yo[4], xo[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    yo[a] = lb + (((2 * (wn * 4 + a) + (pp >> 1)) ^ sx) << 4);
+    xo[a] = lb + (((2 * ((wk & 1) * 4 + a) + (pp >> 1)) ^ sx) << 4) + (1 + (wk >> 1)) * SUB * 16;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  // bias gradient = column sums of dy: the 512 threads take (channel, 16-row quarter) pairs of the dy image
+  const int bch = threadIdx.x & 127, bq = threadIdx.x >> 7;
+  const bool do_bias = p.db != nullptr && tile_k == 0 && n0 + bch < p.C_out;
+
+  const int nsteps = (blk_end - blk_begin + 63) >> 6;
+  int st_issue = 0, st_comp = 0;
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+#define MBX_ISSUE_STEP3()                                                                                      \
+  do {                                                                                                         \
+    u32x4* sp = smem + st_issue * STAGE + wave * 64;                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+      const bool mv = m_run < blk_end;                                                                         \
+      int xoff0, xoff1, yoff;                                                                                  \
+      if (LIN) {                                                                                               \
+        const int rb = m_run * ldx2;                                                                           \
+        xoff0 = (mv && kvalid[0]) ? rb + toff[0] : (int)kOOB;                                                  \
+        xoff1 = (mv && kvalid[1]) ? rb + toff[1] : (int)kOOB;                                                  \
+        yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                                          \
+      } else {                                                                                                 \
+        const int h0 = oh * p.stride - p.pad_t, w0 = ow * p.stride - p.pad_l;                                  \
+        const int rb = (img * p.x_img_stride + (h0 * p.W_in + w0) * p.ldx) * 2;                                \
+        const bool ok0 = mv && ((unsigned)(h0 + tr[0]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[0]) < (unsigned)p.W_in); \
+        const bool ok1 = mv && ((unsigned)(h0 + tr[1]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[1]) < (unsigned)p.W_in); \
+        xoff0 = ok0 ? rb + toff[0] : (int)kOOB;                                                                \
+        xoff1 = ok1 ? rb + toff[1] : (int)kOOB;                                                                \
+        if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                            \
+        else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB; \
+      }                                                                                                        \
+      glds16(yr, sp + i * 512, yoff);                                                                          \
+      glds16(xr, sp + SUB + i * 512, xoff0);                                                                   \
+      glds16(xr, sp + 2 * SUB + i * 512, xoff1);                                                               \
+      m_run += 32;                                                                                             \
+      if (!LIN) {                                                                                              \
+        ow += 32;                                                                                              \
+        while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                         \
+        while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                        \
+      }                                                                                                        \
+    }                                                                                                          \
+    st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                         \
+  } while (0)
+
+  if (nsteps > 0) MBX_ISSUE_STEP3();
+  if (nsteps > 1) { MBX_ISSUE_STEP3(); wait_vmcnt<6>(); } else wait_vmcnt<0>();
+  raw_barrier();
+  for (int it = 0; it < nsteps; ++it) {
+    const bool more = it + 2 < nsteps;
+    if (more) MBX_ISSUE_STEP3();
+    {
+      const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 yf[4], xf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192 + 1024));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          yf[a] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192 + 1024));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          xf[b] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+      }
+      if (do_bias) {
+        const unsigned short* cY = reinterpret_cast<const unsigned short*>(base);
+        const int ch = bch >> 3, e = bch & 7;
+#pragma unroll 4
+        for (int r = bq * 16; r < bq * 16 + 16; ++r) bsum += bf2f(cY[r * 128 + ((ch ^ wg_swz(r)) << 3) + e]);
+      }
+      st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
+    }
+    if (more) wait_vmcnt<6>(); else wait_vmcnt<0>();        // step it+1 landed (own DMAs), then everyone's
+    raw_barrier();
+  }
+#undef MBX_ISSUE_STEP3
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
+      if (kc >= p.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+    }
+  }
+  if (do_bias) atomicAdd(p.db + n0 + bch, bsum * p.scale);
+}
+
 template <int NST, int NG, bool LIN, bool BIAS>
 __global__ void __launch_bounds__(kThreads * NG)
 conv_wgrad2_kernel(const WgradK2 q) {
@@ -839,8 +1003,8 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
     if (L.lin) wgrad_narrow_body<2, 2, true, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
     else wgrad_narrow_body<2, 2, false, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
   } else {
-    if (L.lin) wgrad_wide_body<2, 2, true, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-    else wgrad_wide_body<2, 2, false, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+    if (L.lin) wgrad3_body<true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+    else wgrad3_body<false>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
   }
 }
 
@@ -1203,7 +1367,7 @@ static int plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, PlanJob* 
     // tile stages 128 + 128 rows, a narrow one 64 + 128, so ceil(C/128) * 256 <= ceil(C/64) * 192 unless C_out <= 64
     pj[j].narrow = (d.C_out <= 64 && dense) ? 1 : 0;
     pj[j].tiles_n = pj[j].narrow ? (d.C_out + 63) / 64 : (d.C_out + 127) / 128;
-    pj[j].tiles_k = (Ktot + 127) / 128;
+    pj[j].tiles_k = pj[j].narrow ? (Ktot + 127) / 128 : (Ktot + 255) / 256;     // wgrad3: 256 filter columns per tile
     pj[j].steps = (int)((M + 63) / 64);
     total += (double)pj[j].tiles_n * pj[j].tiles_k * pj[j].steps;
   }
@@ -1300,7 +1464,7 @@ extern "C" int mbx_conv_wgrad_grouped(const void* device_image, const mbx_wgrad_
   if (reinterpret_cast<uintptr_t>(device_image) & 15) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   static bool attr = false;
-  constexpr int kLds = 2 * 2 * 32768;                 // two wave groups x two stages x (16 KB dy + 16 KB x)
+  constexpr int kLds = 3 * 3 * 16384;                 // wgrad3: three stages x (dy | x 0..127 | x 128..255) x 16 KB
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_grouped_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);

@@ -770,6 +770,10 @@ class Net:
         then the deferred weight gradients in four grouped launches; the Trainer interleaves them per segment.)"""
         for f in self.bwd_launches:
             f()
+        self.run_deferred_wgrad()
+
+    def run_deferred_wgrad(self):
+        """The weight gradients of every layer, after ALL of bwd_launches have run (their dy / x are kept alive)."""
         if self._default_groups is None:
             jobs = [j for j in self.bwd_jobs if j is not None]
             n = max(1, (len(jobs) + 3) // 4)

@@ -132,7 +132,7 @@ def test_forward_backward_parity(env):
 
 def test_stagewise_gradients(env):
     """Orchestration check free of whole-network chaos.  Reduced-depth net (block repeats (2, 2, 1): every
-    kind of op, channel slice, accumulate flag and the in-place trunk gradient across two blocks).  The
+    kind of op, channel slice, accumulate flag and the out-of-place trunk gradient across two blocks).  The
     backward launch list is run in four chunks; between chunks the gradient w.r.t. each stage boundary is
     snapshotted.  Each oracle stage is then run on the ENGINE's stage input and back-propagated from the
     ENGINE's stage-output gradient, so only that stage's few layers separate the two:
@@ -178,6 +178,7 @@ def test_stagewise_gradients(env):
     while li < len(net.bwd_launches):
         net.bwd_launches[li]()
         li += 1
+    net.run_deferred_wgrad()                             # the weight gradients are deferred to grouped launches
     torch.cuda.synchronize()
     acts = {name: nhwc(net.endpoints[name]) for name in bounds}
     m = Model(P, k=5, bn_training=True, q=q_bf16, repeats=reps)
