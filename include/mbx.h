@@ -178,7 +178,11 @@ int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const
  * end of a segment: the launch walks a table of work items (layer, output tile, pixel range) built once by
  * mbx_wgrad_plan.  With hundreds of tiles in flight a tile's pixel reduction is split across blocks only when it
  * is longer than a fair share of one CU's work, so most dw elements have a single adder; flag
- * MBX_WGRAD_DETERMINISTIC forbids every split (bit-reproducible dw).  Semantics per job = mbx_conv_wgrad_scaled.
+ * MBX_WGRAD_DETERMINISTIC forbids every split (bit-reproducible dw).  Semantics per job = mbx_conv_wgrad_scaled,
+ * with one difference: dw / db MUST be zero before the launch and each job needs its own dw -- a tile whose pixel
+ * reduction is not split is written with plain stores (one adder: nothing to add to), split tiles add atomically.
+ * The launch is PERSISTENT: one 768-thread workgroup per CU (8 MFMA waves + 4 LDS-DMA loader waves) pulls work items
+ * from per-XCD queues inside the image (queue heads are reset by a memset the call enqueues before the kernel).
  * mbx_wgrad_plan writes a HOST image of mbx_wgrad_plan_bytes() bytes; copy it to 16-byte aligned device memory
  * once and pass that pointer to every launch.  The image embeds the jobs' device pointers.                    */
 typedef struct {
@@ -190,13 +194,16 @@ typedef struct {
 typedef struct {
   int32_t n_layers, n_items;
   int64_t layers_off, items_off;   /* byte offsets of the two tables inside the image */
+  int64_t queues_off, heads_off;   /* per-XCD work queues: item ranges, and the queue heads the launch advances */
   double flops;                    /* 2 * M * C_out * R*S*C_in summed over the jobs */
 } mbx_wgrad_plan_info;
 #define MBX_WGRAD_DETERMINISTIC 1
+#define MBX_WGRAD_SCATTER 2        /* A/B knob: deal single items round-robin to the queues (no L2 panel sharing) */
 size_t mbx_wgrad_plan_bytes(const mbx_wgrad_job* jobs /*HOST*/, int n_jobs, int flags);
 int mbx_wgrad_plan(const mbx_wgrad_job* jobs /*HOST*/, int n_jobs, int flags, void* host_image, size_t bytes,
                    mbx_wgrad_plan_info* info /*HOST, out*/);
-int mbx_conv_wgrad_grouped(const void* device_image, const mbx_wgrad_plan_info* info /*HOST*/, mbx_stream_t stream);
+int mbx_conv_wgrad_grouped(void* device_image /*queue heads are written*/, const mbx_wgrad_plan_info* info /*HOST*/,
+                           mbx_stream_t stream);
 
 /* Scalars on the dgrad/wgrad path: mbx_conv multiplies the accumulator by `rscale` when
  * epilogue == MBX_EPI_STORE and rscale != 0 (the residual branch scale of model.py:21 on the

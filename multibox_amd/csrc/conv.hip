@@ -13,6 +13,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -116,6 +118,13 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, u32x4* lds_dst,
 }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 __device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's outstanding
+// vector-memory operations (fire-and-forget float atomics of the previous work item keep draining behind it)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -429,6 +438,7 @@ struct WgradK2 {
   WgradK b;
   int pw;            // x rows contiguous: offset = m * ldx (1x1, stride 1, no padding, dense images)
   int ydense;        // dy rows contiguous: offset = m * ld_dy
+  int dbg;           // MBX_WG_DBG ablation switches (diagnosis only): 1 no DMA after the prologue, 2 no LDS reads / MFMA
 };
 
 // NG = 2: eight waves; the two 4-wave groups reduce disjoint halves of the block's pixel range into the
@@ -795,81 +805,72 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem,
 
 
 // ------------------------------------------------------------------------------------------
-// wgrad3: the body of the grouped launch for C_out > 64.  Eight waves share ONE pipeline: a 128 (channels) x 256
-// (filter columns) output tile, 64 pixels per step, tiles staged by LDS-DMA into a THREE-deep ring (two steps of
-// global latency in flight, counted vmcnt: in the grouped launch dy and x come cold from HBM, and the loops run for
-// hundreds of steps).  A stage is three [64 pixels][128 channels] images in the layout of wgrad2 (dy, x columns
-// 0..127, x columns 128..255): 48 KB for 4.2 MFLOP (87 FLOP per staged byte, against 64 for wgrad2's two
-// independent 128 x 128 pipelines), 6 DMA instructions per wave and step instead of 8.
+// wgrad4: the body of the grouped launch for C_out > 64.  TWELVE waves with fixed roles: waves 0-7 COMPUTE a 128
+// (channels) x 256 (filter columns) output tile, waves 8-11 LOAD.  Measured on the all-waves-do-both form (wgrad3,
+// MBX_WG_DBG ablations): the LDS-DMA issue of a 64-pixel step (48 wave-instructions of 1 KiB: ~0.5 us of the CU's
+// address path) and its LDS reads + MFMAs (~0.8 us) ADD UP when every wave does first the one and then the other
+// behind a common barrier -- the matrix pipes idle while the block issues loads.  With loader waves the two run side
+// by side: the compute waves issue no vector-memory instruction in the loop and never wait on vmcnt.
+// A stage is three [64 pixels][128 channels] images (dy, x columns 0..127, x columns 128..255) in the layout of
+// wgrad2; three stages, two steps of global latency in flight (counted vmcnt in the loaders only).
+// The bias gradient (column sums of dy) is summed by the loaders out of the landed dy image (16-byte LDS reads).
+// single != 0: this block is the only adder of its dw tile (the pixel range is the whole layer) -> plain stores.
+#ifndef MBX_WG_LOADERS
+#define MBX_WG_LOADERS 8
+#endif
+constexpr int kWgLoaders = MBX_WG_LOADERS;               // loader waves per block (4 or 8)
+constexpr int kWgGpl = 8 / kWgLoaders;                   // 4-row groups (of the 8 per 32 rows) per loader wave
 template <bool LIN>
-__device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
-                                            const int blk_begin, const int blk_end) {
+__device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
+                                            const int blk_begin, const int blk_end, const int single) {
   const WgradK& p = q.b;
   constexpr int SUB = 64 * 16, STAGE = 3 * SUB, NST = 3;          // 16-byte slots
   const int lane = threadIdx.x & 63;
-  const int wave = wave_id();                                     // 0..7
-  const int wn = wave & 1, wk = wave >> 1;                        // 64-channel half, 64-column quarter
+  const int wave = wave_id();                                     // 0..11
   const int n0 = tile_n * 128, k0 = tile_k * 256;
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
-
-  // ---- DMA lane constants: one instruction fills rows 32 i + 4 wave + r4 (i = 0, 1), 16 chunks each
-  const int r4 = lane >> 4;
-  const int swz = ((r4 & 3) | (((wave >> 1) & 1) << 2)) << 1;     // swz(row): row & 3 = r4, row bit 3 = wave bit 1
-  const int lc = (lane & 15) ^ swz;                               // logical chunk this lane fetches
-  int toff[2], tr[2], ts[2];
-  bool kvalid[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int kcol = k0 + j * 128 + lc * 8;
-    kvalid[j] = kcol < p.Ktot;
-    const int kc = kvalid[j] ? kcol : 0;
-    const int tap = kc / p.C_in, tc = kc - tap * p.C_in;
-    tr[j] = kvalid[j] ? tap / p.S : (1 << 24);
-    ts[j] = tap - (tap / p.S) * p.S;
-    toff[j] = LIN ? kcol * 2 : ((tr[j] * p.W_in + ts[j]) * p.ldx + tc) * 2;
-  }
-  const int ycol = (n0 + lc * 8 < p.C_out) ? (n0 + lc * 8) * 2 : -1;
-  const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
-  int m_run = blk_begin + wave * 4 + r4;                          // next row this lane fetches (+32 per instruction)
-  int img = 0, oh = 0, ow = 0;
-  if (!LIN) {
-    const unsigned mm = (unsigned)min(m_run, p.M - 1);
-    img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
-    const int pix = (int)mm - img * p.HW_out;
-    oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w);
-    ow = pix - oh * p.W_out;
-  }
-
-  // ---- fragment (transpose-read) lane constants, byte offsets inside a stage
-  const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
-  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
-  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
-  int yo[4], xo[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    yo[a] = lb + (((2 * (wn * 4 + a) + (pp >> 1)) ^ sx) << 4);
-    xo[a] = lb + (((2 * ((wk & 1) * 4 + a) + (pp >> 1)) ^ sx) << 4) + (1 + (wk >> 1)) * SUB * 16;
-  }
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  // bias gradient = column sums of dy: the 512 threads take (channel, 16-row quarter) pairs of the dy image
-  const int bch = threadIdx.x & 127, bq = threadIdx.x >> 7;
-  const bool do_bias = p.db != nullptr && tile_k == 0 && n0 + bch < p.C_out;
-
   const int nsteps = (blk_end - blk_begin + 63) >> 6;
-  int st_issue = 0, st_comp = 0;
-  typedef s16x4 __attribute__((address_space(3))) * lds_tr;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-#define MBX_ISSUE_STEP3()                                                                                      \
+  const bool bias = p.db != nullptr && tile_k == 0;               // block-uniform
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = 0.f;
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------------------------------ loader waves
+    const int lw = wave - 8;                                      // takes the rows of "row groups" kWgGpl lw + j
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
+    // one instruction fills rows 32 i + 4 g + r4 (i = 0, 1; row group g = kWgGpl lw + j), 16 chunks each
+    const int r4 = lane >> 4;
+    const int swz = ((r4 & 3) | ((((kWgGpl * lw) >> 1) & 1) << 2)) << 1;   // swz(row): row & 3 = r4, row bit 3 = g bit 1
+    const int lc = (lane & 15) ^ swz;                             // logical chunk this lane fetches
+    int toff[2], tr[2], ts[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kcol = k0 + j * 128 + lc * 8;
+      kvalid[j] = kcol < p.Ktot;
+      const int kc = kvalid[j] ? kcol : 0;
+      const int tap = kc / p.C_in, tc = kc - tap * p.C_in;
+      tr[j] = kvalid[j] ? tap / p.S : (1 << 24);
+      ts[j] = tap - (tap / p.S) * p.S;
+      toff[j] = LIN ? kcol * 2 : ((tr[j] * p.W_in + ts[j]) * p.ldx + tc) * 2;
+    }
+    const int ycol = (n0 + lc * 8 < p.C_out) ? (n0 + lc * 8) * 2 : -1;
+    const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
+    int m_run = blk_begin + 4 * kWgGpl * lw + r4;                 // rows visited: the groups of i = 0, then of i = 1
+    int img = 0, oh = 0, ow = 0;
+    if (!LIN) {
+      const unsigned mm = (unsigned)min(m_run, p.M - 1);
+      img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+      const int pix = (int)mm - img * p.HW_out;
+      oh = (int)fast_div((unsigned)pix, p.mg_w, p.sh_w);
+      ow = pix - oh * p.W_out;
+    }
+    int st_issue = 0, st_bias = 0;
+#define MBX_ISSUE_STEP4()                                                                                      \
   do {                                                                                                         \
-    u32x4* sp = smem + st_issue * STAGE + wave * 64;                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+    u32x4* sp = smem + st_issue * STAGE + (kWgGpl * lw) * 64;                                                  \
+    _Pragma("unroll") for (int slot = 0; slot < 2 * kWgGpl; ++slot) {                                          \
       const bool mv = m_run < blk_end;                                                                         \
       int xoff0, xoff1, yoff;                                                                                  \
       if (LIN) {                                                                                               \
@@ -887,12 +888,14 @@ __device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const
         if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                            \
         else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB; \
       }                                                                                                        \
-      glds16(yr, sp + i * 512, yoff);                                                                          \
-      glds16(xr, sp + SUB + i * 512, xoff0);                                                                   \
-      glds16(xr, sp + 2 * SUB + i * 512, xoff1);                                                               \
-      m_run += 32;                                                                                             \
+      u32x4* d = sp + (slot % kWgGpl) * 64 + (slot / kWgGpl) * 512;                                            \
+      glds16(yr, d, yoff);                                                                                     \
+      glds16(xr, d + SUB, xoff0);                                                                              \
+      glds16(xr, d + 2 * SUB, xoff1);                                                                          \
+      const int adv = (slot % kWgGpl == kWgGpl - 1) ? 32 - 4 * (kWgGpl - 1) : 4;                               \
+      m_run += adv;                                                                                            \
       if (!LIN) {                                                                                              \
-        ow += 32;                                                                                              \
+        ow += adv;                                                                                             \
         while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                         \
         while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                        \
       }                                                                                                        \
@@ -900,13 +903,71 @@ __device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                         \
   } while (0)
 
-  if (nsteps > 0) MBX_ISSUE_STEP3();
-  if (nsteps > 1) { MBX_ISSUE_STEP3(); wait_vmcnt<6>(); } else wait_vmcnt<0>();
-  raw_barrier();
+    if (nsteps > 0) MBX_ISSUE_STEP4();
+    constexpr int NDMA = 6 * kWgGpl;                      // LDS-DMA instructions per wave and step
+    constexpr int RB = 4 * kWgLoaders;                    // bias sums: loader thread lt takes rows (lt >> 4) + RB j
+    if (nsteps > 1) { MBX_ISSUE_STEP4(); wait_vmcnt<NDMA>(); } else wait_vmcnt<0>();
+    raw_barrier();                                        // step 0 has landed
+    const int lt = threadIdx.x - 512;                     // bias sums: rows (lt >> 4) + RB j, LDS slot lt & 15
+    for (int it = 0; it < nsteps; ++it) {
+      const bool more = it + 2 < nsteps;
+      if (more) MBX_ISSUE_STEP4();
+      if (bias) {                                         // dy image of the step being multiplied (landed, read-only now)
+        const u32x4* img_y = smem + st_bias * STAGE;
+#pragma unroll
+        for (int j = 0; j < 64 / RB; ++j) {
+          const u32x4 v = img_y[((lt >> 4) + RB * j) * 16 + (lt & 15)];
+          const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bs[2 * e] += bf2f(w[e] & 0xffffu); bs[2 * e + 1] += bf2f(w[e] >> 16); }
+        }
+        st_bias = st_bias == NST - 1 ? 0 : st_bias + 1;
+      }
+      if (more) wait_vmcnt<NDMA>(); else wait_vmcnt<0>(); // step it+1 has landed (this wave's share), then everyone's
+      raw_barrier();
+    }
+#undef MBX_ISSUE_STEP4
+    if (bias) {                                           // 16 row groups per channel -> LDS -> one adder per channel
+      lds_barrier();                                      // (the compute waves are past their last LDS read)
+      float* red = reinterpret_cast<float*>(smem);        // [RB row groups][128 channels]
+      const int rg = lt >> 4, cg = (lt & 15) ^ wg_swz(lt >> 4);      // logical chunk of this thread's slot (RB = 16, 32: rows
+                                                                     // RB j apart share row & 3 and row bit 3)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[rg * 128 + cg * 8 + j] = bs[j];
+      lds_barrier();
+      if (lt < 128 && n0 + lt < p.C_out) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) t += red[r * 128 + lt];
+        atomicAdd(p.db + n0 + lt, t * p.scale);
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- compute waves
+  const int wn = wave & 1, wk = wave >> 1;                        // 64-channel half, 64-column quarter
+  // fragment (transpose-read) lane constants, byte offsets inside a stage
+  const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
+  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
+  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
+  int yo[4], xo[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    yo[a] = lb + (((2 * (wn * 4 + a) + (pp >> 1)) ^ sx) << 4);
+    xo[a] = lb + (((2 * ((wk & 1) * 4 + a) + (pp >> 1)) ^ sx) << 4) + (1 + (wk >> 1)) * SUB * 16;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int st_comp = 0;
+  typedef s16x4 __attribute__((address_space(3))) * lds_tr;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  raw_barrier();                                          // step 0 has landed
   for (int it = 0; it < nsteps; ++it) {
-    const bool more = it + 2 < nsteps;
-    if (more) MBX_ISSUE_STEP3();
-    {
+    if (!(q.dbg & 2)) {
       const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -931,18 +992,12 @@ __device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const
           for (int b = 0; b < 4; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
       }
-      if (do_bias) {
-        const unsigned short* cY = reinterpret_cast<const unsigned short*>(base);
-        const int ch = bch >> 3, e = bch & 7;
-#pragma unroll 4
-        for (int r = bq * 16; r < bq * 16 + 16; ++r) bsum += bf2f(cY[r * 128 + ((ch ^ wg_swz(r)) << 3) + e]);
-      }
-      st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
     }
-    if (more) wait_vmcnt<6>(); else wait_vmcnt<0>();        // step it+1 landed (own DMAs), then everyone's
+    st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS reads are done before the stage is reused
     raw_barrier();
   }
-#undef MBX_ISSUE_STEP3
+  if (bias) { lds_barrier(); lds_barrier(); }             // the loaders reduce the bias sums through LDS meanwhile
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
@@ -951,11 +1006,23 @@ __device__ __forceinline__ void wgrad3_body(const WgradK2& q, u32x4* smem, const
       const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
       if (kc >= p.Ktot) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (nb + r < p.C_out) atomicAdd(p.dw + (size_t)(nb + r) * p.Ktot + kc, acc[a][b][r] * p.scale);
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r >= p.C_out) continue;
+        float* dst = p.dw + (size_t)(nb + r) * p.Ktot + kc;
+        if (single) *dst = acc[a][b][r] * p.scale;        // dw is zero before the launch and this block is its only adder
+        else atomicAdd(dst, acc[a][b][r] * p.scale);
+      }
     }
   }
-  if (do_bias) atomicAdd(p.db + n0 + bch, bsum * p.scale);
+}
+
+// what a loader wave of the 12-wave grouped kernel does while waves 0-7 run a NARROW item (wgrad_narrow_body with
+// NG = 2: all of its barriers are block-wide): the same number of barriers, nothing else
+__device__ __forceinline__ void wgrad_narrow_idle(const int blk_begin, const int blk_end) {
+  const int half = ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63);
+  const int nsteps = (half + 63) >> 6;
+  for (int i = 0; i < nsteps + 1; ++i) raw_barrier();     // prologue + one per step
+  __syncthreads();                                        // group 1 -> LDS -> group 0 exchange
 }
 
 template <int NST, int NG, bool LIN, bool BIAS>
@@ -991,20 +1058,48 @@ conv_wgrad2n_kernel(const WgradK2 q) {
 // (no atomic traffic to speak of, bit-reproducible), loops run for hundreds of steps instead of a dozen, and
 // there is one launch tail per segment instead of one per layer.
 struct WgradLayer { WgradK2 q; int narrow, lin, pad0, pad1; };
-struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, pad0, pad1, pad2; };
+struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, single, pad1, pad2; };   // single: the only adder of its dw tile
+constexpr int kWgradLds = 3 * 3 * 16384;               // wgrad4: three stages x (dy | x 0..127 | x 128..255) x 16 KB
+constexpr int kQueues = 8;                             // one work queue per XCD
+constexpr int kCounterStride = 32;                     // ints: every queue head on its own 128-byte line
 
-__global__ void __launch_bounds__(kThreads * 2)
-conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem* __restrict__ items) {
+// PERSISTENT: one 512-thread block per CU; a block reads the id of the XCD it runs on and pulls items from THAT
+// XCD's queue (one returning atomic per item), then steals from the other queues.  The host deals whole panel groups
+// -- all output tiles of one (layer, pixel range), which stream the same dy / x rows -- to one queue, so the ~32
+// blocks that share an L2 walk the same pixels at the same time and all but the first read of a row is an L2 hit
+// (LDS-DMA from the XCD's L2 runs at twice the rate of the Infinity Cache, MI355X_MICROARCH.md "Indexed rows").
+// Placement is for speed only: any block may run any item.
+__global__ void __launch_bounds__(64 * (8 + kWgLoaders))
+conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem* __restrict__ items,
+                          const int* __restrict__ qrange /*[2][kQueues]: begin | end*/, int* __restrict__ heads) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  const WgradItem it = items[blockIdx.x];              // block-uniform: scalar loads
-  const WgradLayer& L = layers[it.layer];
-  const WgradK2 q = L.q;
-  if (L.narrow) {
-    if (L.lin) wgrad_narrow_body<2, 2, true, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-    else wgrad_narrow_body<2, 2, false, true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-  } else {
-    if (L.lin) wgrad3_body<true>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-    else wgrad3_body<false>(q, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+  volatile int* s_idx = reinterpret_cast<volatile int*>(smem + kWgradLds / 16);     // one word past the rings
+  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (kQueues - 1);         // HW_REG_XCC_ID[3:0]
+  const bool loader = wave_id() >= 8;
+  for (int q = 0; q < kQueues; ++q) {
+    const int qx = (xcd + q) & (kQueues - 1);
+    const int qb = qrange[qx], qe = qrange[kQueues + qx];
+    if (qb >= qe) continue;
+    for (;;) {
+      lds_barrier();                                     // everyone is done with the previous item (LDS, s_idx)
+      // dequeue by a LOADER lane: its wave has nothing in flight, while a compute wave's returning atomic would queue
+      // behind the dw atomics it has just fired (vmcnt retires in order)
+      if (threadIdx.x == 512) *s_idx = qb + atomicAdd(heads + qx * kCounterStride, 1);
+      lds_barrier();
+      const int idx = __builtin_amdgcn_readfirstlane(*s_idx);
+      if (idx >= qe) break;
+      const WgradItem it = items[idx];                   // block-uniform: scalar loads
+      const WgradLayer& L = layers[it.layer];
+      const WgradK2 q2 = L.q;
+      if (L.narrow) {
+        if (loader) wgrad_narrow_idle(it.m_begin, it.m_end);
+        else if (L.lin) wgrad_narrow_body<2, 2, true, true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+        else wgrad_narrow_body<2, 2, false, true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
+      } else {
+        if (L.lin) wgrad4_body<true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end, it.single);
+        else wgrad4_body<false>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end, it.single);
+      }
+    }
   }
 }
 
@@ -1238,6 +1333,9 @@ static int fill_wgrad(const mbx_conv_desc* d, const void* dy, int64_t dy_img_str
   k2.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1 &&
            d->x_img_stride == (int64_t)d->H_in * d->W_in * d->ldx) ? 1 : 0;
   k2.ydense = (dy_img_stride == (int64_t)k.HW_out * ld_dy) ? 1 : 0;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MBX_WG_DBG"); dbg = e ? atoi(e) : 0; }
+  k2.dbg = dbg;
   return MBX_OK;
 }
 
@@ -1353,11 +1451,13 @@ static int plan_cus() {
 }
 
 struct PlanJob { int narrow, tiles_n, tiles_k, steps, splits; };
+struct PlanGroup { int job, m_begin, m_end, tiles; double len; };     // all output tiles of one (layer, pixel range)
 
-static int plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, PlanJob* pj, long long* n_items_out) {
+static void plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, std::vector<PlanJob>& pj) {
   // work unit: one 64-pixel step of one tile.  A tile is split only when it is longer than a quarter of a CU's fair
   // share of the whole group (and never below 16 steps per piece): most tiles keep a single adder.
   double total = 0.0;
+  pj.resize(n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
     const mbx_conv_desc& d = jobs[j].desc;
     const long long M = (long long)d.N * d.H_out * d.W_out;
@@ -1374,106 +1474,143 @@ static int plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, PlanJob* 
   const double share = total / plan_cus();
   double wmax = share / 4.0;
   if (wmax < 16.0) wmax = 16.0;
-  long long n_items = 0;
   for (int j = 0; j < n_jobs; ++j) {
     int splits = (flags & MBX_WGRAD_DETERMINISTIC) ? 1 : (int)((pj[j].steps + wmax - 1) / wmax);
     const int max_splits = (pj[j].steps + 15) / 16;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     pj[j].splits = splits;
-    n_items += (long long)pj[j].tiles_n * pj[j].tiles_k * splits;
   }
-  *n_items_out = n_items;
-  return MBX_OK;
+}
+
+// Panel groups dealt to the XCD queues: longest items first (the short ones fill the tail), each group to the queue
+// with the least work so far; a queue keeps that order.  MBX_WGRAD_SCATTER (A/B knob) deals single items instead.
+static void plan_queues(const mbx_wgrad_job* jobs, int n_jobs, int flags, const std::vector<PlanJob>& pj,
+                        std::vector<WgradItem>& items, int* qrange) {
+  std::vector<PlanGroup> groups;
+  for (int j = 0; j < n_jobs; ++j) {
+    const mbx_conv_desc& d = jobs[j].desc;
+    const long long M = (long long)d.N * d.H_out * d.W_out;
+    long long mps = (M + pj[j].splits - 1) / pj[j].splits;
+    mps = ((mps + 63) / 64) * 64;
+    for (long long b = 0; b < M; b += mps) {
+      PlanGroup g;
+      g.job = j; g.m_begin = (int)b; g.m_end = (int)(b + mps < M ? b + mps : M);
+      g.tiles = pj[j].tiles_n * pj[j].tiles_k;
+      g.len = (double)((g.m_end - g.m_begin + 63) / 64) * (pj[j].narrow ? 0.6 : 1.0);   // a narrow step stages 24 of 48 KB
+      groups.push_back(g);
+    }
+  }
+  std::stable_sort(groups.begin(), groups.end(), [](const PlanGroup& a, const PlanGroup& b) {
+    return a.len != b.len ? a.len > b.len : a.tiles > b.tiles;
+  });
+  std::vector<WgradItem> q[kQueues];
+  double load[kQueues] = {0};
+  int rr = 0;
+  for (const PlanGroup& g : groups) {
+    for (int tk = 0; tk < pj[g.job].tiles_k; ++tk)
+      for (int tn = 0; tn < pj[g.job].tiles_n; ++tn) {
+        int best = 0;
+        if (flags & MBX_WGRAD_SCATTER) best = rr++ % kQueues;
+        else if (tk == 0 && tn == 0) { for (int x = 1; x < kQueues; ++x) if (load[x] < load[best]) best = x; rr = best; }
+        else best = rr;
+        WgradItem I;
+        memset(&I, 0, sizeof(I));
+        I.layer = g.job; I.tile_n = tn; I.tile_k = tk; I.m_begin = g.m_begin; I.m_end = g.m_end;
+        I.single = pj[g.job].splits == 1 ? 1 : 0;
+        q[best].push_back(I);
+        load[best] += g.len;
+      }
+  }
+  items.clear();
+  for (int x = 0; x < kQueues; ++x) {
+    qrange[x] = (int)items.size();
+    items.insert(items.end(), q[x].begin(), q[x].end());
+    qrange[kQueues + x] = (int)items.size();
+  }
+}
+
+static size_t plan_image_bytes(int n_jobs, size_t n_items, int64_t* items_off, int64_t* queues_off, int64_t* heads_off) {
+  size_t o = sizeof(WgradLayer) * (size_t)n_jobs;
+  if (items_off) *items_off = (int64_t)o;
+  o += sizeof(WgradItem) * n_items;
+  o = (o + 127) / 128 * 128;
+  if (queues_off) *queues_off = (int64_t)o;
+  o += 128;                                            // qrange: 2 x kQueues ints
+  if (heads_off) *heads_off = (int64_t)o;
+  o += (size_t)kQueues * kCounterStride * sizeof(int);
+  return o;
 }
 
 extern "C" size_t mbx_wgrad_plan_bytes(const mbx_wgrad_job* jobs, int n_jobs, int flags) {
   if (!jobs || n_jobs <= 0) return 0;
-  PlanJob* pj = (PlanJob*)malloc(sizeof(PlanJob) * n_jobs);
-  if (!pj) return 0;
-  long long n_items = 0;
-  plan_jobs(jobs, n_jobs, flags, pj, &n_items);
-  free(pj);
-  return sizeof(WgradLayer) * (size_t)n_jobs + sizeof(WgradItem) * (size_t)n_items;
+  std::vector<PlanJob> pj;
+  std::vector<WgradItem> items;
+  int qrange[2 * kQueues];
+  plan_jobs(jobs, n_jobs, flags, pj);
+  plan_queues(jobs, n_jobs, flags, pj, items, qrange);
+  return plan_image_bytes(n_jobs, items.size(), nullptr, nullptr, nullptr);
 }
 
 extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, void* host_image, size_t bytes,
                               mbx_wgrad_plan_info* info) {
   if (!jobs || n_jobs <= 0 || !host_image || !info) return MBX_ERR_INVALID_ARG;
-  PlanJob* pj = (PlanJob*)malloc(sizeof(PlanJob) * n_jobs);
-  if (!pj) return MBX_ERR_WORKSPACE;
-  long long n_items = 0;
-  plan_jobs(jobs, n_jobs, flags, pj, &n_items);
-  const size_t need = sizeof(WgradLayer) * (size_t)n_jobs + sizeof(WgradItem) * (size_t)n_items;
-  if (bytes < need || n_items >= (1LL << 31)) { free(pj); return MBX_ERR_WORKSPACE; }
-  WgradLayer* layers = reinterpret_cast<WgradLayer*>(host_image);
-  WgradItem* items = reinterpret_cast<WgradItem*>(layers + n_jobs);
+  std::vector<PlanJob> pj;
+  std::vector<WgradItem> items;
+  int qrange[2 * kQueues];
+  plan_jobs(jobs, n_jobs, flags, pj);
+  plan_queues(jobs, n_jobs, flags, pj, items, qrange);
+  int64_t items_off, queues_off, heads_off;
+  const size_t need = plan_image_bytes(n_jobs, items.size(), &items_off, &queues_off, &heads_off);
+  if (bytes < need || items.size() >= (1ull << 30)) return MBX_ERR_WORKSPACE;
+  memset(host_image, 0, need);
+  char* base = reinterpret_cast<char*>(host_image);
+  WgradLayer* layers = reinterpret_cast<WgradLayer*>(base);
   double flops = 0.0;
-  // jobs ordered longest tile first, so that the long items are dispatched first and the short ones fill the tail
-  int* order = (int*)malloc(sizeof(int) * n_jobs);
-  if (!order) { free(pj); return MBX_ERR_WORKSPACE; }
-  for (int j = 0; j < n_jobs; ++j) order[j] = j;
-  for (int a = 1; a < n_jobs; ++a) {               // insertion sort, descending steps per piece (stable)
-    const int v = order[a];
-    const double wv = (double)pj[v].steps / pj[v].splits;
-    int b = a - 1;
-    while (b >= 0 && (double)pj[order[b]].steps / pj[order[b]].splits < wv) { order[b + 1] = order[b]; --b; }
-    order[b + 1] = v;
-  }
-  long long it = 0;
-  int status = MBX_OK;
-  for (int j = 0; j < n_jobs && status == MBX_OK; ++j) {
+  for (int j = 0; j < n_jobs; ++j) {
     const mbx_wgrad_job& J = jobs[j];
     WgradLayer& L = layers[j];
-    memset(&L, 0, sizeof(L));
-    status = fill_wgrad(&J.desc, J.dy, J.dy_img_stride, J.ld_dy, J.scale, J.dw, J.db, L.q);
-    if (status != MBX_OK) break;
+    const int status = fill_wgrad(&J.desc, J.dy, J.dy_img_stride, J.ld_dy, J.scale, J.dw, J.db, L.q);
+    if (status != MBX_OK) return status;
     L.narrow = pj[j].narrow;
     L.lin = (L.q.pw && L.q.ydense) ? 1 : 0;
     L.q.b.tiles_n = pj[j].tiles_n;
     flops += 2.0 * L.q.b.M * (double)L.q.b.C_out * L.q.b.Ktot;
   }
-  for (int o = 0; o < n_jobs && status == MBX_OK; ++o) {
-    const int j = order[o];
-    const int M = layers[j].q.b.M;
-    int mps = (M + pj[j].splits - 1) / pj[j].splits;
-    mps = ((mps + 63) / 64) * 64;
-    for (int sp = 0; sp * (long long)mps < M; ++sp)
-      for (int tk = 0; tk < pj[j].tiles_k; ++tk)
-        for (int tn = 0; tn < pj[j].tiles_n; ++tn) {
-          WgradItem& I = items[it++];
-          memset(&I, 0, sizeof(I));
-          I.layer = j; I.tile_n = tn; I.tile_k = tk;
-          I.m_begin = sp * mps;
-          I.m_end = (sp + 1) * (long long)mps < M ? (sp + 1) * mps : M;
-        }
-  }
-  free(order);
-  free(pj);
-  if (status != MBX_OK) return status;
+  memcpy(base + items_off, items.data(), sizeof(WgradItem) * items.size());
+  memcpy(base + queues_off, qrange, sizeof(qrange));
   info->n_layers = n_jobs;
-  info->n_items = (int32_t)it;                       // <= the bound used for the byte count
+  info->n_items = (int32_t)items.size();
   info->layers_off = 0;
-  info->items_off = (int64_t)(sizeof(WgradLayer) * (size_t)n_jobs);
+  info->items_off = items_off;
+  info->queues_off = queues_off;
+  info->heads_off = heads_off;
   info->flops = flops;
   return MBX_OK;
 }
 
-extern "C" int mbx_conv_wgrad_grouped(const void* device_image, const mbx_wgrad_plan_info* info, mbx_stream_t stream) {
+extern "C" int mbx_conv_wgrad_grouped(void* device_image, const mbx_wgrad_plan_info* info, mbx_stream_t stream) {
   if (!device_image || !info || info->n_items <= 0 || info->n_layers <= 0) return MBX_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(device_image) & 15) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   static bool attr = false;
-  constexpr int kLds = 3 * 3 * 16384;                 // wgrad3: three stages x (dy | x 0..127 | x 128..255) x 16 KB
+  constexpr int kLds = kWgradLds + 16;                 // + the broadcast word of the item index
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_grouped_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr = true;
   }
-  const char* base = reinterpret_cast<const char*>(device_image);
-  hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3(info->n_items), dim3(2 * kThreads), kLds, mbx_s(stream),
+  char* base = reinterpret_cast<char*>(device_image);
+  hipStream_t s = mbx_s(stream);
+  // queue heads back to zero (a memset node when the launch is captured into a hipGraph)
+  if (hipMemsetAsync(base + info->heads_off, 0, (size_t)kQueues * kCounterStride * sizeof(int), s) != hipSuccess)
+    return MBX_ERR_LAUNCH;
+  const int blocks = info->n_items < plan_cus() ? info->n_items : plan_cus();      // one persistent block per CU
+  hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3(blocks), dim3(64 * (8 + kWgLoaders)), kLds, s,
                      reinterpret_cast<const WgradLayer*>(base + info->layers_off),
-                     reinterpret_cast<const WgradItem*>(base + info->items_off));
+                     reinterpret_cast<const WgradItem*>(base + info->items_off),
+                     reinterpret_cast<const int*>(base + info->queues_off),
+                     reinterpret_cast<int*>(base + info->heads_off));
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

@@ -42,7 +42,7 @@ class WgradJob(C.Structure):
 class WgradPlanInfo(C.Structure):
     """mbx_wgrad_plan_info (include/mbx.h)."""
     _fields_ = [("n_layers", C.c_int32), ("n_items", C.c_int32), ("layers_off", C.c_int64), ("items_off", C.c_int64),
-                ("flops", C.c_double)]
+                ("queues_off", C.c_int64), ("heads_off", C.c_int64), ("flops", C.c_double)]
 
 
 class View:
@@ -231,7 +231,7 @@ class WgradGroup:
         l = _lib.lib()
         self.n = len(jobs)
         arr = (WgradJob * self.n)(*jobs)
-        flags = 1 if deterministic else 0
+        flags = (1 if deterministic else 0) | (2 if os.environ.get("MBX_WGRAD_SCATTER") == "1" else 0)   # 2: A/B knob
         nbytes = l.mbx_wgrad_plan_bytes(arr, self.n, flags)
         assert nbytes > 0
         host = (C.c_uint8 * nbytes)()

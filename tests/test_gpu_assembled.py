@@ -124,6 +124,16 @@ for run in range(2):
     outs.append((net.Wg.clone(), net.Btg.clone()))
 same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 print("IDENTICAL" if same else "DIFFERENT", float(outs[0][0].abs().sum()))
+if not same:                       # name the variables whose gradients differ (bisecting aid)
+    bad = []
+    for name, (buf, off, shape, cpad) in net.param_index.items():
+        if buf not in ("W", "Bt"):
+            continue
+        n = int(np.prod(shape[:-1] + (cpad,) if cpad is not None else shape))
+        a, b = (outs[0][0], outs[1][0]) if buf == "W" else (outs[0][1], outs[1][1])
+        if not torch.equal(a[off:off + n], b[off:off + n]):
+            bad.append(name)
+    print(len(bad), "variables differ; first:", bad[:8], "last:", bad[-4:])
 """
 
 

@@ -26,9 +26,11 @@ dgi = iter(dg)
 rec = {}
 for op, r in zip(convs, fwd):
     rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1), "fwd_grid": r["Grid_Size_X"]}
-for op, r in zip(bw, wg):
-    rec[id(op)]["wg"] = dur(r)
-    rec[id(op)]["wg_grid"] = "%sx%s" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"])
+if len(wg) == len(bw):          # per-layer weight-gradient launches (round 1); the grouped launches have no per-layer time
+    for op, r in zip(bw, wg):
+        rec[id(op)]["wg"] = dur(r)
+        rec[id(op)]["wg_grid"] = "%sx%s" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"])
+for op in bw:
     if op.need_dx:
         d = next(dgi)
         rec[id(op)]["dg"] = dur(d)
@@ -53,3 +55,11 @@ for key, a in agg.items():
     print("%-58s %7d %5d %5d %dx%d | %7.1f %7.1f %7.1f | %4.0f %4.0f %4.0f | x%d f<%s> d<%s> w[%s]" % (
         name, M, Cin, K, R, S, a[0], a[1], a[2], tf(a[0]), tf(a[1]), tf(a[2]), n, a[5], a[6], a[7]))
 print("totals us: fwd %.0f dgrad %.0f wgrad %.0f" % tuple(tot))
+other = {}
+for r in step:
+    n = r["Kernel_Name"].split("(")[0].split("<")[0]
+    o = other.setdefault(n, [0, 0.0]); o[0] += 1; o[1] += dur(r)
+print("kernels of the last step:")
+for n, (c, t) in sorted(other.items(), key=lambda kv: -kv[1][1]):
+    print("  %-50s x%-4d %9.1f us" % (n[:50], c, t))
+print("  sum %.1f us; span %.1f us" % (sum(t for _, t in other.values()), (int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e3))
