@@ -805,61 +805,66 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem,
 
 
 // ------------------------------------------------------------------------------------------
-// wgrad4: the body of the grouped launch for C_out > 64.  TWELVE waves with fixed roles: waves 0-7 COMPUTE a 128
-// (channels) x 256 (filter columns) output tile, waves 8-11 LOAD.  Measured on the all-waves-do-both form (wgrad3,
-// MBX_WG_DBG ablations): the LDS-DMA issue of a 64-pixel step (48 wave-instructions of 1 KiB: ~0.5 us of the CU's
-// address path) and its LDS reads + MFMAs (~0.8 us) ADD UP when every wave does first the one and then the other
-// behind a common barrier -- the matrix pipes idle while the block issues loads.  With loader waves the two run side
-// by side: the compute waves issue no vector-memory instruction in the loop and never wait on vmcnt.
-// A stage is three [64 pixels][128 channels] images (dy, x columns 0..127, x columns 128..255) in the layout of
-// wgrad2; three stages, two steps of global latency in flight (counted vmcnt in the loaders only).
-// The bias gradient (column sums of dy) is summed by the loaders out of the landed dy image (16-byte LDS reads).
-// single != 0: this block is the only adder of its dw tile (the pixel range is the whole layer) -> plain stores.
+// wgrad5: the body of the grouped launch.  SIXTEEN waves with fixed roles: waves 0-7 COMPUTE a (64 NY channels) x
+// (64 NX filter columns) output tile, waves 8-15 LOAD.
+//  * Roles.  Measured on the all-waves-do-both form (MBX_WG_DBG ablations of the round-2 wgrad3 body): the LDS-DMA
+//    issue of a 64-pixel step (~0.5 us of the CU's address path) and its LDS reads + MFMAs (~0.8 us) ADD UP when every
+//    wave does first the one and then the other behind a common barrier -- the matrix pipes idle while the block
+//    issues loads.  With loader waves the two run side by side: the compute waves issue no vector-memory instruction
+//    in the loop and never wait on vmcnt.  Eight loaders beat four by 9 % (a wave issues one DMA per ~100 cycles).
+//  * Tile shapes.  The launch is bound by the bytes the CUs pull through the L2 -> LDS path (~45 GB/s per CU), so the
+//    planner picks, per layer, the (NY, NX) that moves the fewest bytes: a stage is NY + NX sub-images of
+//    [64 pixels][64 channels] (8 KB, 128-byte rows, the transposing-read swizzle of the old narrow dy tile), so
+//    channel counts like 160 / 192 / 320 / 1088 and filter widths like 384 / 896 / 1120 stop padding a fixed 128 x 256
+//    tile (32 % of the MFMAs and a quarter of the bytes of the step were padding).
+//  * Three stages, two steps of global latency in flight (counted vmcnt in the loaders only).  Loader lw fills rows
+//    8 lw .. 8 lw + 7 of every sub-image: ONE pixel row per lane and step.
+//  * The bias gradient (column sums of dy) is summed by the loaders out of the landed dy sub-images.
+//  * single != 0: this block is the only adder of its dw tile (the pixel range is the whole layer) -> plain stores.
 #ifndef MBX_WG_LOADERS
 #define MBX_WG_LOADERS 8
 #endif
-constexpr int kWgLoaders = MBX_WG_LOADERS;               // loader waves per block (4 or 8)
-constexpr int kWgGpl = 8 / kWgLoaders;                   // 4-row groups (of the 8 per 32 rows) per loader wave
-template <bool LIN>
-__device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
+static_assert(MBX_WG_LOADERS == 8, "wgrad5: one 8-row piece of every sub-image per loader wave");
+constexpr int kWgLoaders = 8;
+constexpr int kWgStageSlots = 6 * 512;                            // 16-byte slots per stage: up to six 8 KB sub-images
+__device__ __forceinline__ int wg_swz64(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+
+template <int NY, int NX>
+__device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const int tile_n, const int tile_k,
                                             const int blk_begin, const int blk_end, const int single) {
+  static_assert(NY + NX <= 6 && NY >= 1 && NX >= 1, "stage = at most six sub-images (48 KB)");
   const WgradK& p = q.b;
-  constexpr int SUB = 64 * 16, STAGE = 3 * SUB, NST = 3;          // 16-byte slots
+  constexpr int NSUB = NY + NX, STAGE = kWgStageSlots, NST = 3;
   const int lane = threadIdx.x & 63;
-  const int wave = wave_id();                                     // 0..11
-  const int n0 = tile_n * 128, k0 = tile_k * 256;
+  const int wave = wave_id();                                     // 0..15
+  const int n0 = tile_n * 64 * NY, k0 = tile_k * 64 * NX;
   const int nsteps = (blk_end - blk_begin + 63) >> 6;
   const bool bias = p.db != nullptr && tile_k == 0;               // block-uniform
-  float bs[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bs[j] = 0.f;
 
   if (wave >= 8) {
     // ------------------------------------------------------------------------------------------ loader waves
-    const int lw = wave - 8;                                      // takes the rows of "row groups" kWgGpl lw + j
+    const int lw = wave - 8;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.dy, p.dy_bytes);
-    // one instruction fills rows 32 i + 4 g + r4 (i = 0, 1; row group g = kWgGpl lw + j), 16 chunks each
-    const int r4 = lane >> 4;
-    const int swz = ((r4 & 3) | ((((kWgGpl * lw) >> 1) & 1) << 2)) << 1;   // swz(row): row & 3 = r4, row bit 3 = g bit 1
-    const int lc = (lane & 15) ^ swz;                             // logical chunk this lane fetches
-    int toff[2], tr[2], ts[2];
-    bool kvalid[2];
+    const int r8 = lane >> 3;                                     // this lane's row inside the 8-row piece
+    const int lc = (lane & 7) ^ wg_swz64(8 * lw + r8);            // logical chunk fetched into physical slot lane & 7
+    int toff[NX], tr[NX], ts[NX], ycol[NY];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kcol = k0 + j * 128 + lc * 8;
-      kvalid[j] = kcol < p.Ktot;
-      const int kc = kvalid[j] ? kcol : 0;
+    for (int j = 0; j < NX; ++j) {
+      const int kcol = k0 + j * 64 + lc * 8;
+      const bool kv = kcol < p.Ktot;
+      const int kc = kv ? kcol : 0;
       const int tap = kc / p.C_in, tc = kc - tap * p.C_in;
-      tr[j] = kvalid[j] ? tap / p.S : (1 << 24);
+      tr[j] = kv ? tap / p.S : (1 << 24);                         // an invalid column fails the row bound check below
       ts[j] = tap - (tap / p.S) * p.S;
-      toff[j] = LIN ? kcol * 2 : ((tr[j] * p.W_in + ts[j]) * p.ldx + tc) * 2;
+      toff[j] = ((tr[j] * p.W_in + ts[j]) * p.ldx + tc) * 2;
     }
-    const int ycol = (n0 + lc * 8 < p.C_out) ? (n0 + lc * 8) * 2 : -1;
-    const int ldx2 = p.ldx * 2, ldy2 = p.ld_dy * 2;
-    int m_run = blk_begin + 4 * kWgGpl * lw + r4;                 // rows visited: the groups of i = 0, then of i = 1
-    int img = 0, oh = 0, ow = 0;
-    if (!LIN) {
+#pragma unroll
+    for (int j = 0; j < NY; ++j) ycol[j] = (n0 + j * 64 + lc * 8 < p.C_out) ? (n0 + j * 64 + lc * 8) * 2 : -1;
+    const int ldy2 = p.ld_dy * 2;
+    int m_run = blk_begin + 8 * lw + r8;                          // + 64 per step
+    int img, oh, ow;
+    {
       const unsigned mm = (unsigned)min(m_run, p.M - 1);
       img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
       const int pix = (int)mm - img * p.HW_out;
@@ -867,78 +872,66 @@ __device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const
       ow = pix - oh * p.W_out;
     }
     int st_issue = 0, st_bias = 0;
-#define MBX_ISSUE_STEP4()                                                                                      \
+#define MBX_ISSUE_STEP5()                                                                                      \
   do {                                                                                                         \
-    u32x4* sp = smem + st_issue * STAGE + (kWgGpl * lw) * 64;                                                  \
-    _Pragma("unroll") for (int slot = 0; slot < 2 * kWgGpl; ++slot) {                                          \
-      const bool mv = m_run < blk_end;                                                                         \
-      int xoff0, xoff1, yoff;                                                                                  \
-      if (LIN) {                                                                                               \
-        const int rb = m_run * ldx2;                                                                           \
-        xoff0 = (mv && kvalid[0]) ? rb + toff[0] : (int)kOOB;                                                  \
-        xoff1 = (mv && kvalid[1]) ? rb + toff[1] : (int)kOOB;                                                  \
-        yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                                          \
-      } else {                                                                                                 \
-        const int h0 = oh * p.stride - p.pad_t, w0 = ow * p.stride - p.pad_l;                                  \
-        const int rb = (img * p.x_img_stride + (h0 * p.W_in + w0) * p.ldx) * 2;                                \
-        const bool ok0 = mv && ((unsigned)(h0 + tr[0]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[0]) < (unsigned)p.W_in); \
-        const bool ok1 = mv && ((unsigned)(h0 + tr[1]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[1]) < (unsigned)p.W_in); \
-        xoff0 = ok0 ? rb + toff[0] : (int)kOOB;                                                                \
-        xoff1 = ok1 ? rb + toff[1] : (int)kOOB;                                                                \
-        if (q.ydense) yoff = (mv && ycol >= 0) ? (m_run * ldy2 + ycol) : (int)kOOB;                            \
-        else yoff = (mv && ycol >= 0) ? ((img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2 + ycol) : (int)kOOB; \
-      }                                                                                                        \
-      u32x4* d = sp + (slot % kWgGpl) * 64 + (slot / kWgGpl) * 512;                                            \
-      glds16(yr, d, yoff);                                                                                     \
-      glds16(xr, d + SUB, xoff0);                                                                              \
-      glds16(xr, d + 2 * SUB, xoff1);                                                                          \
-      const int adv = (slot % kWgGpl == kWgGpl - 1) ? 32 - 4 * (kWgGpl - 1) : 4;                               \
-      m_run += adv;                                                                                            \
-      if (!LIN) {                                                                                              \
-        ow += adv;                                                                                             \
-        while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                         \
-        while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                        \
-      }                                                                                                        \
+    u32x4* d = smem + st_issue * STAGE + lw * 64;                                                              \
+    const bool mv = m_run < blk_end;                                                                           \
+    const int h0 = oh * p.stride - p.pad_t, w0 = ow * p.stride - p.pad_l;                                      \
+    const int rb = (img * p.x_img_stride + (h0 * p.W_in + w0) * p.ldx) * 2;                                    \
+    const int yb = q.ydense ? m_run * ldy2 : (img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2;      \
+    _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                             \
+      glds16(yr, d + j * 512, (mv && ycol[j] >= 0) ? yb + ycol[j] : (int)kOOB);                                \
+    _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                           \
+      const bool ok = mv && ((unsigned)(h0 + tr[j]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[j]) < (unsigned)p.W_in); \
+      glds16(xr, d + (NY + j) * 512, ok ? rb + toff[j] : (int)kOOB);                                           \
     }                                                                                                          \
+    m_run += 64;                                                                                               \
+    ow += 64;                                                                                                  \
+    while (ow >= p.W_out) { ow -= p.W_out; ++oh; }                                                             \
+    while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                            \
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                         \
   } while (0)
 
-    if (nsteps > 0) MBX_ISSUE_STEP4();
-    constexpr int NDMA = 6 * kWgGpl;                      // LDS-DMA instructions per wave and step
-    constexpr int RB = 4 * kWgLoaders;                    // bias sums: loader thread lt takes rows (lt >> 4) + RB j
-    if (nsteps > 1) { MBX_ISSUE_STEP4(); wait_vmcnt<NDMA>(); } else wait_vmcnt<0>();
+    if (nsteps > 0) MBX_ISSUE_STEP5();
+    if (nsteps > 1) { MBX_ISSUE_STEP5(); wait_vmcnt<NSUB>(); } else wait_vmcnt<0>();
     raw_barrier();                                        // step 0 has landed
-    const int lt = threadIdx.x - 512;                     // bias sums: rows (lt >> 4) + RB j, LDS slot lt & 15
+    const int lt = threadIdx.x - 512;                     // 0..511: bias sums of slot lt (row lt >> 3) of every dy image
+    float bs[NY][8];
+#pragma unroll
+    for (int j = 0; j < NY; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bs[j][e] = 0.f;
     for (int it = 0; it < nsteps; ++it) {
       const bool more = it + 2 < nsteps;
-      if (more) MBX_ISSUE_STEP4();
-      if (bias) {                                         // dy image of the step being multiplied (landed, read-only now)
+      if (more) MBX_ISSUE_STEP5();
+      if (bias) {                                         // dy images of the step being multiplied (landed, read-only now)
         const u32x4* img_y = smem + st_bias * STAGE;
 #pragma unroll
-        for (int j = 0; j < 64 / RB; ++j) {
-          const u32x4 v = img_y[((lt >> 4) + RB * j) * 16 + (lt & 15)];
+        for (int j = 0; j < NY; ++j) {
+          const u32x4 v = img_y[j * 512 + lt];
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bs[2 * e] += bf2f(w[e] & 0xffffu); bs[2 * e + 1] += bf2f(w[e] >> 16); }
+          for (int e = 0; e < 4; ++e) { bs[j][2 * e] += bf2f(w[e] & 0xffffu); bs[j][2 * e + 1] += bf2f(w[e] >> 16); }
         }
         st_bias = st_bias == NST - 1 ? 0 : st_bias + 1;
       }
-      if (more) wait_vmcnt<NDMA>(); else wait_vmcnt<0>(); // step it+1 has landed (this wave's share), then everyone's
+      if (more) wait_vmcnt<NSUB>(); else wait_vmcnt<0>(); // step it+1 has landed (this wave's share), then everyone's
       raw_barrier();
     }
-#undef MBX_ISSUE_STEP4
-    if (bias) {                                           // 16 row groups per channel -> LDS -> one adder per channel
+#undef MBX_ISSUE_STEP5
+    if (bias) {                                           // 64 rows per channel -> LDS -> one adder per channel
       lds_barrier();                                      // (the compute waves are past their last LDS read)
-      float* red = reinterpret_cast<float*>(smem);        // [RB row groups][128 channels]
-      const int rg = lt >> 4, cg = (lt & 15) ^ wg_swz(lt >> 4);      // logical chunk of this thread's slot (RB = 16, 32: rows
-                                                                     // RB j apart share row & 3 and row bit 3)
+      float* red = reinterpret_cast<float*>(smem);        // [NY][64 rows][64 channels]
+      const int row = lt >> 3, cg = (lt & 7) ^ wg_swz64(lt >> 3);     // logical chunk of this thread's slot
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[rg * 128 + cg * 8 + j] = bs[j];
+      for (int j = 0; j < NY; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(j * 64 + row) * 64 + cg * 8 + e] = bs[j][e];
       lds_barrier();
-      if (lt < 128 && n0 + lt < p.C_out) {
+      if (lt < 64 * NY && n0 + lt < p.C_out) {
+        const int j = lt >> 6, c = lt & 63;
         float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) t += red[r * 128 + lt];
+        for (int r = 0; r < 64; ++r) t += red[(j * 64 + r) * 64 + c];
         atomicAdd(p.db + n0 + lt, t * p.scale);
       }
     }
@@ -946,22 +939,29 @@ __device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const
   }
 
   // ---------------------------------------------------------------------------------------------- compute waves
-  const int wn = wave & 1, wk = wave >> 1;                        // 64-channel half, 64-column quarter
+  // 2 (channels) x 4 (columns) waves; a wave owns A = 2 NY channel blocks x NX column blocks of 16 x 16
+  constexpr int A = 2 * NY;
+  const int wn = wave & 1, wk = wave >> 1;
   // fragment (transpose-read) lane constants, byte offsets inside a stage
   const int g = lane >> 4, t = lane & 15, fq = t >> 2, pp = t & 3;
-  const int lb = (8 * g + fq) * 256 + (pp & 1) * 8;
-  const int sx = ((fq & 3) | ((g & 1) << 2)) << 1;
-  int yo[4], xo[4];
+  const int lby = (8 * g + fq) * 128 + (pp & 1) * 8;
+  const int sxy = ((((fq >> 1) & 1) | ((g & 1) << 1)) << 1);
+  int yo[A], xo[NX];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    yo[a] = lb + (((2 * (wn * 4 + a) + (pp >> 1)) ^ sx) << 4);
-    xo[a] = lb + (((2 * ((wk & 1) * 4 + a) + (pp >> 1)) ^ sx) << 4) + (1 + (wk >> 1)) * SUB * 16;
+  for (int a = 0; a < A; ++a) {
+    const int nb = wn * A + a;                                    // channel block 0 .. 4 NY - 1 of the tile
+    yo[a] = (nb >> 2) * 8192 + lby + (((2 * (nb & 3) + (pp >> 1)) ^ sxy) << 4);
   }
-  f32x4 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int b = 0; b < NX; ++b) {
+    const int kb = wk * NX + b;                                   // column block 0 .. 4 NX - 1
+    xo[b] = (NY + (kb >> 2)) * 8192 + lby + (((2 * (kb & 3) + (pp >> 1)) ^ sxy) << 4);
+  }
+  f32x4 acc[A][NX];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b < NX; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   int st_comp = 0;
   typedef s16x4 __attribute__((address_space(3))) * lds_tr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -971,25 +971,25 @@ __device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const
       const char* base = reinterpret_cast<const char*>(smem + st_comp * STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 yf[4], xf[4];
+        bf16x8 yf[A], xf[NX];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 8192 + 1024));
+        for (int a = 0; a < A; ++a) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096 + 512));
           const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           yf[a] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 8192 + 1024));
+        for (int b = 0; b < NX; ++b) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 4096));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 4096 + 512));
           const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           xf[b] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < A; ++a)
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < NX; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
       }
     }
@@ -999,11 +999,11 @@ __device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const
   }
   if (bias) { lds_barrier(); lds_barrier(); }             // the loaders reduce the bias sums through LDS meanwhile
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int nb = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+  for (int a = 0; a < A; ++a) {
+    const int nb = n0 + (wn * A + a) * 16 + (lane >> 4) * 4;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int kc = k0 + wk * 64 + b * 16 + (lane & 15);
+    for (int b = 0; b < NX; ++b) {
+      const int kc = k0 + (wk * NX + b) * 16 + (lane & 15);
       if (kc >= p.Ktot) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1014,15 +1014,6 @@ __device__ __forceinline__ void wgrad4_body(const WgradK2& q, u32x4* smem, const
       }
     }
   }
-}
-
-// what a loader wave of the 12-wave grouped kernel does while waves 0-7 run a NARROW item (wgrad_narrow_body with
-// NG = 2: all of its barriers are block-wide): the same number of barriers, nothing else
-__device__ __forceinline__ void wgrad_narrow_idle(const int blk_begin, const int blk_end) {
-  const int half = ((((blk_end - blk_begin) + 1) / 2 + 63) & ~63);
-  const int nsteps = (half + 63) >> 6;
-  for (int i = 0; i < nsteps + 1; ++i) raw_barrier();     // prologue + one per step
-  __syncthreads();                                        // group 1 -> LDS -> group 0 exchange
 }
 
 template <int NST, int NG, bool LIN, bool BIAS>
@@ -1058,8 +1049,9 @@ conv_wgrad2n_kernel(const WgradK2 q) {
 // (no atomic traffic to speak of, bit-reproducible), loops run for hundreds of steps instead of a dozen, and
 // there is one launch tail per segment instead of one per layer.
 struct WgradLayer { WgradK2 q; int narrow, lin, pad0, pad1; };
-struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, single, pad1, pad2; };   // single: the only adder of its dw tile
-constexpr int kWgradLds = 3 * 3 * 16384;               // wgrad4: three stages x (dy | x 0..127 | x 128..255) x 16 KB
+struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, single, cfg, pad2; };   // single: the only adder of its dw tile;
+                                                                                         // cfg: tile shape, index into kWgCfgs
+constexpr int kWgradLds = 3 * 3 * 16384;               // wgrad5: three stages x (dy | x 0..127 | x 128..255) x 16 KB
 constexpr int kQueues = 8;                             // one work queue per XCD
 constexpr int kCounterStride = 32;                     // ints: every queue head on its own 128-byte line
 
@@ -1069,13 +1061,16 @@ constexpr int kCounterStride = 32;                     // ints: every queue head
 // blocks that share an L2 walk the same pixels at the same time and all but the first read of a row is an L2 hit
 // (LDS-DMA from the XCD's L2 runs at twice the rate of the Infinity Cache, MI355X_MICROARCH.md "Indexed rows").
 // Placement is for speed only: any block may run any item.
+// tile shapes (NY, NX) the grouped launch is instantiated for: index = WgradItem.cfg
+constexpr int kWgCfgs[][2] = {{1, 4}, {1, 5}, {2, 2}, {2, 3}, {2, 4}, {3, 2}, {3, 3}};
+constexpr int kNumWgCfgs = sizeof(kWgCfgs) / sizeof(kWgCfgs[0]);
+
 __global__ void __launch_bounds__(64 * (8 + kWgLoaders))
 conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem* __restrict__ items,
                           const int* __restrict__ qrange /*[2][kQueues]: begin | end*/, int* __restrict__ heads) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   volatile int* s_idx = reinterpret_cast<volatile int*>(smem + kWgradLds / 16);     // one word past the rings
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (kQueues - 1);         // HW_REG_XCC_ID[3:0]
-  const bool loader = wave_id() >= 8;
   for (int q = 0; q < kQueues; ++q) {
     const int qx = (xcd + q) & (kQueues - 1);
     const int qb = qrange[qx], qe = qrange[kQueues + qx];
@@ -1089,16 +1084,14 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
       const int idx = __builtin_amdgcn_readfirstlane(*s_idx);
       if (idx >= qe) break;
       const WgradItem it = items[idx];                   // block-uniform: scalar loads
-      const WgradLayer& L = layers[it.layer];
-      const WgradK2 q2 = L.q;
-      if (L.narrow) {
-        if (loader) wgrad_narrow_idle(it.m_begin, it.m_end);
-        else if (L.lin) wgrad_narrow_body<2, 2, true, true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-        else wgrad_narrow_body<2, 2, false, true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end);
-      } else {
-        if (L.lin) wgrad4_body<true>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end, it.single);
-        else wgrad4_body<false>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end, it.single);
+      const WgradK2 q2 = layers[it.layer].q;
+#define MBX_WG_CASE(I)                                                                                         \
+      case I: wgrad5_body<kWgCfgs[I][0], kWgCfgs[I][1]>(q2, smem, it.tile_n, it.tile_k, it.m_begin, it.m_end, it.single); break;
+      switch (it.cfg) {
+        MBX_WG_CASE(0) MBX_WG_CASE(1) MBX_WG_CASE(2) MBX_WG_CASE(3) MBX_WG_CASE(4) MBX_WG_CASE(5) MBX_WG_CASE(6)
+        default: break;
       }
+#undef MBX_WG_CASE
     }
   }
 }
@@ -1450,32 +1443,39 @@ static int plan_cus() {
   return ncu;
 }
 
-struct PlanJob { int narrow, tiles_n, tiles_k, steps, splits; };
+struct PlanJob { int cfg, ny, nx, tiles_n, tiles_k, steps, splits; double step_cost; };
 struct PlanGroup { int job, m_begin, m_end, tiles; double len; };     // all output tiles of one (layer, pixel range)
 
 static void plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, std::vector<PlanJob>& pj) {
-  // work unit: one 64-pixel step of one tile.  A tile is split only when it is longer than a quarter of a CU's fair
-  // share of the whole group (and never below 16 steps per piece): most tiles keep a single adder.
+  // Tile shape per layer: the launch is bound by the bytes a CU pulls through the L2 -> LDS path (8 KB per sub-image and
+  // 64-pixel step, ~390 cycles at the measured ~45 GB/s per CU) unless the MFMAs of the step take longer (128 NY NX
+  // cycles: 4 NY NX per wave, 16 cycles each, two compute waves per SIMD) -- take the shape with the smallest total.
+  // Work unit for splitting: one 64-pixel step of one tile, weighted by that cost.  A tile is split only when it is
+  // longer than a quarter of a CU's fair share of the whole group (and never below 16 steps per piece): most tiles keep
+  // a single adder.
   double total = 0.0;
   pj.resize(n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
     const mbx_conv_desc& d = jobs[j].desc;
     const long long M = (long long)d.N * d.H_out * d.W_out;
     const int Ktot = d.R * d.S * d.C_in;
-    const bool dense = jobs[j].dy_img_stride == (int64_t)d.H_out * d.W_out * jobs[j].ld_dy;
-    // narrow (64-channel) tile only where the 128-wide one would be at least half padding: per 64-pixel step a wide
-    // tile stages 128 + 128 rows, a narrow one 64 + 128, so ceil(C/128) * 256 <= ceil(C/64) * 192 unless C_out <= 64
-    pj[j].narrow = (d.C_out <= 64 && dense) ? 1 : 0;
-    pj[j].tiles_n = pj[j].narrow ? (d.C_out + 63) / 64 : (d.C_out + 127) / 128;
-    pj[j].tiles_k = pj[j].narrow ? (Ktot + 127) / 128 : (Ktot + 255) / 256;     // wgrad3: 256 filter columns per tile
+    double best = 1e300;
+    for (int c = 0; c < kNumWgCfgs; ++c) {
+      const int ny = kWgCfgs[c][0], nx = kWgCfgs[c][1];
+      const int tn = (d.C_out + 64 * ny - 1) / (64 * ny), tk = (Ktot + 64 * nx - 1) / (64 * nx);
+      const double dma = 390.0 * (ny + nx), mfma = 128.0 * ny * nx;
+      const double step = dma > mfma ? dma : mfma;
+      const double cost = (double)tn * tk * step;
+      if (cost < best) { best = cost; pj[j].cfg = c; pj[j].ny = ny; pj[j].nx = nx; pj[j].tiles_n = tn; pj[j].tiles_k = tk; pj[j].step_cost = step / (390.0 * 6); }
+    }
     pj[j].steps = (int)((M + 63) / 64);
-    total += (double)pj[j].tiles_n * pj[j].tiles_k * pj[j].steps;
+    total += (double)pj[j].tiles_n * pj[j].tiles_k * pj[j].steps * pj[j].step_cost;
   }
   const double share = total / plan_cus();
   double wmax = share / 4.0;
   if (wmax < 16.0) wmax = 16.0;
   for (int j = 0; j < n_jobs; ++j) {
-    int splits = (flags & MBX_WGRAD_DETERMINISTIC) ? 1 : (int)((pj[j].steps + wmax - 1) / wmax);
+    int splits = (flags & MBX_WGRAD_DETERMINISTIC) ? 1 : (int)((pj[j].steps * pj[j].step_cost + wmax - 1) / wmax);
     const int max_splits = (pj[j].steps + 15) / 16;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1497,7 +1497,7 @@ static void plan_queues(const mbx_wgrad_job* jobs, int n_jobs, int flags, const 
       PlanGroup g;
       g.job = j; g.m_begin = (int)b; g.m_end = (int)(b + mps < M ? b + mps : M);
       g.tiles = pj[j].tiles_n * pj[j].tiles_k;
-      g.len = (double)((g.m_end - g.m_begin + 63) / 64) * (pj[j].narrow ? 0.6 : 1.0);   // a narrow step stages 24 of 48 KB
+      g.len = (double)((g.m_end - g.m_begin + 63) / 64) * pj[j].step_cost;
       groups.push_back(g);
     }
   }
@@ -1518,6 +1518,7 @@ static void plan_queues(const mbx_wgrad_job* jobs, int n_jobs, int flags, const 
         memset(&I, 0, sizeof(I));
         I.layer = g.job; I.tile_n = tn; I.tile_k = tk; I.m_begin = g.m_begin; I.m_end = g.m_end;
         I.single = pj[g.job].splits == 1 ? 1 : 0;
+        I.cfg = pj[g.job].cfg;
         q[best].push_back(I);
         load[best] += g.len;
       }
@@ -1572,7 +1573,7 @@ extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, 
     WgradLayer& L = layers[j];
     const int status = fill_wgrad(&J.desc, J.dy, J.dy_img_stride, J.ld_dy, J.scale, J.dw, J.db, L.q);
     if (status != MBX_OK) return status;
-    L.narrow = pj[j].narrow;
+    L.narrow = 0;
     L.lin = (L.q.pw && L.q.ydense) ? 1 : 0;
     L.q.b.tiles_n = pj[j].tiles_n;
     flops += 2.0 * L.q.b.M * (double)L.q.b.C_out * L.q.b.Ktot;

@@ -12,7 +12,11 @@ from multibox_amd import _lib, ops
 
 
 class _Item(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("layer", "tile_n", "tile_k", "m_begin", "m_end", "p0", "p1", "p2")]
+    _fields_ = [(n, C.c_int32) for n in ("layer", "tile_n", "tile_k", "m_begin", "m_end", "single", "cfg", "p2")]
+
+
+# tile shapes of the grouped launch, in 64-channel / 64-column sub-images (kWgCfgs in csrc/conv.hip)
+WG_CFGS = [(1, 4), (1, 5), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3)]
 
 
 def _jobs():
@@ -61,17 +65,17 @@ def test_plan_covers_every_tile_once(flags):
     # queues partition the item table
     begin, end = q[:8], q[8:]
     assert begin[0] == 0 and end[-1] == info.n_items and all(begin[1:] == end[:-1]) and all(end >= begin)
-    cover = {}
+    cover, cfg_of = {}, {}
     for i, it in enumerate(items):
         cover.setdefault((it.layer, it.tile_n, it.tile_k), []).append((it.m_begin, it.m_end, i))
+        assert 0 <= it.cfg < len(WG_CFGS) and cfg_of.setdefault(it.layer, it.cfg) == it.cfg     # one shape per layer
     flops = 0.0
     for j, job in enumerate(jobs):
         d = job.desc
         M, Kt = d.N * d.H_out * d.W_out, d.R * d.S * d.C_in
         flops += 2.0 * M * d.C_out * Kt
-        narrow = d.C_out <= 64
-        tn = -(-d.C_out // (64 if narrow else 128))
-        tk = -(-Kt // (128 if narrow else 256))
+        ny, nx = WG_CFGS[cfg_of[j]]
+        tn, tk = -(-d.C_out // (64 * ny)), -(-Kt // (64 * nx))
         for a in range(tn):
             for b in range(tk):
                 r = sorted(cover.pop((j, a, b)))
@@ -80,6 +84,7 @@ def test_plan_covers_every_tile_once(flags):
                 assert all(x[0] % 64 == 0 for x in r)
                 if flags & 1:
                     assert len(r) == 1, "MBX_WGRAD_DETERMINISTIC: one adder per dw element"
+                assert all(items[x[2]].single == (1 if len(r) == 1 else 0) for x in r)     # plain stores only when alone
     assert not cover, "items outside every layer's tile grid"
     assert abs(info.flops - flops) <= 1e-9 * flops
     if not flags & 2:

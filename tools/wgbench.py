@@ -1,5 +1,5 @@
 """Micro-benchmark of the GROUPED weight-gradient launch (mbx_conv_wgrad_grouped) one layer shape at a time, and of
-all of them in one launch: time, useful TFLOP/s, and the padded work the tiles really do (tile-steps x 4.2 MFLOP).
+all of them in one launch: time, useful TFLOP/s, and the padded work the tiles really do (tile-steps x tile area).
 usage: python tools/wgbench.py            (KB_B=64 batch; KB_ONLY=substring filter)"""
 import ctypes as C
 import os
@@ -41,7 +41,10 @@ iters = int(os.environ.get("KB_ITERS", "10"))
 
 
 class Item(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("layer", "tile_n", "tile_k", "m_begin", "m_end", "p0", "p1", "p2")]
+    _fields_ = [(n, C.c_int32) for n in ("layer", "tile_n", "tile_k", "m_begin", "m_end", "single", "cfg", "p2")]
+
+
+WG = [(1, 4), (1, 5), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3)]      # kWgCfgs (csrc/conv.hip)
 
 
 def timeit(fn):
@@ -79,9 +82,8 @@ def padded_flops(group, jobs):
     items = (Item * info.n_items).from_buffer_copy(raw[info.items_off:info.items_off + 32 * info.n_items])
     tot = 0.0
     for it in items:
-        narrow = jobs[it.layer].desc.C_out <= 64
         steps = (it.m_end - it.m_begin + 63) // 64
-        tot += steps * 2.0 * 64 * (64 if narrow else 128) * (128 if narrow else 256)
+        ny, nx = WG[it.cfg]; tot += steps * 2.0 * 64 * (64 * ny) * (64 * nx)
     return tot, info.n_items
 
 
