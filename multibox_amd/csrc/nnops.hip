@@ -248,22 +248,37 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
                       const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ beta, int relu,
                       unsigned short* __restrict__ a, int ld_a, float* __restrict__ mean, float* __restrict__ rstd,
                       float* __restrict__ mmean, float* __restrict__ mvar, int rows_per_chunk) {
-  __shared__ double red[4][kBnGroup][2];
+  __shared__ double red[8][kBnGroup][2];
   __shared__ float s_mean[kBnGroup], s_rstd[kBnGroup], s_beta[kBnGroup];
   const int c0 = blockIdx.x * kBnGroup;
   const int cw = min(kBnGroup, C - c0);
   {
-    const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    double s1 = 0.0, s2 = 0.0;
-    if (ch < cw)
-      for (int r = rl; r < rows; r += 4) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c0 + ch) * 2);
-        s1 += v.x; s2 += v.y;
+    // lane = (channel pair, one of 8 row lanes): 16-byte loads of {sum, sumsq} x 2 channels, SIXTEEN partial rows in
+    // flight per lane (one L2 round trip per batch instead of one per row).  The order of the additions is fixed, so
+    // every workgroup of a channel group computes bit-identical statistics.  (C % 8 == 0: a pair never straddles C.)
+    const int cp = (threadIdx.x & 31) * 2, rl = threadIdx.x >> 5;
+    double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
+    if (cp < cw) {
+      const float* src = part + ((size_t)c0 + cp) * 2;
+      int r = rl;
+      for (; r + 8 * 15 < rows; r += 8 * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 8 * u) * C * 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s1a += v[u].x; s2a += v[u].y; s1b += v[u].z; s2b += v[u].w; }
       }
-    red[rl][ch][0] = s1; red[rl][ch][1] = s2;
+      for (; r < rows; r += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * C * 2);
+        s1a += v.x; s2a += v.y; s1b += v.z; s2b += v.w;
+      }
+    }
+    red[rl][cp][0] = s1a; red[rl][cp][1] = s2a; red[rl][cp + 1][0] = s1b; red[rl][cp + 1][1] = s2b;
     __syncthreads();
-    if (rl == 0 && ch < cw) {
-      for (int r = 1; r < 4; ++r) { s1 += red[r][ch][0]; s2 += red[r][ch][1]; }
+    const int ch = threadIdx.x;
+    if (ch < cw) {
+      double s1 = red[0][ch][0], s2 = red[0][ch][1];
+      for (int r = 1; r < 8; ++r) { s1 += red[r][ch][0]; s2 += red[r][ch][1]; }
       const double m = s1 * inv_count;
       double var = s2 * inv_count - m * m;
       if (var < 0.0) var = 0.0;
@@ -296,9 +311,12 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
   }
 }
 
-inline void bn_fused_grid(long long M, int C, int& groups, int& chunks, int& rpc) {
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline void bn_fused_grid(long long M, int C, int rows, int& groups, int& chunks, int& rpc) {
   groups = (C + kBnGroup - 1) / kBnGroup;
-  long long want = 1024 / groups;
+  // every workgroup re-reduces rows x 64 partials: with many partial rows, fewer (longer) workgroups
+  static const int blocks_few = env_int("MBX_BN_FUSED_BLOCKS", 1024), blocks_many = env_int("MBX_BN_FUSED_BLOCKS_MANY", 256);
+  long long want = (rows > 16 ? blocks_many : blocks_few) / groups;
   if (want < 1) want = 1;
   long long maxc = (M + 255) / 256;
   if (want > maxc) want = maxc;
@@ -1168,14 +1186,20 @@ extern "C" int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t 
   if (!stats_partial || !y || !a || !beta || !mean || !rstd || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_a % 8 ||
       count <= 0 || !al16(y) || !al16(a))
     return MBX_ERR_INVALID_ARG;
-  if (rows > 16) {            // re-reducing more partial rows per workgroup costs more than the extra launch (measured)
+  // Fused (one launch: every workgroup re-reduces the partial rows of its 64 channels) only for few partial rows.  In
+  // isolation (tools/bnf_bench.py) the fused launch wins up to ~1000 rows on small tensors (8 vs 13 us); inside the
+  // captured step it LOSES 0.28 ms (round 2, same-box A/B, MBX_BN_FUSED_ROWS=1024): a graph-internal kernel boundary
+  // costs ~1.5 us, the 5 us finalize overlaps the conv's tail, and 256 long workgroups stream a cold tensor badly.
+  static const int fused_rows = env_int("MBX_BN_FUSED_ROWS", 16);
+  static const long long fused_elems = env_int("MBX_BN_FUSED_KELEMS", 6200) * 1000LL;
+  if (rows > 16 && (rows > fused_rows || M * C > fused_elems)) {
     int st = mbx_bn_finalize(stats_partial, rows, C, count, eps, decay, mean, rstd, mmean, mvar, stream);
     if (st != MBX_OK) return st;
     return mbx_bn_apply(y, M, C, mean, rstd, beta, relu, a, ld_a, stream);
   }
   MBX_ENTER();
   int groups, chunks, rpc;
-  bn_fused_grid(M, C, groups, chunks, rpc);
+  bn_fused_grid(M, C, rows, groups, chunks, rpc);
   hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
                      1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
                      mvar, rpc);

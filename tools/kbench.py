@@ -53,10 +53,14 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
         continue
     Ho = (H + 2 * pt - R) // st + 1
     Wo = (W + 2 * pl - S) // st + 1
-    x = ops.View.alloc(B, H, W, Ci); x.buf.normal_()
-    y = ops.View.alloc(B, Ho, Wo, Co)
-    dy = ops.View.alloc(B, Ho, Wo, Co); dy.buf.normal_()
-    dx = ops.View.alloc(B, H, W, Ci)
+    # KB_LDX / KB_LDY: pixel pitch (channels) of the input / output buffers, as when the tensors are channel slices of a
+    # wider buffer (block17's 672-channel branch buffer: KB_LDX=672); default = dense
+    ldx, ldy = int(os.environ.get("KB_LDX", "0")) or Ci, int(os.environ.get("KB_LDY", "0")) or Co
+    ldx, ldy = max(ldx, Ci), max(ldy, Co)
+    x = ops.View.alloc(B, H, W, ldx).slice(0, Ci); x.buf.normal_()
+    y = ops.View.alloc(B, Ho, Wo, ldy).slice(0, Co)
+    dy = ops.View.alloc(B, Ho, Wo, ldy).slice(0, Co); dy.buf.normal_()
+    dx = ops.View.alloc(B, H, W, ldx).slice(0, Ci)
     w = (torch.randn(Co, R, S, Ci, device="cuda") * 0.05).to(torch.bfloat16)
     wT = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
