@@ -20,7 +20,8 @@ ARCH = "gfx950"
 SOURCES = {
     "priors.cpp": ["-ffp-contract=off"],
     "postproc.hip": ["-ffp-contract=off"],
-    "conv.hip": ["-munsafe-fp-atomics"] + ([("-DMBX_WG_LOADERS=" + os.environ["MBX_WG_LOADERS"])] if os.environ.get("MBX_WG_LOADERS") else []),
+    "conv.hip": ["-munsafe-fp-atomics"],
+    "conv5.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,350 @@
+// libmbx: conv_igemm5_kernel -- the persistent, loader / compute specialised implicit-GEMM convolution (round 2) -- and
+// its launcher.  Separate translation unit so that it compiles beside conv.hip.
+#include "conv_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ igemm5
+// The same implicit GEMM (same LDS image, same K order, same MFMA order: bit-identical results), restructured the way
+// the grouped weight gradient was in round 2:
+//  * SIXTEEN waves with fixed roles: waves 0-7 multiply, waves 8-15 issue the LDS-DMA.  In conv_igemm3_kernel every
+//    wave does both behind one barrier, so the ~0.5 us of DMA issue and the LDS reads + MFMAs of a K step add up; it
+//    gets its overlap from 2-3 small blocks per CU, which caps the tile at 128 x 64 / 128 x 128 (43 - 64 FLOP per byte
+//    pulled through the L2 -> LDS path, and that path, ~45 GB/s per CU, is what bounds these launches).
+//  * PERSISTENT: one block per CU walks tiles t = first, first + grid, ...; the loaders run two K steps ahead ACROSS
+//    tile boundaries, so the next tile's first filter / pixel tiles land while the compute waves write the current
+//    tile out.  The epilogue therefore cannot borrow the ring: it goes through its own LDS window, CR rows at a time
+//    (the loaders attend its barriers).
+//  * Tiles are (64 MY pixels) x (64 NW channels): 192 x 128 and 256 x 128 move 77 / 85 FLOP per byte.
+// Stride-2 data gradients and the float32 head epilogue stay on conv_igemm3_kernel.
+template <int MY, int NW>
+struct Ig5 {
+  static constexpr int BM = 64 * MY, BN = 64 * NW;
+  static_assert(NW == 1 || NW == 2 || NW == 4, "64 / 128 / 256 output channels per tile (8-channel groups per row divide 512)");
+  // compute-wave grid (WM x WN = 8) and the 16 x 16 blocks per wave:
+  //   128x64: 4x2 (2x2 blocks)   256x64: 8x1 (2x4)   192x64: 4x2 (3x2)   64x128: 2x4 (2x2)   128x128: 2x4 (4x2)
+  //   192x128: 2x4 (6x2)         256x128: 4x2 (4x4)  128x256: 2x4 (4x4)
+  static constexpr int WM = (NW == 1) ? (MY == 4 ? 8 : 4) : (MY == 4 && NW == 2) ? 4 : 2;
+  static constexpr int WN = 8 / WM;
+  static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  static constexpr int STAGE = (BM + BN) * 8;                       // 16-byte slots per ring stage
+  static constexpr int NST = 3;
+  static constexpr int LDT = BN + 4;                                // floats per staged row
+  static constexpr int RING_BYTES = NST * STAGE * 16;
+  static constexpr int CR = (RING_BYTES + 64 * LDT * 4 <= 160 * 1024 - 64) ? 64 : (RING_BYTES + 32 * LDT * 4 <= 160 * 1024 - 64) ? 32 : 16;
+  static constexpr int EP_BYTES = CR * LDT * 4;
+  static constexpr int LDS_BYTES = RING_BYTES + EP_BYTES;
+  static constexpr int NCHUNK = BM / CR;                            // epilogue passes through the window
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && WM * WN == 8, "wave grid");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int MY, int NW, int EV, int MODE>
+__global__ void __launch_bounds__(1024)
+conv_igemm5_kernel(const ConvK p) {
+  using G = Ig5<MY, NW>;
+  constexpr bool PW = MODE == 1;
+  constexpr int BM = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, MI = G::MI, NI = G::NI, STAGE = G::STAGE, NST = G::NST;
+  constexpr int NL = MY + NW;                                       // LDS-DMA instructions per loader wave and K step
+  constexpr int LDT = G::LDT, CR = G::CR, NCHUNK = G::NCHUNK;
+  // row-wise walk of a window by the 512 compute threads: TPR threads per row, RP rows per pass
+  constexpr int TPR = BN / 8, RPP2 = 512 / TPR, RP = RPP2 < CR ? RPP2 : CR, NPASS = CR / RP;
+  static_assert(CR % RP == 0 && NPASS >= 1, "window rows per pass");
+  constexpr int NBAR = 2 * NCHUNK + (EV == 1 ? 2 : 0);              // barriers of one tile's epilogue
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  float* const ep = reinterpret_cast<float*>(smem + NST * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int first = xcd_remap(blockIdx.x, gridDim.x);               // tiles first, first + grid, ...
+  const int nk = (p.Ktot + 63) >> 6;
+
+  if (wave >= 8) {
+    // -------------------------------------------------------------------------------------------- loader waves
+    const int lw = wave - 8;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+    const int r8 = lane >> 3;
+    const int chunk = (lane & 7) ^ r8;                              // source chunk of this lane's slot (row & 7 == r8)
+    const int ldx2 = p.ldx * 2;
+    // issue cursor: (tile, K step) two steps ahead of the compute waves; row state of THAT tile
+    int t_i = first, it_i = 0, st_issue = 0;
+    int hb[MY], wb[MY], ro[MY], wo[NW];
+    int kc = 0, kr = 0, ks = 0;
+#define MBX5_SETUP_TILE()                                                                                     \
+  do {                                                                                                        \
+    const int tn_ = t_i % p.tiles_n, tm_ = t_i / p.tiles_n;                                                   \
+    _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                          \
+      const int m = tm_ * BM + 64 * i + 8 * lw + r8;                                                          \
+      const bool mv = m < p.M;                                                                                \
+      int img, oh, ow;                                                                                        \
+      decode_pixel(p, mv ? (unsigned)m : 0u, img, oh, ow);                                                    \
+      hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);                                                         \
+      wb[i] = ow * p.mul - p.pad_l;                                                                           \
+      ro[i] = (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;                                  \
+      if (PW && !mv) ro[i] = (int)kOOB;                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                          \
+      const int n = tn_ * BN + 64 * i + 8 * lw + r8;                                                          \
+      wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;                                                              \
+    }                                                                                                         \
+    kc = chunk * 8; kr = 0; ks = 0;                                                                           \
+    while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
+  } while (0)
+#define MBX5_ISSUE()                                                                                          \
+  do {                                                                                                        \
+    u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
+    const bool kv = kr < p.R;                                                                                 \
+    if (PW) {                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < MY; ++i)                                                          \
+        glds16(xr, sp + i * 512, (kv && ro[i] >= 0) ? (ro[i] + kc * 2) : (int)kOOB);                          \
+    } else {                                                                                                  \
+      const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;                                                    \
+      _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                        \
+        const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) &&                                  \
+                        ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);                                          \
+        glds16(xr, sp + i * 512, ok ? (ro[i] + toff) : (int)kOOB);                                            \
+      }                                                                                                       \
+    }                                                                                                         \
+    const int kb = (it_i * 64 + chunk * 8) * 2;                                                               \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                            \
+      glds16(wr, sp + (MY + i) * 512, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                         \
+    kc += 64;                                                                                                 \
+    while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
+    st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
+    if (++it_i == nk) { it_i = 0; t_i += gridDim.x; if (t_i < ntiles) MBX5_SETUP_TILE(); }                    \
+  } while (0)
+
+    if (t_i < ntiles) {
+      MBX5_SETUP_TILE();
+      MBX5_ISSUE();                                                 // global step 0
+      if (t_i < ntiles) { MBX5_ISSUE(); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
+    }
+    raw_barrier();                                                  // step 0 has landed
+    for (int t = first; t < ntiles; t += gridDim.x) {
+      for (int it = 0; it < nk; ++it) {
+        const bool more = t_i < ntiles;                             // anything left to issue (this or a later tile)?
+        if (more) MBX5_ISSUE();
+        if (more) wait_vmcnt<NL>(); else wait_vmcnt<0>();           // the NEXT step has landed (this wave's share)
+        raw_barrier();
+      }
+#pragma unroll 1
+      for (int b = 0; b < NBAR; ++b) raw_barrier();                 // the compute waves' epilogue (own LDS window)
+    }
+#undef MBX5_ISSUE
+#undef MBX5_SETUP_TILE
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- compute waves
+  constexpr int WN = G::WN;
+  const int wn = wave % WN, wm = wave / WN;
+  const int frow = lane & 15, fch = lane >> 4;
+  const int fr0 = frow * 8 + (fch ^ (frow & 7));
+  const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
+  int st_comp = 0;
+  raw_barrier();                                                    // step 0 has landed
+  for (int t = first; t < ntiles; t += gridDim.x) {
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < nk; ++it) {
+      const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
+      const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int fr = kk ? fr1 : fr0;
+        bf16x8 wf[NI], pf[MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[a * 128 + fr]);
+#pragma unroll
+        for (int b = 0; b < MI; ++b) pf[b] = __builtin_bit_cast(bf16x8, cP[b * 128 + fr]);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+      }
+      st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS reads are done before the stage is reused
+      raw_barrier();
+    }
+    // ---------------------------------------------------------------- epilogue: CR rows at a time through `ep`
+    const int cg = tid % TPR, r0 = tid / TPR;                       // this thread's 8-channel group and row inside a pass
+    const int c0 = n0 + cg * 8;
+    const bool cok = c0 < p.C_out;                                  // C_out % 8 == 0 for bf16 outputs
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+    if constexpr (EV == 3 || EV == 4) {
+      if (cok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (p.scale) sc[j] = p.scale[c0 + j];
+          if (p.shiftv) sh[j] = p.shiftv[c0 + j];
+        }
+      }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+      // the accumulator blocks whose rows fall into this window (compile-time block index, run-time predicate)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        const int row = wm * TM + b * 16 + frow - ch * CR;
+        if ((unsigned)(wm * TM + b * 16 - ch * CR) < (unsigned)CR) {
+#pragma unroll
+          for (int a = 0; a < NI; ++a)
+            *reinterpret_cast<f32x4*>(ep + row * LDT + wn * TN + a * 16 + fch * 4) = acc[a][b];
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int wrow = ps * RP + r0;                              // row inside the window
+        const int m = m0 + ch * CR + wrow;
+        if (r0 < RP && m < p.M && cok) {
+          const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8 + 4);
+          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + img * p.y_img_stride + pix * p.ldy + c0;
+          if constexpr (EV == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+          } else if constexpr (EV == 4) {
+            const u32x4 sk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+            const unsigned w[4] = {sk.x, sk.y, sk.z, sk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[2 * j]);
+              v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[2 * j + 1]);
+            }
+          } else {
+            if (p.rscale != 0.f) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
+            }
+          }
+          if constexpr (EV == 2) {
+            if (p.accumulate) {
+              const u32x4 old = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
+              const unsigned w[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
+            }
+            if (p.skip) {                      // relu backward of the tensor this gradient belongs to
+              const u32x4 mk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+              const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
+                if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
+              }
+            }
+          }
+          if constexpr (EV == 3 || EV == 4) {
+            if (p.relu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+          }
+          unsigned q8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
+          *reinterpret_cast<u32x4*>(yp) = u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)};
+          if constexpr (EV == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[j] += f; s2[j] += f * f; }
+          }
+        }
+      }
+      lds_barrier();
+    }
+    if constexpr (EV == 1) {
+      // batch-norm statistics partials of this tile: per-thread sums over its rows -> over the row groups of a wave
+      // (lanes TPR apart share a channel group; fixed order) -> over the 8 waves through the window
+#pragma unroll
+      for (int off = TPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], off); s2[j] += __shfl_xor(s2[j], off); }
+      }
+      float* red = ep;                                              // [8 waves][BN][2] floats <= 16 rows of the window
+      if (lane < TPR) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red[(wave * BN + cg * 8 + j) * 2] = s1[j];
+          red[(wave * BN + cg * 8 + j) * 2 + 1] = s2[j];
+        }
+      }
+      lds_barrier();
+      if (tid < BN && n0 + tid < p.C_out) {
+        float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+        float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
+        o[0] = x1;
+        o[1] = x2;
+      }
+      lds_barrier();
+    }
+  }
+}
+
+
+template <int MY, int NW>
+int launch5(ConvK& k, hipStream_t s) {
+  using G = Ig5<MY, NW>;
+  k.tiles_m = (k.M + G::BM - 1) / G::BM;
+  k.tiles_n = (k.C_out + G::BN - 1) / G::BN;
+  const int ntiles = k.tiles_m * k.tiles_n;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  const int grid = ntiles < ncu ? ntiles : ncu;                     // one persistent block per CU
+  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+  static bool attr[5][2] = {};
+#define MBX5_LAUNCH(EV, MODE)                                                                                 \
+  do {                                                                                                        \
+    if (!attr[EV][MODE]) {                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm5_kernel<MY, NW, EV, MODE>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);                    \
+      attr[EV][MODE] = true;                                                                                  \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, MODE>), dim3(grid), dim3(1024), G::LDS_BYTES, s, k);   \
+  } while (0)
+#define MBX5_EV(EV) case EV: if (k.pw) MBX5_LAUNCH(EV, 1); else MBX5_LAUNCH(EV, 0); break;
+  switch (ev) { MBX5_EV(0) MBX5_EV(1) MBX5_EV(2) MBX5_EV(3) MBX5_EV(4) }
+#undef MBX5_EV
+#undef MBX5_LAUNCH
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+}  // namespace
+
+// tile shapes of the igemm5 launch: mbx_conv_desc.tile_config = 32 + index + 1
+extern const int mbx_i5_tiles[][2] = {{128, 64}, {128, 128}, {192, 128}, {256, 128}, {256, 64}};
+extern const int mbx_i5_num_tiles = 5;
+
+int mbx_launch_igemm5(void* convk, int index, hipStream_t s) {
+  ConvK& k = *reinterpret_cast<ConvK*>(convk);
+  if (k.shift || k.epi == MBX_EPI_STORE_F32) return MBX_ERR_UNSUPPORTED;   // stride-2 data gradient / float32 heads: igemm3
+  switch (index) {
+    case 0: return launch5<2, 1>(k, s);
+    case 1: return launch5<2, 2>(k, s);
+    case 2: return launch5<3, 2>(k, s);
+    case 3: return launch5<4, 2>(k, s);
+    case 4: return launch5<4, 1>(k, s);
+    default: return MBX_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,120 @@
+// Device helpers and the kernel parameter block shared by the convolution translation units (conv.hip: igemm3 +
+// weight gradients + host entry points; conv5.hip: the persistent igemm5 kernel).  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace {
+
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+struct ConvK {
+  const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
+  const unsigned short* w; int C_out, R, S, Ktot;
+  unsigned x_bytes, w_bytes;
+  int mul, shift, pad_t, pad_l, W_out, HW_out, M;
+  void* y; int y_img_stride, ldy;
+  int epi, relu, accumulate;
+  const float* scale; const float* shiftv;
+  const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
+  const unsigned short* acc_src; int acc_img_stride, ld_acc;      // accumulate: OLD value read from here (may alias y)
+  float* stats;
+  int tiles_m, tiles_n;
+  unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
+  int pw;                              // pointwise: R = S = 1, no padding, unit stride
+  // stride-2 data gradient (shift = 1): output pixels are walked PARITY-CLASS-major (class = (oh & 1) * 2 + (ow & 1)),
+  // so a pixel tile lies in one class and only the filter taps of that class are multiplied (a quarter of them)
+  int cls_m0[4], cls_hw[4], cls_w[4];  // first pixel index, pixels per image (Hc * Wc) and row length Wc per class
+  int skip_taps;                       // C_in % 64 == 0: K tiles never straddle taps, whole taps can be skipped
+  int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
+};
+
+constexpr int kThreads = 256;
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): four v_add_f32_dpp row_ror, every lane
+// ends up with the row sum -- no LDS traffic (ds_bpermute shuffles made the epilogue VALU/LDS-bound).
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+// exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
+__device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
+  return (unsigned)(((unsigned long long)m * magic) >> shift);
+}
+// pixel index m -> (image, output row, output column)
+__device__ __forceinline__ void decode_pixel(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {
+  img = (int)fast_div(m, p.mg_hw, p.sh_hw);
+  const int rem = (int)m - img * p.HW_out;
+  oh = (int)fast_div((unsigned)rem, p.mg_w, p.sh_w);
+  ow = rem - oh * p.W_out;
+}
+// ... in the parity-class-major order of the stride-2 data gradient
+__device__ __forceinline__ void decode_pixel_parity(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {
+  const int c = ((int)m >= p.cls_m0[1]) + ((int)m >= p.cls_m0[2]) + ((int)m >= p.cls_m0[3]);
+  const int m0 = c == 0 ? p.cls_m0[0] : c == 1 ? p.cls_m0[1] : c == 2 ? p.cls_m0[2] : p.cls_m0[3];
+  const int hw = c == 0 ? p.cls_hw[0] : c == 1 ? p.cls_hw[1] : c == 2 ? p.cls_hw[2] : p.cls_hw[3];
+  const int wc = c == 0 ? p.cls_w[0] : c == 1 ? p.cls_w[1] : c == 2 ? p.cls_w[2] : p.cls_w[3];
+  unsigned r = m - (unsigned)m0;
+  img = (int)(r / (unsigned)hw);
+  r -= (unsigned)img * (unsigned)hw;
+  const int a = (int)(r / (unsigned)wc), b = (int)r - a * wc;
+  oh = 2 * a + (c >> 1);
+  ow = 2 * b + (c & 1);
+}
+__device__ __forceinline__ int pixel_class(const ConvK& p, int m) {
+  return (m >= p.cls_m0[1]) + (m >= p.cls_m0[2]) + (m >= p.cls_m0[3]);
+}
+constexpr unsigned kOOB = 0x80000000u;      // byte offset beyond every tensor: buffer loads return 0 there
+
+// Buffer loads: 32-bit byte offsets off an SGPR descriptor; an out-of-range offset yields zeros,
+// so zero padding / tile edges need no branch and no exec masking.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
+
+// XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each
+// XCD a contiguous run of logical tiles so that tiles sharing a pixel panel share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// The GEMM loop: tiles staged by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip) into a
+// 3-deep ring of 64-deep K tiles: tile t+2 is in flight while tile t is multiplied, so two tiles of
+// global latency are covered per block.  The LDS image is the XOR-swizzled [row][8 chunks] layout;
+// because an LDS-DMA wave-instruction writes 64 consecutive 16-B slots (8 rows x 8 chunks), the
+// swizzle is applied to the SOURCE chunk each lane fetches (chunk = slot ^ (row & 7)).
+// Counted s_waitcnt vmcnt + raw s_barrier: nothing in the loop drains the DMA queue.
+// LDS-DMA: 16 B per lane from buffer offset `off` to lds_dst + lane (lds_dst wave-uniform); offsets
+// past the buffer write zeros.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, u32x4* lds_dst, int off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
+}
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's outstanding
+// vector-memory operations (fire-and-forget float atomics of the previous work item keep draining behind it)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+}  // namespace

@@ -139,6 +139,59 @@ def test_conv_epilogues(T):
     assert ok, "accumulate: " + msg
 
 
+@pytest.mark.parametrize("g", [("e1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("e7", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
+                               ("e3", 2, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1))], ids=["1x1", "1x7", "3x3"])
+def test_igemm5_epilogues_bit_identical(T, g):
+    """Every epilogue of the persistent igemm5 launch (statistics, frozen-BN affine, residual, accumulate + ReLU mask,
+    plain scaled store) against the igemm3 launch of the same descriptor: same arithmetic in the same order."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=21)
+    gen = torch.Generator().manual_seed(22)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    xb = ops.View.alloc(N, H, W, Ci + 8).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    sc, sh = (torch.rand(Co, generator=gen) + 0.5).cuda(), torch.randn(Co, generator=gen).cuda()
+    skip = ops.View.alloc(N, Ho, Wo, Co + 8).slice(8, Co)
+    skip.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+    old = ops.View.alloc(N, Ho, Wo, Co)
+    old.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def variants(y, stats):
+        return {
+            "stats": ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y, stats=stats),
+            "affine": ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y, epilogue=ops.EPI_AFFINE, relu=1, scale=sc, shift=sh),
+            "residual": ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17),
+            "acc_mask": ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y, accumulate=1, skip=skip, acc_src=old, rscale=0.2),
+            "scaled": ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y, rscale=0.3),
+        }
+    y0, y1 = ops.View.alloc(N, Ho, Wo, Co, zero=True), ops.View.alloc(N, Ho, Wo, Co, zero=True)
+    for cfg in ops.I5_TILE_CONFIGS:
+        for kind in ("stats", "affine", "residual", "acc_mask", "scaled"):
+            d0 = variants(y0, None)[kind]
+            rows0 = ops.conv_stats_rows(d0)
+            st0 = torch.zeros((rows0, Co, 2), device="cuda")
+            d0 = variants(y0, st0)[kind]
+            d1 = variants(y1, None)[kind]
+            d1.tile_config = cfg
+            rows1 = ops.conv_stats_rows(d1)
+            st1 = torch.zeros((rows1, Co, 2), device="cuda")
+            d1 = variants(y1, st1)[kind]
+            d1.tile_config = cfg
+            y0.tensor().zero_(); y1.tensor().zero_()
+            assert l.mbx_conv(C.byref(d0), stream) == 0 and l.mbx_conv(C.byref(d1), stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y0.tensor(), y1.tensor()), "%s %s cfg %d" % (name, kind, cfg)
+            if kind == "stats":      # partial rows differ with the tile height; their totals are sums of the same bf16 values
+                a, b = st0.double().sum(0), st1.double().sum(0)
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-3), "%s stats cfg %d" % (name, cfg)
+
+
 def test_conv_f32_head_output(T):
     """model.py:213-219: 1x1, no BN/bias/act, C_out = 5k = 25 (locations 4k + confidences k), fp32 out."""
     torch = T
@@ -214,6 +267,23 @@ def test_conv_dgrad_wgrad(T, g):
         dx.tensor().zero_()
         ops.conv(ddg)
         assert torch.equal(dx.tensor(), dx_ref), "dgrad tile_config %d" % cfg
+    # ... and the persistent igemm5 launches (tile_config 32 + t: 8 MFMA waves + 8 loader waves, tiles walked by one block
+    # per CU): same K order and MFMA order, so bit-identical too; the stride-2 data gradient stays on igemm3 (-2)
+    import ctypes as C
+    from multibox_amd import _lib
+    l = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    for cfg in ops.I5_TILE_CONFIGS:
+        dfw.tile_config = cfg
+        yv2.tensor().zero_()
+        assert l.mbx_conv(C.byref(dfw), stream) == 0
+        assert torch.equal(yv2.tensor(), yv.tensor()), "forward igemm5 tile_config %d" % cfg
+        ddg.tile_config = cfg
+        dx.tensor().zero_()
+        rc = l.mbx_conv(C.byref(ddg), stream)
+        assert rc == (0 if st == 1 else -2), (cfg, rc)
+        if rc == 0:
+            assert torch.equal(dx.tensor(), dx_ref), "dgrad igemm5 tile_config %d" % cfg
 
 
 def test_wgrad_odd_cout_padded_dy(T):

@@ -80,9 +80,14 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
         act = ops.View.alloc(B, H, W, Ci); act.buf.normal_()         # data gradient: accumulate + relu mask
         d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1, accumulate=1, skip=act)
     d_f.tile_config = kb_cfg; d_d.tile_config = kb_cfg
+    import ctypes as _C
+    from multibox_amd import _lib as _L
+    for d_ in (d_f, d_d):                              # a configuration that does not apply to this shape: library default
+        if _L.lib().mbx_conv(_C.byref(d_), torch.cuda.current_stream().cuda_stream) != 0:
+            d_.tile_config = 0
     tf = timeit(lambda: ops.conv(d_f))
     td = timeit(lambda: ops.conv(d_d))
-    tw = timeit(lambda: ops.conv_wgrad(d_w, dy, dw))
+    tw = timeit(lambda: ops.conv_wgrad(d_w, dy, dw)) if not os.environ.get("KB_NO_WGRAD") else 1.0
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
-    print("%-26s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f" % (name, tf, flops / tf / 1e6, td, flops / td / 1e6, tw, flops / tw / 1e6))
+    print("%-26s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f  cfg f%d d%d" % (name, tf, flops / tf / 1e6, td, flops / td / 1e6, tw, flops / tw / 1e6, d_f.tile_config, d_d.tile_config))
 print("weighted per-step totals (ms): fwd %.2f dgrad %.2f wgrad %.2f" % (tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3))

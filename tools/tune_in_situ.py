@@ -17,7 +17,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CONV_CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14)
+CONV_CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37)      # 33..37: the persistent igemm5 tiles
 WGRAD_CANDIDATES = (2, 3, 4, 7, 8, 9, 10)
 
 
@@ -87,6 +87,11 @@ def main():
             state["rows"] = ops.conv_stats_rows(d)            # the partial-row count follows the tile
         r = timed(lambda: orig_conv(desc_ref, stream), ent[0], d.tile_config)
         d.tile_config = tuned[C.addressof(d)]
+        if r != 0:                                             # the candidate does not apply to this launch: not a time
+            state["recs"].pop()
+            if d.stats_partial:
+                state["rows"] = ops.conv_stats_rows(d)
+            r = orig_conv(desc_ref, stream)
         return r
 
     def wgrad(desc_ref, *rest):
