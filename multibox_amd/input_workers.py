@@ -1,0 +1,227 @@
+"""Multi-process training input + asynchronous host-to-device hand-over.
+
+The reference feeds tf.train.shuffle_batch from NUM_INPUT_THREADS queue runners (inputs.py:353-371,
+config.yaml.example:94-100): decoding and augmenting a JPEG costs milliseconds of host time, the training step of this
+build takes ~17 ms for 64 images, so one host thread starves it by two orders of magnitude.  Here:
+
+  * ``ParallelTrainInput``: NUM_INPUT_THREADS worker PROCESSES (the pipeline is numpy / PIL code: threads would share
+    one GIL).  Worker k prepares the records i with i % n == k (multibox_amd.inputs.train_examples, its own RandomState
+    and its own share of the shuffle pool) and writes each finished example into a slot of a ring in shared memory (a
+    memory-mapped file under TMPDIR: no /dev/shm size limit, no pickling of the 1 MB images); slot numbers travel
+    through two small queues.  The parent assembles batches in arrival order, which interleaves the workers.
+    Workers are started with the ``forkserver`` method and never touch the GPU (they do not import torch).
+  * ``DevicePrefetcher``: a background thread copies each batch into pinned host buffers and issues the H2D copies
+    on a side stream, ``depth`` batches ahead; ``next()`` hands back device tensors whose copies the current stream
+    has been made to wait for, so ``Trainer.set_batch`` is a device-to-device copy.
+
+No TensorFlow, no torch DataLoader.  Random draws come from numpy (see inputs.py: "parity unpinned" for sampled values);
+with one worker, shuffle off and the same seed the example stream equals train_batches() exactly (tests/test_inputs_cpu.py).
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import queue
+import tempfile
+import threading
+
+import numpy as np
+
+
+def _worker_main(k, n, tfrecords, cfg_dict, max_num_bboxes, num_epochs, seed, shuffle, capacity, min_after_dequeue,
+                 ring_path, slots, S, free_q, ready_q):
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # one core per worker: no BLAS thread pools
+        os.environ.setdefault(v, "1")
+    from .config import Cfg
+    from .inputs import train_examples
+    ring = np.memmap(ring_path, dtype=np.float32, mode="r+", shape=(slots, S, S, 3))
+    try:
+        stream = train_examples(tfrecords, Cfg(cfg_dict), max_num_bboxes, num_epochs, seed + k, shuffle,
+                                max(capacity // n, 1), min_after_dequeue // n, shard=(k, n))
+        for img, bb, nb, image_id in stream:
+            slot = free_q.get()
+            if slot is None:                                   # the parent is shutting down
+                return
+            ring[slot] = img
+            ready_q.put((slot, bb, nb, image_id))
+        ready_q.put(("done", k))
+    except BaseException as e:                                 # surface the failure in the parent instead of hanging it
+        ready_q.put(("error", "%s: %r" % (type(e).__name__, e)))
+        raise
+
+
+def _plain(d):
+    if isinstance(d, dict):
+        return {k: _plain(v) for k, v in d.items()}
+    if isinstance(d, (list, tuple)):
+        return [_plain(v) for v in d]
+    return d
+
+
+class ParallelTrainInput:
+    """Iterator of (images [B,S,S,3] float32, bboxes [B,G,4], num_bboxes [B] int32, image_ids) built by worker processes."""
+
+    def __init__(self, tfrecords, cfg, batch_size, max_num_bboxes, num_workers=None, num_epochs=None, seed=0,
+                 shuffle=True, capacity=1000, min_after_dequeue=96, ring_batches=4, tmpdir=None):
+        self.B, self.G, self.S = int(batch_size), int(max_num_bboxes), int(cfg.INPUT_SIZE)
+        self.n = max(1, int(num_workers if num_workers is not None else cfg.get("NUM_INPUT_THREADS", 4)))
+        self.slots = max(int(ring_batches), 2) * self.B
+        fd, self.ring_path = tempfile.mkstemp(prefix="mbx_input_ring_", suffix=".f32", dir=tmpdir or os.environ.get("TMPDIR"))
+        os.ftruncate(fd, self.slots * self.S * self.S * 3 * 4)
+        os.close(fd)
+        self.ring = np.memmap(self.ring_path, dtype=np.float32, mode="r+", shape=(self.slots, self.S, self.S, 3))
+        ctx = mp.get_context("forkserver")
+        self.free_q, self.ready_q = ctx.Queue(), ctx.Queue()
+        for s in range(self.slots):
+            self.free_q.put(s)
+        self.procs = [ctx.Process(target=_worker_main, daemon=True,
+                                  args=(k, self.n, list(tfrecords), _plain(cfg), self.G, num_epochs, int(seed), bool(shuffle),
+                                        int(capacity), int(min_after_dequeue), self.ring_path, self.slots, self.S,
+                                        self.free_q, self.ready_q)) for k in range(self.n)]
+        for p in self.procs:
+            p.start()
+        self.alive = self.n
+        self.closed = False
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        imgs = np.empty((self.B, self.S, self.S, 3), np.float32)
+        self.next_into(imgs)
+        return imgs, self._bb, self._n, self._ids
+
+    def next_into(self, images_out):
+        """Assemble the next batch with the images written straight into `images_out` (e.g. a pinned buffer); returns
+        (bboxes, num_bboxes, image_ids).  Raises StopIteration when every worker has finished its epochs."""
+        bb = np.zeros((self.B, self.G, 4), np.float32)
+        nn = np.zeros((self.B,), np.int32)
+        ids = []
+        i = 0
+        while i < self.B:
+            if self.alive == 0 and self.ready_q.empty():
+                raise StopIteration                              # (the incomplete last batch is dropped, like tf.train.batch)
+            try:
+                item = self.ready_q.get(timeout=1.0)
+            except queue.Empty:
+                if not any(p.is_alive() for p in self.procs) and self.ready_q.empty():
+                    if self.alive:
+                        raise RuntimeError("input workers died without reporting")
+                    raise StopIteration
+                continue
+            if item[0] == "done":
+                self.alive -= 1
+                continue
+            if item[0] == "error":
+                self.close()
+                raise RuntimeError("input worker failed: " + item[1])
+            slot, b, n, image_id = item
+            images_out[i] = self.ring[slot]
+            self.free_q.put(slot)
+            bb[i], nn[i] = b, n
+            ids.append(image_id)
+            i += 1
+        self._bb, self._n, self._ids = bb, nn, ids
+        return bb, nn, ids
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        for _ in self.procs:
+            try:
+                self.free_q.put(None)
+            except Exception:
+                pass
+        for p in self.procs:
+            p.join(timeout=2.0)
+            if p.is_alive():
+                p.terminate()                                   # exactly the processes this object started
+        try:
+            del self.ring
+            os.unlink(self.ring_path)
+        except OSError:
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevicePrefetcher:
+    """Pinned double buffers + H2D copies on a side stream, `depth` batches ahead of the training step."""
+
+    def __init__(self, source, batch_size, input_size, max_num_bboxes, device="cuda", depth=2):
+        import torch
+        self.torch, self.src = torch, source
+        self.dev = torch.device(device)
+        self.depth = max(int(depth), 1)
+        B, S, G = batch_size, input_size, max_num_bboxes
+        pin = self.dev.type == "cuda"
+        self.host = [(torch.empty((B, S, S, 3), dtype=torch.float32, pin_memory=pin),
+                      torch.empty((B, G, 4), dtype=torch.float32, pin_memory=pin),
+                      torch.empty((B,), dtype=torch.int32, pin_memory=pin)) for _ in range(self.depth + 1)]
+        self.devb = [tuple(torch.empty_like(t, device=self.dev) for t in h) for h in self.host]
+        self.stream = torch.cuda.Stream(device=self.dev) if pin else None
+        self.q = queue.Queue(maxsize=self.depth)
+        self.free = queue.Queue()
+        for i in range(self.depth + 1):
+            self.free.put(i)
+        self.err = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch = self.torch
+        try:
+            while True:
+                i = self.free.get()
+                if i is None:
+                    return
+                himg, hbb, hn = self.host[i]
+                if hasattr(self.src, "next_into"):
+                    bb, nn, ids = self.src.next_into(himg.numpy())
+                else:
+                    images, bb, nn, ids = next(self.src)
+                    himg.numpy()[...] = images
+                hbb.numpy()[...] = bb
+                hn.numpy()[...] = nn
+                ev = None
+                if self.stream is not None:
+                    with torch.cuda.stream(self.stream):
+                        for h, d in zip(self.host[i], self.devb[i]):
+                            d.copy_(h, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                else:
+                    for h, d in zip(self.host[i], self.devb[i]):
+                        d.copy_(h)
+                self.q.put((i, ev, ids))
+        except StopIteration:
+            self.q.put(None)
+        except BaseException as e:
+            self.err = e
+            self.q.put(None)
+
+    def next(self):
+        """(images, bboxes, num_bboxes, image_ids) on the device; the CURRENT stream waits for their copies.  The buffers
+        are reused `depth` batches later: consume them (Trainer.set_batch copies) before calling next() that often."""
+        item = self.q.get()
+        if item is None:
+            if self.err is not None:
+                raise self.err
+            raise StopIteration
+        i, ev, ids = item
+        if ev is not None:
+            self.torch.cuda.current_stream().wait_event(ev)
+        if getattr(self, "_last", None) is not None:
+            self.free.put(self._last)                           # the batch handed out before this one has been consumed
+        self._last = i
+        return self.devb[i] + (ids,)
+
+    def close(self):
+        self.free.put(None)
+        if hasattr(self.src, "close"):
+            self.src.close()

@@ -25,7 +25,13 @@ import io
 import numpy as np
 
 from . import tfrecord
-from .detect import extract_patches
+
+
+def extract_patches(*args, **kwargs):
+    """multibox_amd.detect.extract_patches (detect.py:20-72), imported on first use: that module imports torch, which the
+    training input worker processes (input_workers.py) neither need nor should load."""
+    from .detect import extract_patches as f
+    return f(*args, **kwargs)
 
 
 def decode_image(jpeg_bytes):
@@ -157,22 +163,29 @@ def resize_bicubic_tf(img, out_h, out_w):
 
 def resize_area_tf(img, out_h, out_w):
     """tf.image.resize_area: every output pixel is the area-weighted mean of the source rectangle
-    [dst*scale, (dst+1)*scale) (fractional coverage of the border pixels)."""
-    img = np.asarray(img, np.float64)
+    [dst*scale, (dst+1)*scale) (fractional coverage of the border pixels).  Separable; an output pixel covers at most
+    ceil(scale) + 1 source pixels, so each axis is that many weighted gathers (a dense [out, in] weight matrix product
+    cost 0.2 s per image and starved the input workers)."""
+    img = np.asarray(img, np.float32)
 
-    def weights(n_in, n_out):
+    def axis(x, n_in, n_out, ax):
         scale = n_in / float(n_out)
-        Wm = np.zeros((n_out, n_in), np.float64)
-        for o in range(n_out):
-            lo, hi = o * scale, (o + 1) * scale
-            i = int(np.floor(lo))
-            while i < hi and i < n_in:
-                Wm[o, i] = min(hi, i + 1) - max(lo, i)
-                i += 1
-            Wm[o] /= max(Wm[o].sum(), 1e-12)
-        return Wm
-    Wy, Wx = weights(img.shape[0], out_h), weights(img.shape[1], out_w)
-    return np.einsum("oh,hwc->owc", Wy, np.einsum("pw,hwc->hpc", Wx, img)).astype(np.float32)
+        o = np.arange(n_out, dtype=np.float64)
+        lo, hi = o * scale, (o + 1) * scale
+        i0 = np.floor(lo).astype(np.int64)
+        taps = int(np.ceil(scale)) + 1
+        idx = i0[None, :] + np.arange(taps)[:, None]                                   # [taps, n_out]
+        w = np.minimum(hi[None, :], idx + 1.0) - np.maximum(lo[None, :], idx.astype(np.float64))
+        w = np.where((idx < n_in) & (w > 0), w, 0.0)
+        w = (w / np.maximum(w.sum(0, keepdims=True), 1e-12)).astype(np.float32)
+        idx = np.minimum(idx, n_in - 1)
+        shape = [1] * x.ndim
+        shape[ax] = n_out
+        out = np.take(x, idx[0], axis=ax) * w[0].reshape(shape)
+        for k in range(1, taps):
+            out += np.take(x, idx[k], axis=ax) * w[k].reshape(shape)
+        return out
+    return axis(axis(img, img.shape[0], out_h, 0), img.shape[1], out_w, 1).astype(np.float32)
 
 
 RESIZE_METHODS = (resize_bilinear_tf, resize_nearest_tf, resize_bicubic_tf, resize_area_tf)   # tf.image.ResizeMethod 0..3
@@ -332,19 +345,31 @@ def augment_example(image01, image_height, image_width, xmin, ymin, xmax, ymax, 
     return np.ascontiguousarray(img, np.float32), xmin, ymin, xmax, ymax
 
 
-def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, seed=0, shuffle=False, capacity=1000,
-                  min_after_dequeue=96):
-    """Yield (images [B,S,S,3] in [-1,1], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B] int32, image_ids).
-    shuffle: a tf.train.shuffle_batch-like buffer (random pick once more than min_after_dequeue examples wait)."""
+def _records_sharded(tfrecords, shard):
+    """Records number i (counted over all files, every epoch alike) with i % n == k for shard = (k, n); the others are
+    skipped unparsed (the TFRecord framing gives their length)."""
+    k, n = shard
+    i = 0
+    for path in tfrecords:
+        for payload in tfrecord.read_records(path):
+            if i % n == k:
+                yield tfrecord.parse_example(payload)
+            i += 1
+
+
+def train_examples(tfrecords, cfg, max_num_bboxes, num_epochs=None, seed=0, shuffle=False, capacity=1000,
+                   min_after_dequeue=96, shard=(0, 1)):
+    """Yield prepared training examples (image [S,S,3] float32 in [-1,1], bboxes [G,4] x1,y1,x2,y2, num_bboxes, image_id)
+    of this shard of the records: decode + augmentation (inputs.py:200-351), then an optional shuffle pool
+    (tf.train.shuffle_batch-like: a random pick once more than min_after_dequeue examples wait)."""
     rng = np.random.RandomState(seed)
-    pool, out = [], []
-    imgs, boxes, nums, ids = [], [], [], []
+    pool = []
 
     def examples():
         epoch = 0
         while num_epochs is None or epoch < num_epochs:
             got = False
-            for ex in _records(tfrecords):
+            for ex in _records_sharded(tfrecords, shard):
                 got = True
                 yield ex
             if not got:
@@ -372,7 +397,16 @@ def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, s
                 yield pool.pop(int(rng.randint(0, len(pool))))
         while pool:
             yield pool.pop(int(rng.randint(0, len(pool))))
-    for img, bb, n, image_id in (shuffled() if shuffle else prepared()):
+    return shuffled() if shuffle else prepared()
+
+
+def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, seed=0, shuffle=False, capacity=1000,
+                  min_after_dequeue=96):
+    """Yield (images [B,S,S,3] in [-1,1], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B] int32, image_ids): the
+    single-process form; multibox_amd/input_workers.py runs the same example stream in NUM_INPUT_THREADS processes."""
+    imgs, boxes, nums, ids = [], [], [], []
+    for img, bb, n, image_id in train_examples(tfrecords, cfg, max_num_bboxes, num_epochs, seed, shuffle, capacity,
+                                               min_after_dequeue):
         imgs.append(img); boxes.append(bb); nums.append(n); ids.append(image_id)
         if len(imgs) == batch_size:
             yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), ids

@@ -198,3 +198,41 @@ def test_eval_batches(tmp_path):
     assert images.shape == (2, 299, 299, 3) and boxes.shape == (2, 4, 4) and areas.shape == (2, 4) and nums.tolist() == [1, 0]
     assert np.isclose(areas[0, 0], .4 * 400 * .4 * 320) and not areas[0, 1:].any() and not areas[1].any() and ids == ["1000", "1001"]
     assert np.allclose(images[0], (I.resize_bilinear_tf(I.decode_image(_jpeg(320, 400, 0)), 299, 299) - 0.5) * 2.0)
+
+
+def test_parallel_train_input_workers(tmp_path):
+    """multibox_amd/input_workers.py (the NUM_INPUT_THREADS queue runners of inputs.py:353-371 as worker PROCESSES over
+    a shared-memory ring): one worker, shuffle off = the single-process stream bit for bit; three workers cover every
+    record exactly once per epoch, in batches, and stop at the end of the epoch; the prefetcher hands the same batches on."""
+    from multibox_amd.input_workers import ParallelTrainInput, DevicePrefetcher
+    path = str(tmp_path / "t.tfrecords")
+    specs = [(300 + 7 * i, 310 + 5 * i, [[.1, .2, .5, .6]] if i % 3 else []) for i in range(10)]
+    _make_records(path, specs)
+    cfg = Cfg(dict(INPUT_SIZE=299, DO_RANDOM_FLIP_LEFT_RIGHT=True, DO_COLOR_DISTORTION=1.0, COLOR_DISTORT_FAST=True,
+                   NUM_INPUT_THREADS=3))
+    ref = list(I.train_batches([path], cfg, 2, 5, num_epochs=1, seed=5))
+    src = ParallelTrainInput([path], cfg, 2, 5, num_workers=1, num_epochs=1, seed=5, shuffle=False, tmpdir=str(tmp_path))
+    got = list(src)
+    src.close()
+    assert len(got) == len(ref) == 5
+    for (a, b, n, ids), (ra, rb, rn, rids) in zip(got, ref):
+        assert np.array_equal(a, ra) and np.array_equal(b, rb) and np.array_equal(n, rn) and ids == rids
+    # three workers (cfg.NUM_INPUT_THREADS), two epochs, shuffled: every record twice, whole batches only
+    src = ParallelTrainInput([path], cfg, 4, 5, num_epochs=2, seed=9, shuffle=True, capacity=6, min_after_dequeue=3,
+                             tmpdir=str(tmp_path))
+    assert src.n == 3
+    pre = DevicePrefetcher(src, 4, 299, 5, device="cpu", depth=2)
+    seen = []
+    while True:
+        try:
+            images, bb, n, ids = pre.next()
+        except StopIteration:
+            break
+        assert tuple(images.shape) == (4, 299, 299, 3) and float(images.min()) >= -1 and float(images.max()) <= 1
+        assert tuple(bb.shape) == (4, 5, 4) and n.dtype.is_floating_point is False
+        for i, image_id in enumerate(ids):
+            want = 1 if (int(image_id) - 1000) % 3 else 0
+            assert int(n[i]) == want
+        seen += ids
+    pre.close()
+    assert len(seen) == 20 and sorted(seen) == sorted([str(1000 + i) for i in range(10)] * 2)

@@ -102,15 +102,18 @@ def main():
     step0 = tr.global_step
     real = None
     if args.tfrecords and not args.synthetic:
-        from multibox_amd.inputs import train_batches
+        from multibox_amd.input_workers import ParallelTrainInput, DevicePrefetcher
         files = args.tfrecords[rank::world] if len(args.tfrecords) >= world else args.tfrecords     # shard files over ranks
-        real = train_batches(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_epochs=None,
-                             seed=int(cfg.get("RANDOM_SEED", 1)) + rank, shuffle=True,                   # train.py:214-225
-                             capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)))
+        # NUM_INPUT_THREADS worker processes (inputs.py:353-371) -> shared-memory ring -> pinned buffers -> async H2D
+        src = ParallelTrainInput(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_workers=int(cfg.get("NUM_INPUT_THREADS", 4)),
+                                 num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + 1000 * rank, shuffle=True,   # train.py:214-225
+                                 capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)))
+        real = DevicePrefetcher(src, cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, device="cuda", depth=2)
+
     def next_real():
         # an exhausted / empty file shard on ONE rank must stop every rank, not leave the others in all_reduce
         try:
-            b = next(real)
+            b = real.next()
         except StopIteration:
             b = None
         if world > 1:
@@ -119,15 +122,17 @@ def main():
             if int(ok) == 0:
                 b = None
         if b is None:
+            real.close()
             raise SystemExit("input exhausted on at least one rank at step %d" % tr.global_step)
         return b
 
     while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
         if real is not None:
-            images, gt, n, _ = next_real()
+            images, gt, n, _ = next_real()                      # already on the device (prefetched two batches ahead)
+            tr.set_batch(images, gt, n)
         else:
             images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
-        tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+            tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
         tr.step()
         if tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
             tr.check_health()        # every rank: matching status (py_func error -> abort, loss.py:82) + barrier timeouts
@@ -144,6 +149,8 @@ def main():
         if rank == 0 and time.time() - t_save > cfg.SAVE_INTERVAL_SECS:
             CK.save(args.logdir, tr, cfg.MAX_TO_KEEP)
             t_save = time.time()
+    if real is not None:
+        real.close()                                              # stop the input worker processes
     if rank == 0:
         print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP))
     if world > 1:
