@@ -87,6 +87,45 @@ def test_train_then_detect(tmp_path):
     assert os.path.exists(log2 / "model.ckpt-1.pt")
 
 
+def test_train_from_tfrecords_with_input_workers(tmp_path):
+    """train.py --tfrecords: JPEG records -> NUM_INPUT_THREADS worker processes (multibox_amd/input_workers.py) ->
+    pinned buffers -> asynchronous H2D -> Trainer, six steps with every augmentation switched on."""
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import priors as PR
+    from tests.test_inputs_cpu import _make_records
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CFG.replace("DETECTION :", """NUM_INPUT_THREADS : 3
+QUEUE_CAPACITY : 24
+QUEUE_MIN : 8
+DO_RANDOM_FLIP_LEFT_RIGHT : true
+DO_RANDOM_BBOX_SHIFT : 0.5
+RANDOM_BBOX_SHIFT_EXTENT : 4
+DO_RANDOM_CROP : 0.5
+RANDOM_CROP_MIN_OBJECT_COVERED : 0.7
+RANDOM_CROP_ASPECT_RATIO_RANGE : [0.7, 1.4]
+RANDOM_CROP_AREA_RANGE : [0.5, 1.0]
+RANDOM_CROP_MAX_ATTEMPTS : 100
+RANDOM_CROP_MINIMUM_AREA : 50
+DO_COLOR_DISTORTION : 0.5
+COLOR_DISTORT_FAST : false
+DETECTION :"""))
+    pri = tmp_path / "priors.pkl"
+    PR.save_priors(str(pri), PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]))
+    rec = str(tmp_path / "train.tfrecords")
+    _make_records(rec, [(300 + 11 * i, 330 + 7 * i, [[.1, .2, .5, .6], [.3, .3, .9, .8]][: i % 3]) for i in range(12)])
+    logdir = tmp_path / "log"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(logdir),
+                        "--config", str(cfg), "--tfrecords", rec, "--max_number_of_steps", "6"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    recs = [json.loads(l) for l in open(logdir / "train_log.jsonl")]
+    assert [x["global_step"] for x in recs] == [1, 2, 3, 4, 5, 6]
+    assert all(np.isfinite(x["total_loss"]) and x["location_loss"] >= 0 and x["confidence_loss"] > 0 for x in recs)
+    assert any(x["location_loss"] > 0 for x in recs)             # the boxes arrived (two of three images have some)
+    assert "saved" in r.stdout
+
+
 def test_detect_from_tfrecords(tmp_path):
     """detect.py --tfrecords: the reference's multi-crop input (detect.py:134-292) end to end on three JPEG images."""
     import __graft_entry__ as g
