@@ -69,7 +69,10 @@ def main():
     keeps = [int(det.get("ORIGINAL_IMAGE_MAX_TO_KEEP", 200)), int(det.get("FLIPPED_IMAGE_MAX_TO_KEEP", 0))]
     keeps += [int(c.MAX_TO_KEEP) for c in (det.get("CROPS", None) or [])]
     max_keep = max(keeps + [1])
-    pp = D.DetectPostprocess(bbox_priors, B, k_max=max_keep)
+    # DETECTION.NMS_IOU_THRESHOLD (not a key of the reference, which has no NMS -- detect.py:408-443): optional greedy
+    # per-patch non-maximum suppression after the top-K stage; absent = the reference's behaviour
+    nms_iou = det.get("NMS_IOU_THRESHOLD", None)
+    pp = D.DetectPostprocess(bbox_priors, B, k_max=max_keep, nms_iou=nms_iou)
     conf = torch.empty((B, net.P), dtype=torch.float32, device="cuda")
     results, step = [], 0
     S = cfg.INPUT_SIZE

@@ -113,6 +113,14 @@ int mbx_decode_filter_topk(const float* raw_locs /*[B,P,4]*/, const float* conf 
                            float* out_scores /*[B,k_max]*/, int32_t* out_index /*[B,k_max]*/,
                            int32_t* out_count /*[B]*/, mbx_stream_t stream);
 
+/* OPTIONAL greedy non-maximum suppression per patch on the output of mbx_decode_filter_topk, in place (row N1: BASELINE's
+ * north_star names an NMS stage; the reference has none -- detect.py:408-443 keeps the top max_to_keep boxes -- so it is
+ * off by default and outside the parity path).  Boxes are taken in their stored (score-descending) order; box i is
+ * dropped iff IoU(i, j) > iou_threshold for an earlier KEPT box j; survivors are compacted to the front of each row of
+ * out_boxes / out_scores / out_index and out_count[b] becomes their number.  IoU in float64, k_max <= 1024.      */
+int mbx_nms(double* boxes /*[B,k_max,4] x1,y1,x2,y2*/, float* scores /*[B,k_max]*/, int32_t* index /*[B,k_max]*/,
+            int32_t* count /*[B], in/out*/, int B, int k_max, double iou_threshold, mbx_stream_t stream);
+
 /* ------------------------------------------------------------ convolution stack (A2-A4)
  * Replaces slim.conv2d (+ batch_norm + relu) of model.py:6-324 and its TF gradients
  * (train.py:263).  Activations are NHWC bf16 *views*: element (n,h,w,c) of a tensor lives at

@@ -396,6 +396,108 @@ extern "C" int mbx_loss_fwd_bwd(const float* decoded, const float* logits, int c
   return MBX_OK;
 }
 
+// ------------------------------------------------------------------------------------------ optional NMS (N1)
+// The reference has NO non-maximum suppression (detect.py keeps the top max_to_keep boxes of every patch);
+// BASELINE's north_star names one, so it exists as an OPTIONAL stage after mbx_decode_filter_topk, off by default.
+// Greedy NMS per patch over the score-sorted list: box i is kept iff its IoU with every earlier KEPT box is <= thr.
+// One workgroup per patch: the K x K "suppresses" relation as bit rows in LDS (pair (i, j), j > i, computed in
+// float64 in the operation order of the numpy restatement: bit-exact decisions), then one wave walks the rows in
+// order OR-ing the rows of kept boxes into the removed set (wavefront ballot-free: 64-bit words per lane), then the
+// survivors are compacted in place.  K <= 1024.
+constexpr int kNmsMaxK = 1024;
+
+__global__ void __launch_bounds__(kThreads)
+nms_kernel(double* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ index,
+           int32_t* __restrict__ count, int k_max, double thr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long nms_lds[];
+  const int b = blockIdx.x;
+  const int K = min(count[b], k_max);
+  const int W = (K + 63) >> 6;                               // 64-bit words per row
+  unsigned long long* rows = nms_lds;                        // [K][W]
+  unsigned long long* removed = nms_lds + (size_t)K * W;     // [W]
+  double* bx = boxes + (size_t)b * k_max * 4;
+  for (int i = threadIdx.x; i < K * W; i += kThreads) rows[i] = 0ull;
+  if (threadIdx.x < W) removed[threadIdx.x] = 0ull;
+  __syncthreads();
+  // pair (i, j), j > i: thread t takes row i = t / W', word w: 64 columns at a time
+  for (int t = threadIdx.x; t < K * W; t += kThreads) {
+    const int i = t / W, w = t - i * W;
+    const double x1 = bx[i * 4], y1 = bx[i * 4 + 1], x2 = bx[i * 4 + 2], y2 = bx[i * 4 + 3];
+    const double ai = (x2 - x1) * (y2 - y1);
+    unsigned long long bits = 0ull;
+    const int j0 = max(w * 64, i + 1), j1 = min(w * 64 + 64, K);
+    for (int j = j0; j < j1; ++j) {
+      const double u1 = bx[j * 4], v1 = bx[j * 4 + 1], u2 = bx[j * 4 + 2], v2 = bx[j * 4 + 3];
+      const double iw = fmin(x2, u2) - fmax(x1, u1), ih = fmin(y2, v2) - fmax(y1, v1);
+      const double inter = (iw > 0.0 && ih > 0.0) ? iw * ih : 0.0;
+      const double uni = ai + (u2 - u1) * (v2 - v1) - inter;
+      const double iou = uni > 0.0 ? inter / uni : 0.0;
+      if (iou > thr) bits |= 1ull << (j & 63);
+    }
+    rows[t] = bits;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                    // one wave: lane w owns word w of the removed set (W <= 16)
+    const int lane = threadIdx.x;
+    unsigned long long rem = 0ull;
+    for (int i = 0; i < K; ++i) {
+      const unsigned long long word = __shfl(rem, i >> 6, 64);          // is box i still alive?
+      if (!((word >> (i & 63)) & 1ull) && lane < W) rem |= rows[i * W + lane];
+    }
+    if (lane < W) removed[lane] = rem;
+  }
+  __syncthreads();
+  // compaction: survivor i moves to position (number of survivors before i); one thread per box, prefix by popcount
+  int dst = -1;
+  double kb[4] = {0, 0, 0, 0};
+  float ks = 0.f;
+  int ki = 0;
+  const int i = threadIdx.x;
+  for (int base = 0; base < K; base += kThreads) {           // K <= 1024: at most four sweeps, each box read before any write
+    const int ii = base + i;
+    dst = -1;
+    if (ii < K && !((removed[ii >> 6] >> (ii & 63)) & 1ull)) {
+      int before = 0;
+      for (int w = 0; w < (ii >> 6); ++w) before += __popcll(~removed[w]);
+      before += __popcll(~removed[ii >> 6] & ((1ull << (ii & 63)) - 1ull));
+      dst = before;
+      kb[0] = bx[ii * 4]; kb[1] = bx[ii * 4 + 1]; kb[2] = bx[ii * 4 + 2]; kb[3] = bx[ii * 4 + 3];
+      ks = scores[(size_t)b * k_max + ii];
+      ki = index[(size_t)b * k_max + ii];
+    }
+    __syncthreads();                                          // dst <= ii and all sources of this sweep are in registers
+    if (dst >= 0) {
+      bx[dst * 4] = kb[0]; bx[dst * 4 + 1] = kb[1]; bx[dst * 4 + 2] = kb[2]; bx[dst * 4 + 3] = kb[3];
+      scores[(size_t)b * k_max + dst] = ks;
+      index[(size_t)b * k_max + dst] = ki;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int kept = 0;
+    for (int w = 0; w < W; ++w) kept += __popcll(~removed[w] & (w == W - 1 && (K & 63) ? ((1ull << (K & 63)) - 1ull) : ~0ull));
+    count[b] = K == 0 ? 0 : kept;
+  }
+}
+
+extern "C" int mbx_nms(double* boxes, float* scores, int32_t* index, int32_t* count, int B, int k_max,
+                       double iou_threshold, mbx_stream_t stream) {
+  if (!boxes || !scores || !index || !count || B < 0 || k_max <= 0) return MBX_ERR_INVALID_ARG;
+  if (k_max > kNmsMaxK) return MBX_ERR_UNSUPPORTED;
+  if (B == 0) return MBX_OK;
+  const int W = (k_max + 63) / 64;
+  const size_t lds = ((size_t)k_max * W + W) * sizeof(unsigned long long);
+  MBX_ENTER();
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return MBX_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(kThreads), lds, mbx_s(stream), boxes, scores, index, count, k_max,
+                     iou_threshold);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 extern "C" int mbx_decode_filter_topk(const float* raw_locs, const float* conf, const float* priors,
                                       const mbx_patch_meta* meta, int B, int P, int k_max, double* out_boxes,
                                       float* out_scores, int32_t* out_index, int32_t* out_count,

@@ -57,7 +57,10 @@ def make_patch_meta(offsets, dims, is_flipped, restrictions, max_to_keep, image_
 class DetectPostprocess:
     """Preallocated outputs for B patches x k_max detections (k_max >= every max_to_keep)."""
 
-    def __init__(self, bbox_priors, batch_size, k_max=200, device="cuda"):
+    def __init__(self, bbox_priors, batch_size, k_max=200, device="cuda", nms_iou=None):
+        """nms_iou: None (the reference: no NMS, detect.py:408-443) or an IoU threshold for the optional greedy
+        per-patch NMS stage (mbx_nms, row N1)."""
+        self.nms_iou = None if nms_iou is None else float(nms_iou)
         self.priors = torch.as_tensor(bbox_priors, dtype=torch.float32).to(device).contiguous()
         self.P, self.B, self.K = self.priors.shape[0], int(batch_size), int(k_max)
         self.boxes = torch.empty((self.B, self.K, 4), dtype=torch.float64, device=device)
@@ -75,6 +78,10 @@ class DetectPostprocess:
                                                      self.scores.data_ptr(), self.index.data_ptr(),
                                                      self.count.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    "mbx_decode_filter_topk")
+        if self.nms_iou is not None:
+            _lib.check(_lib.lib().mbx_nms(self.boxes.data_ptr(), self.scores.data_ptr(), self.index.data_ptr(),
+                                          self.count.data_ptr(), B, self.K, self.nms_iou,
+                                          torch.cuda.current_stream().cuda_stream), "mbx_nms")
         return self.boxes, self.scores, self.index, self.count
 
 

@@ -290,3 +290,26 @@ def rmsprop_step(w, g, ms, mom, lr, decay=0.9, momentum=0.0, eps=1.0):
 def ema_decay(decay, num_updates):
     """tf.train.ExponentialMovingAverage(decay, num_updates) (train.py:253-256)."""
     return min(decay, (1.0 + num_updates) / (10.0 + num_updates))
+
+
+def nms_greedy(boxes, iou_threshold):
+    """Greedy non-maximum suppression over boxes already sorted by descending score (row N1: NOT part of the reference,
+    which has no NMS -- detect.py:408-443; the standard algorithm, restated in the operation order of the HIP kernel so
+    that the keep decisions can be compared exactly).  boxes [K,4] float64 x1,y1,x2,y2.  Returns the kept indices."""
+    b = np.asarray(boxes, np.float64).reshape(-1, 4)
+    keep = []
+    for i in range(len(b)):
+        ok = True
+        ai = (b[i, 2] - b[i, 0]) * (b[i, 3] - b[i, 1])
+        for j in keep:
+            iw = min(b[j, 2], b[i, 2]) - max(b[j, 0], b[i, 0])
+            ih = min(b[j, 3], b[i, 3]) - max(b[j, 1], b[i, 1])
+            inter = iw * ih if (iw > 0.0 and ih > 0.0) else 0.0
+            union = (b[j, 2] - b[j, 0]) * (b[j, 3] - b[j, 1]) + ai - inter
+            iou = inter / union if union > 0.0 else 0.0
+            if iou > iou_threshold:
+                ok = False
+                break
+        if ok:
+            keep.append(i)
+    return np.array(keep, np.int64)

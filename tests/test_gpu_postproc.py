@@ -229,3 +229,65 @@ def test_decode_filter_topk_full_size_properties(torch_cuda, golden):
         assert scores[b, :count[b]].tobytes() == rs.tobytes()
         assert boxes[b, :count[b]].tobytes() == rb.tobytes()
         assert (np.diff(scores[b, :count[b]]) <= 0).all()     # sortedness
+
+
+def test_optional_nms_matches_oracle_and_properties():
+    """mbx_nms (row N1, optional, off by default: the reference has no NMS): keep decisions equal the numpy restatement
+    exactly (float64 IoU, same operation order), survivors keep their order, no two survivors overlap above the
+    threshold, threshold 1.0 keeps everything, ragged counts and empty patches are honoured."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import _lib
+    from oracle import ref_numpy as R
+    l = _lib.lib()
+    rng = np.random.RandomState(5)
+    B, K = 9, 200
+    xy = rng.uniform(0, .8, (B, K, 2)); wh = rng.uniform(.02, .3, (B, K, 2))
+    boxes = np.concatenate([xy, xy + wh], -1)
+    boxes[1, 50:60] = boxes[1, 40:50]                                    # exact duplicates
+    boxes[2, :, :] = boxes[2, :1, :]                                     # one box 200 times
+    boxes[3, :, 2:] = boxes[3, :, :2]                                    # zero-area boxes: IoU 0 by definition
+    scores = np.sort(rng.uniform(0, 1, (B, K)).astype(np.float32), axis=1)[:, ::-1].copy()
+    index = np.tile(np.arange(K, dtype=np.int32), (B, 1))
+    count = np.array([200, 200, 200, 200, 0, 1, 63, 64, 129], np.int32)
+    for thr in (0.5, 0.3, 1.0, 0.0):
+        tb, ts, ti, tc = [torch.from_numpy(a.copy()).cuda() for a in (boxes, scores, index, count)]
+        _lib.check(l.mbx_nms(tb.data_ptr(), ts.data_ptr(), ti.data_ptr(), tc.data_ptr(), B, K, float(thr),
+                             torch.cuda.current_stream().cuda_stream), "mbx_nms")
+        ob, os_, oi, oc = [t.cpu().numpy() for t in (tb, ts, ti, tc)]
+        for b in range(B):
+            keep = R.nms_greedy(boxes[b, :count[b]], thr)
+            assert oc[b] == len(keep), (thr, b, oc[b], len(keep))
+            assert np.array_equal(oi[b, :oc[b]], keep.astype(np.int32)), (thr, b)
+            assert ob[b, :oc[b]].tobytes() == boxes[b][keep].tobytes() and os_[b, :oc[b]].tobytes() == scores[b][keep].tobytes()
+            if thr == 1.0:
+                assert oc[b] == count[b]
+            if count[b] > 0:
+                assert oi[b, 0] == 0                                     # the best box always survives
+        assert oc[2] == (1 if thr < 1.0 else 200) and oc[3] == 200 and oc[4] == 0 and oc[5] == 1
+
+
+def test_detect_postprocess_with_nms_option():
+    """DetectPostprocess(nms_iou=...) = the reference path followed by the NMS stage; nms_iou=None is the reference."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import detect as D
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(8)
+    P, B = 646, 4
+    priors = rng.uniform(0.1, 0.5, (P, 4)).astype(np.float32)
+    priors[:, 2:] = priors[:, :2] + rng.uniform(0.05, 0.4, (P, 2)).astype(np.float32)
+    raw = (rng.randn(B, P, 4) * 0.02).astype(np.float32)
+    confs = rng.uniform(0, 1, (B, P)).astype(np.float32)
+    dims = np.tile([[299, 299]], (B, 1))
+    meta = D.make_patch_meta(np.zeros((B, 2), np.int32), dims, np.zeros((B,), np.int32),
+                             np.tile([[0, 0, 1, 1]], (B, 1)).astype(np.float32), np.full((B,), 200, np.int32), dims)
+    T = lambda a: torch.from_numpy(a).cuda()
+    base = [t.cpu().numpy().copy() for t in D.DetectPostprocess(priors, B, k_max=200)(T(raw), T(confs), meta)]
+    out = [t.cpu().numpy() for t in D.DetectPostprocess(priors, B, k_max=200, nms_iou=0.45)(T(raw), T(confs), meta)]
+    for b in range(B):
+        keep = R.nms_greedy(base[0][b, :base[3][b]], 0.45)
+        assert out[3][b] == len(keep) < base[3][b]
+        assert np.array_equal(out[2][b, :len(keep)], base[2][b][keep]) and out[0][b, :len(keep)].tobytes() == base[0][b][keep].tobytes()

@@ -148,3 +148,16 @@ def test_trainable_scopes_ranges():
     tr.w_lo, tr.bt_lo = net.head_w_start, net.head_bt_start
     r = tr._optimizer_ranges(["InceptionResnetV2"])
     assert all(x[3] == 0 for x in r) and tr.trainable_names == []
+
+
+def test_oracle_nms_known_answers():
+    """oracle.ref_numpy.nms_greedy (row N1; the reference has no NMS, so these are hand-computed answers)."""
+    from oracle import ref_numpy as R
+    import numpy as np
+    b = np.array([[0, 0, 1, 1], [0, 0, 1, .5], [.5, .5, 1.5, 1.5], [2, 2, 3, 3], [0, 0, 1, 1]], np.float64)
+    # IoU(0,1) = .5, IoU(0,2) = .25/1.75, IoU(0,4) = 1, IoU(1,2) = 0 (touching edge), box 3 is disjoint
+    assert R.nms_greedy(b, 0.5).tolist() == [0, 1, 2, 3]              # strictly greater than the threshold suppresses
+    assert R.nms_greedy(b, 0.49).tolist() == [0, 2, 3]
+    assert R.nms_greedy(b, 0.1).tolist() == [0, 3]
+    assert R.nms_greedy(b, 1.0).tolist() == [0, 1, 2, 3, 4]
+    assert R.nms_greedy(np.zeros((0, 4)), 0.5).tolist() == []
