@@ -460,6 +460,12 @@ class Net:
         self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
             ops.autotune(d, key)
+            # Data-parallel runs (bn_max_wg > 0: RCCL kernels of the bucket in flight hold CUs for milliseconds): the
+            # persistent igemm5 launch assigns its tiles to blocks STATICALLY and needs a whole CU per block, so a block
+            # that cannot start until an RCCL block leaves would finish its share late.  Use the library's igemm3 pick
+            # there (the grouped weight gradient is persistent too, but its blocks pull work from queues and steal).
+            if self.bn_max_wg and d.tile_config > ops.I5_FLAG:
+                d.tile_config = 0
         return d
 
     def _build_forward_launches(self):
