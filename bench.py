@@ -277,6 +277,19 @@ def detect_leg(args, world, rank, pg):
             out["postprocess"] = {"kernel": "decode_filter_topk_kernel", "bound": "hbm (launch-latency in practice)",
                                   "us_per_batch": round(us, 1), "achieved": round(alg / us / 1e3, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 5)}
+            # BASELINE config 4 names a per-image NMS; the reference has none, so it is an OPTIONAL stage that
+            # is NOT part of `value` above: timed here on the same batch for the record (mbx_nms, IoU 0.5)
+            ppn = D.DetectPostprocess(priors, B, k_max=200, nms_iou=0.5)
+            ppn(net.locs, conf, meta)
+            a.record()
+            for _ in range(20):
+                ppn(net.locs, conf, meta)
+            b.record()
+            torch.cuda.synchronize()
+            out["optional_nms"] = {"kernel": "decode_filter_topk_kernel + nms_kernel", "iou_threshold": 0.5,
+                                   "us_per_batch": round(a.elapsed_time(b) / 20 * 1e3, 1),
+                                   "mean_kept_of_200": round(float(ppn.count.float().mean()), 1),
+                                   "note": "not in the reference (detect.py:408-443 has no NMS); not included in value"}
         except Exception as e:
             out["roofline"] = {"error": repr(e)}
     del gr
