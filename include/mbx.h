@@ -190,7 +190,8 @@ int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const
  * with one difference: dw / db MUST be zero before the launch and each job needs its own dw -- a tile whose pixel
  * reduction is not split is written with plain stores (one adder: nothing to add to), split tiles add atomically.
  * The launch is PERSISTENT: one 768-thread workgroup per CU (8 MFMA waves + 4 LDS-DMA loader waves) pulls work items
- * from per-XCD queues inside the image (queue heads are reset by a memset the call enqueues before the kernel).
+ * from per-XCD queues inside the image (the queue heads start at zero in the image and the kernel's last block
+ * resets them, so the same image serves every launch; one launch of an image at a time).
  * mbx_wgrad_plan writes a HOST image of mbx_wgrad_plan_bytes() bytes; copy it to 16-byte aligned device memory
  * once and pass that pointer to every launch.  The image embeds the jobs' device pointers.                    */
 typedef struct {

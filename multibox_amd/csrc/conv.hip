@@ -989,6 +989,18 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
 #undef MBX_WG_CASE
     }
   }
+  // Leave the queue heads at zero for the next launch: the LAST block to get here (every other block has left its
+  // dequeue loops) resets them.  (A hipMemsetAsync in front of the kernel did this first; as a memset NODE of a captured
+  // graph replayed hundreds of times with the host far ahead it ended in GPU memory-access faults, 4 of 10 400-step
+  // runs -- the launch now carries no memset.)
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    int* exits = heads + kQueues * kCounterStride;
+    if (atomicAdd(exits, 1) == (int)gridDim.x - 1) {
+      for (int q = 0; q < kQueues; ++q) atomicExch(heads + q * kCounterStride, 0);
+      atomicExch(exits, 0);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -1362,7 +1374,9 @@ static void plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, std::vec
     const long long M = (long long)d.N * d.H_out * d.W_out;
     const int Ktot = d.R * d.S * d.C_in;
     double best = 1e300;
-    for (int c = 0; c < kNumWgCfgs; ++c) {
+    static int max_cfg = -1;
+    if (max_cfg < 0) { const char* e = getenv("MBX_WG_MAXCFG"); max_cfg = e ? atoi(e) : kNumWgCfgs; }   // bisecting aid
+    for (int c = 0; c < kNumWgCfgs && c < max_cfg; ++c) {
       const int ny = kWgCfgs[c][0], nx = kWgCfgs[c][1];
       const int tn = (d.C_out + 64 * ny - 1) / (64 * ny), tk = (Ktot + 64 * nx - 1) / (64 * nx);
       const double dma = 390.0 * (ny + nx), mfma = 128.0 * ny * nx;
@@ -1441,7 +1455,7 @@ static size_t plan_image_bytes(int n_jobs, size_t n_items, int64_t* items_off, i
   if (queues_off) *queues_off = (int64_t)o;
   o += 128;                                            // qrange: 2 x kQueues ints
   if (heads_off) *heads_off = (int64_t)o;
-  o += (size_t)kQueues * kCounterStride * sizeof(int);
+  o += (size_t)(kQueues + 1) * kCounterStride * sizeof(int);            // queue heads + the exit counter, a line each
   return o;
 }
 
@@ -1505,9 +1519,7 @@ extern "C" int mbx_conv_wgrad_grouped(void* device_image, const mbx_wgrad_plan_i
   }
   char* base = reinterpret_cast<char*>(device_image);
   hipStream_t s = mbx_s(stream);
-  // queue heads back to zero (a memset node when the launch is captured into a hipGraph)
-  if (hipMemsetAsync(base + info->heads_off, 0, (size_t)kQueues * kCounterStride * sizeof(int), s) != hipSuccess)
-    return MBX_ERR_LAUNCH;
+  // (queue heads: zero in the plan image, and reset by the kernel's last block at the end of every launch)
   const int blocks = info->n_items < plan_cus() ? info->n_items : plan_cus();      // one persistent block per CU
   hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3(blocks), dim3(64 * (8 + kWgLoaders)), kLds, s,
                      reinterpret_cast<const WgradLayer*>(base + info->layers_off),

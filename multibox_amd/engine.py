@@ -464,7 +464,7 @@ class Net:
             # persistent igemm5 launch assigns its tiles to blocks STATICALLY and needs a whole CU per block, so a block
             # that cannot start until an RCCL block leaves would finish its share late.  Use the library's igemm3 pick
             # there (the grouped weight gradient is persistent too, but its blocks pull work from queues and steal).
-            if self.bn_max_wg and d.tile_config > ops.I5_FLAG:
+            if (self.bn_max_wg or os.environ.get("MBX_NO_I5") == "1") and d.tile_config > ops.I5_FLAG:
                 d.tile_config = 0
         return d
 

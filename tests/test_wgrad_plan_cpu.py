@@ -52,8 +52,8 @@ def _plan(jobs, flags):
     raw = bytes(host)
     items = (_Item * info.n_items).from_buffer_copy(raw[info.items_off:info.items_off + 32 * info.n_items])
     q = np.frombuffer(raw[info.queues_off:info.queues_off + 64], dtype=np.int32)
-    assert info.heads_off + 8 * 32 * 4 <= nbytes and info.heads_off % 128 == 0
-    assert not any(raw[info.heads_off:info.heads_off + 8 * 32 * 4])          # queue heads start at zero
+    assert info.heads_off + 9 * 32 * 4 <= nbytes and info.heads_off % 128 == 0
+    assert not any(raw[info.heads_off:info.heads_off + 9 * 32 * 4])          # queue heads + exit counter start at zero
     return info, items, q
 
 
