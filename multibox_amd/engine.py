@@ -465,7 +465,7 @@ class Net:
             # that cannot start until an RCCL block leaves would finish its share late.  Use the library's igemm3 pick
             # there (the grouped weight gradient is persistent too, but its blocks pull work from queues and steal).
             if (self.bn_max_wg or os.environ.get("MBX_NO_I5") == "1") and d.tile_config > ops.I5_FLAG:
-                d.tile_config = 0
+                d.tile_config = ops._TUNED.get(repr(key) + "#i3", 0)       # the best igemm3 tile the tuner saw, else the rule
         return d
 
     def _build_forward_launches(self):

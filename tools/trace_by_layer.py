@@ -57,7 +57,7 @@ for key, a in agg.items():
 print("totals us: fwd %.0f dgrad %.0f wgrad %.0f" % tuple(tot))
 other = {}
 for r in step:
-    n = r["Kernel_Name"].split("(")[0].split("<")[0]
+    n = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("<")[0].split("(")[0]
     o = other.setdefault(n, [0, 0.0]); o[0] += 1; o[1] += dur(r)
 print("kernels of the last step:")
 for n, (c, t) in sorted(other.items(), key=lambda kv: -kv[1][1]):

@@ -154,6 +154,11 @@ def main():
             gain += t_cur - t_best
             print("%-6s %-110s %2d -> %2d  %8.1f -> %8.1f us" % (what_of[key], key[:110], cur, best, 1e3 * t_cur, 1e3 * t_best))
             ops._TUNED[key] = best
+        if best > ops.I5_FLAG:
+            # data-parallel runs do not use the persistent igemm5 launch (engine._tune): keep the best igemm3 tile beside it
+            i3 = {cfg: med(v) for cfg, v in per_cfg.items() if cfg <= ops.N_TILE_CONFIGS and (cfg in allowed or cfg == cur)}
+            if i3:
+                ops._TUNED[key + "#i3"] = min(i3, key=i3.get)
     print("%d of %d shapes changed; summed in-step gain %.3f ms per step (event-timed)" % (changed, len(times), gain))
     ops.save_tune_cache(args.out)
 
