@@ -65,3 +65,25 @@ def test_head_grids():
     from multibox_amd.priors import head_grids
     assert head_grids(299) == ([8, 6, 4, 3, 2], 1)
     assert head_grids(512) == ([14, 12, 7, 6, 5], 49)
+
+
+def test_conv_stats_rows_follow_the_tile(lib):
+    """mbx_conv_stats_rows (host): the number of BN-statistics partial rows a forward launch writes is ceil(M / BM) of the
+    tile the launch will use -- igemm3 tiles 1..14 and the persistent igemm5 tiles 33..37 (csrc/conv5.hip); unknown
+    igemm5 indices are rejected."""
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    d = ops.ConvDesc()
+    d.N, d.H_in, d.W_in, d.C_in, d.C_out, d.R, d.S, d.stride = 64, 17, 17, 128, 160, 1, 7, 1
+    d.H_out, d.W_out = 17, 17
+    M = 64 * 17 * 17
+    l = _lib.lib()
+    bm3 = {1: 128, 2: 128, 3: 64, 4: 128, 5: 64, 6: 256, 7: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 256, 14: 128}
+    for cfg, bm in bm3.items():
+        d.tile_config = cfg
+        assert l.mbx_conv_stats_rows(C.byref(d)) == -(-M // bm), cfg
+    for cfg, bm in zip(ops.I5_TILE_CONFIGS, (128, 128, 192, 256, 256)):
+        d.tile_config = cfg
+        assert l.mbx_conv_stats_rows(C.byref(d)) == -(-M // bm), cfg
+    d.tile_config = ops.I5_FLAG + 9
+    assert l.mbx_conv_stats_rows(C.byref(d)) < 0
