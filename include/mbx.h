@@ -335,6 +335,32 @@ int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* mom /*NULL 
                          int trainable, float* reg_loss, mbx_stream_t stream);
 int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, mbx_stream_t stream);
 
+/* ------------------------------------------------------------ training input augmentation (row F1)
+ * The pixel half of the reference's training input graph (inputs.py:264-351: crop, tf.image.resize_images with a
+ * random ResizeMethod, distort_color, random_flip_left_right, (image - 0.5) * 2) for one batch.  The host draws every
+ * random decision and decodes the JPEGs (multibox_amd/inputs.py: plan_augmentation); each item describes one image:
+ * its already-cropped pixels [src_h][src_w][3] uint8 at src + src_offset, the resize method (0 bilinear, 1 nearest,
+ * 2 bicubic, 3 area: TF 0.11's legacy kernels, align_corners = False; 4 = the bytes at src_offset are a float32
+ * [S][S][3] picture in [0,1] the host prepared itself, src_offset a multiple of 4), the colour ops in application
+ * order (0 brightness delta, 1 saturation factor, 2 hue delta, 3 contrast factor; n_ops = 0: no colour distortion and
+ * no clipping), and the flip.  out[b] = the [S][S][3] float32 picture in [-1,1].
+ * any_contrast must be non-zero iff some item has a contrast op (it adds the per-image mean pass).
+ * Resize arithmetic is float32 in the host restatement's rounding order (bit-identical to it); colour ops run in
+ * float64 like the restatement and differ from it only through the summation order of the contrast mean.          */
+typedef struct {
+  uint64_t src_offset;
+  int32_t src_h, src_w;
+  int32_t method;
+  int32_t flip;
+  int32_t n_ops;
+  int32_t op[4];
+  int32_t pad_;
+  double arg[4];
+} mbx_augment_item;                                   /* 80 bytes */
+size_t mbx_augment_workspace_bytes(int B, int S);
+int mbx_augment_batch(const uint8_t* src /*device*/, const mbx_augment_item* items /*device, [B]*/, int B, int S,
+                      int any_contrast, float* out /*[B,S,S,3]*/, void* workspace, mbx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""Device side of the training input augmentation: mbx_augment_batch behind a small host class.
+
+The reference runs crop / tf.image.resize_images(random method) / distort_color / random_flip_left_right / (x-0.5)*2
+(inputs.py:264-351) as TF CPU ops inside NUM_INPUT_THREADS queue runners.  Here the host (inputs.plan_augmentation)
+keeps the random draws, the box arithmetic and the JPEG decode; the pixel work of a whole batch is three HIP launches.
+`BatchAugmenter.stage()` packs the cropped uint8 pictures of a batch into one pinned buffer (one H2D copy) and
+`run()` launches the kernels on the current stream.  There is no host fallback here: without libmbx this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .inputs import COLOR_CONTRAST
+
+ITEM_DTYPE = np.dtype([("src_offset", "<u8"), ("src_h", "<i4"), ("src_w", "<i4"), ("method", "<i4"), ("flip", "<i4"),
+                       ("n_ops", "<i4"), ("op", "<i4", (4,)), ("pad_", "<i4"), ("arg", "<f8", (4,))])
+assert ITEM_DTYPE.itemsize == 80                       # mbx_augment_item (include/mbx.h)
+METHOD_PREPARED = 4
+ALIGN = 16
+
+
+def source_bytes(h, w):
+    return (int(h) * int(w) * 3 + ALIGN - 1) // ALIGN * ALIGN
+
+
+def fill_item(item, offset, h, w, method, flip, color):
+    """Write one mbx_augment_item; `color` is [(op, argument), ...] in application order (inputs.color_ops)."""
+    if not 0 <= int(method) <= METHOD_PREPARED or h <= 0 or w <= 0 or len(color) > 4:
+        raise ValueError("bad augmentation item: method %r, %rx%r, %d colour ops" % (method, h, w, len(color)))
+    item["src_offset"], item["src_h"], item["src_w"] = offset, h, w
+    item["method"], item["flip"], item["n_ops"] = method, int(bool(flip)), len(color)
+    item["op"][:] = 0
+    item["arg"][:] = 0.0
+    for k, (op, arg) in enumerate(color):
+        if not 0 <= int(op) <= 3:
+            raise ValueError("unknown colour op %r" % (op,))
+        item["op"][k], item["arg"][k] = op, arg
+    return any(op == COLOR_CONTRAST for op, _ in color)
+
+
+class BatchAugmenter:
+    """Buffers for one in-flight batch: pinned staging (pixels + items), their device copies, the kernel workspace and
+    the [B,S,S,3] float32 output in [-1,1]."""
+
+    def __init__(self, batch_size, input_size, slot_bytes, device="cuda"):
+        import torch
+        self.torch = torch
+        self.B, self.S = int(batch_size), int(input_size)
+        self.slot_bytes = max(int(slot_bytes), self.S * self.S * 3 * 4)
+        self.capacity = self.B * (self.slot_bytes + ALIGN)
+        self.h_pix = torch.empty((self.capacity,), dtype=torch.uint8, pin_memory=True)
+        self.h_items = torch.empty((self.B * ITEM_DTYPE.itemsize,), dtype=torch.uint8, pin_memory=True)
+        self.items = self.h_items.numpy().view(ITEM_DTYPE)
+        self.d_pix = torch.empty((self.capacity,), dtype=torch.uint8, device=device)
+        self.d_items = torch.empty_like(self.h_items, device=device)
+        ws = int(_lib.lib().mbx_augment_workspace_bytes(self.B, self.S))
+        self.workspace = torch.empty((ws,), dtype=torch.uint8, device=device)
+        self.out = torch.empty((self.B, self.S, self.S, 3), dtype=torch.float32, device=device)
+        self.used = 0
+        self.any_contrast = False
+        self.count = 0
+
+    def begin(self):
+        self.used, self.any_contrast, self.count = 0, False, 0
+
+    def add(self, pixels, method, flip, color):
+        """Append one picture: uint8 [h,w,3] (already cropped) for methods 0..3, or float32 [S,S,3] in [0,1] with
+        method 4 (prepared on the host, e.g. a crop too large for a slot)."""
+        i = self.count
+        if i >= self.B:
+            raise ValueError("batch is full")
+        pixels = np.ascontiguousarray(pixels)
+        if int(method) == METHOD_PREPARED:
+            if pixels.dtype != np.float32 or pixels.shape != (self.S, self.S, 3):
+                raise ValueError("a prepared picture is float32 [S,S,3]")
+            h = w = self.S
+        else:
+            if pixels.dtype != np.uint8 or pixels.ndim != 3 or pixels.shape[2] != 3:
+                raise ValueError("a source picture is uint8 [h,w,3]")
+            h, w = pixels.shape[:2]
+        raw = pixels.reshape(-1).view(np.uint8)
+        if self.used + raw.size > self.capacity:
+            raise ValueError("source pixels exceed the staging buffer (%d bytes)" % self.capacity)
+        self.h_pix.numpy()[self.used:self.used + raw.size] = raw
+        self.any_contrast |= fill_item(self.items[i], self.used, h, w, method, flip, color)
+        self.used += (raw.size + ALIGN - 1) // ALIGN * ALIGN
+        self.count += 1
+
+    def run(self):
+        """H2D copies + the three launches on the CURRENT stream; returns the device tensor [count,S,S,3]."""
+        torch = self.torch
+        n = self.count
+        if n == 0:
+            return self.out[:0]
+        self.d_pix[:self.used].copy_(self.h_pix[:self.used], non_blocking=True)
+        self.d_items.copy_(self.h_items, non_blocking=True)
+        _lib.check(_lib.lib().mbx_augment_batch(self.d_pix.data_ptr(), self.d_items.data_ptr(), n, self.S,
+                                                int(self.any_contrast), self.out.data_ptr(), self.workspace.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "mbx_augment_batch")
+        return self.out[:n]

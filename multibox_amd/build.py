@@ -23,6 +23,7 @@ SOURCES = {
     "conv.hip": ["-munsafe-fp-atomics"],
     "conv5.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
+    "augment.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 

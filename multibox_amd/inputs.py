@@ -282,67 +282,110 @@ def _hsv_to_rgb(hsv):
     return np.stack([(1 - s + s * dr) * v, (1 - s + s * dg) * v, (1 - s + s * db) * v], -1)
 
 
-def distort_color(image, color_ordering, fast_mode, rng):
-    """inputs.py:44-98 with tf.image.random_{brightness,saturation,hue,contrast} restated; result clipped to [0,1]."""
-    img = np.asarray(image, np.float32).astype(np.float64)
+COLOR_BRIGHTNESS, COLOR_SATURATION, COLOR_HUE, COLOR_CONTRAST = 0, 1, 2, 3
+_COLOR_ORDERS = {0: (COLOR_BRIGHTNESS, COLOR_SATURATION, COLOR_HUE, COLOR_CONTRAST),          # inputs.py:44-98
+                 1: (COLOR_SATURATION, COLOR_BRIGHTNESS, COLOR_CONTRAST, COLOR_HUE),
+                 2: (COLOR_CONTRAST, COLOR_HUE, COLOR_BRIGHTNESS, COLOR_SATURATION),
+                 3: (COLOR_HUE, COLOR_SATURATION, COLOR_CONTRAST, COLOR_BRIGHTNESS)}
+_COLOR_RANGES = {COLOR_BRIGHTNESS: (-32.0 / 255.0, 32.0 / 255.0), COLOR_SATURATION: (0.5, 1.5),
+                 COLOR_HUE: (-0.2, 0.2), COLOR_CONTRAST: (0.5, 1.5)}
 
-    def brightness(x):
-        return x + rng.uniform(-32.0 / 255.0, 32.0 / 255.0)
 
-    def saturation(x):
-        hsv = _rgb_to_hsv(x)
-        hsv[..., 1] = np.clip(hsv[..., 1] * rng.uniform(0.5, 1.5), 0, 1)
-        return _hsv_to_rgb(hsv)
-
-    def hue(x):
-        hsv = _rgb_to_hsv(x)
-        hsv[..., 0] = (hsv[..., 0] + rng.uniform(-0.2, 0.2)) % 1.0
-        return _hsv_to_rgb(hsv)
-
-    def contrast(x):
-        m = x.mean((0, 1), keepdims=True)
-        return (x - m) * rng.uniform(0.5, 1.5) + m
+def color_ops(color_ordering, fast_mode, rng):
+    """The (op, argument) list of one distort_color call (inputs.py:44-98): tf.image.random_{brightness,saturation,hue,
+    contrast} each draw their delta / factor when applied, so the draws follow the application order."""
     if fast_mode:
-        order = (brightness, saturation) if color_ordering == 0 else (saturation, brightness)
+        order = (COLOR_BRIGHTNESS, COLOR_SATURATION) if color_ordering == 0 else (COLOR_SATURATION, COLOR_BRIGHTNESS)
     else:
-        order = {0: (brightness, saturation, hue, contrast), 1: (saturation, brightness, contrast, hue),
-                 2: (contrast, hue, brightness, saturation), 3: (hue, saturation, contrast, brightness)}.get(color_ordering)
+        order = _COLOR_ORDERS.get(color_ordering)
         if order is None:
             raise ValueError("color_ordering must be in [0, 3]")
-    for f in order:
-        img = f(img)
+    return [(op, float(rng.uniform(*_COLOR_RANGES[op]))) for op in order]
+
+
+def apply_color_ops(image, ops):
+    """tf.image.adjust_{brightness,saturation,hue,contrast} restated in float64, applied in order; clipped to [0,1]."""
+    img = np.asarray(image, np.float32).astype(np.float64)
+    for op, arg in ops:
+        if op == COLOR_BRIGHTNESS:
+            img = img + arg
+        elif op == COLOR_SATURATION:
+            hsv = _rgb_to_hsv(img)
+            hsv[..., 1] = np.clip(hsv[..., 1] * arg, 0, 1)
+            img = _hsv_to_rgb(hsv)
+        elif op == COLOR_HUE:
+            hsv = _rgb_to_hsv(img)
+            hsv[..., 0] = (hsv[..., 0] + arg) % 1.0
+            img = _hsv_to_rgb(hsv)
+        else:
+            m = img.mean((0, 1), keepdims=True)
+            img = (img - m) * arg + m
     return np.clip(img, 0.0, 1.0).astype(np.float32)
+
+
+def distort_color(image, color_ordering, fast_mode, rng):
+    """inputs.py:44-98 with tf.image.random_{brightness,saturation,hue,contrast} restated; result clipped to [0,1]."""
+    return apply_color_ops(image, color_ops(color_ordering, fast_mode, rng))
+
+
+class AugmentPlan:
+    """Every random decision of one example's augmentation (inputs.py:264-327), drawn in the reference's order, apart
+    from the pixels: `crop` (y, x, h, w) in source pixels or None, `method` (tf.image.ResizeMethod 0..3), `color`
+    [(op, argument)...] (empty = no colour distortion), `flip`, and the boxes after shift / crop / flip."""
+    __slots__ = ("crop", "method", "color", "flip", "xmin", "ymin", "xmax", "ymax")
+
+
+def plan_augmentation(H, W, image_height, image_width, xmin, ymin, xmax, ymax, cfg, rng):
+    """Draw an AugmentPlan for a decoded image of H x W pixels (image_height / image_width are the record's fields the
+    box arithmetic uses, inputs.py:264-285).  The pixel work is apply_plan() on the host or mbx_augment_batch on the GPU."""
+    p = AugmentPlan()
+    n = len(xmin)
+    if rng.uniform() < float(cfg.get("DO_RANDOM_BBOX_SHIFT", 0) or 0) and n > 0:                 # inputs.py:264-270
+        xmin, ymin, xmax, ymax = shift_bboxes(xmin, ymin, xmax, ymax, image_height, image_width,
+                                              cfg.RANDOM_BBOX_SHIFT_EXTENT, rng)
+    p.crop = None
+    if rng.uniform() < float(cfg.get("DO_RANDOM_CROP", 0) or 0):                                 # inputs.py:272-285
+        boxes = np.stack([ymin, xmin, ymax, xmax], 1) if n > 0 else np.zeros((0, 4), np.float32)
+        p.crop = tuple(int(v) for v in sample_distorted_bounding_box(
+            H, W, boxes, cfg.RANDOM_CROP_MIN_OBJECT_COVERED, cfg.RANDOM_CROP_ASPECT_RATIO_RANGE,
+            cfg.RANDOM_CROP_AREA_RANGE, cfg.RANDOM_CROP_MAX_ATTEMPTS, rng))
+        xmin, ymin, xmax, ymax = crop_bboxes(xmin, ymin, xmax, ymax, image_height, image_width, p.crop,
+                                             cfg.RANDOM_CROP_MINIMUM_AREA)
+    p.method = int(rng.randint(0, 4))                                                            # inputs.py:296-302
+    do_color = rng.uniform() < float(cfg.get("DO_COLOR_DISTORTION", 0) or 0)                     # inputs.py:312-320
+    fast = bool(cfg.get("COLOR_DISTORT_FAST", True))
+    ordering = 0 if fast else int(rng.randint(0, 4))
+    p.color = color_ops(ordering, fast, rng) if do_color else []
+    p.flip = bool(cfg.get("DO_RANDOM_FLIP_LEFT_RIGHT", False) and rng.uniform() < 0.5)           # inputs.py:323-327
+    if p.flip:
+        xmin, xmax = np.float32(1.0) - xmax, np.float32(1.0) - xmin
+    p.xmin, p.ymin, p.xmax, p.ymax = xmin, ymin, xmax, ymax
+    return p
+
+
+def crop_pixels(img, plan):
+    if plan.crop is None:
+        return img
+    y, x, ch, cw = plan.crop
+    return img[y:y + ch, x:x + cw]
+
+
+def apply_plan(image01, plan, S):
+    """The pixel half of the augmentation on the host: crop, resize with the drawn method, colour ops, flip.
+    image01 is the decoded image in [0,1]; returns [S,S,3] float32 in [0,1]."""
+    img = RESIZE_METHODS[plan.method](crop_pixels(image01, plan), S, S)
+    if plan.color:
+        img = apply_color_ops(img, plan.color)
+    if plan.flip:
+        img = img[:, ::-1]
+    return np.ascontiguousarray(img, np.float32)
 
 
 def augment_example(image01, image_height, image_width, xmin, ymin, xmax, ymax, cfg, rng):
     """One example through inputs.py:264-327 (the draws in the reference's order): returns
     (image [S,S,3] in [0,1], xmin, ymin, xmax, ymax) with the boxes that survived the crop."""
-    S = int(cfg.INPUT_SIZE)
-    n = len(xmin)
-    if rng.uniform() < float(cfg.get("DO_RANDOM_BBOX_SHIFT", 0) or 0) and n > 0:                 # inputs.py:264-270
-        xmin, ymin, xmax, ymax = shift_bboxes(xmin, ymin, xmax, ymax, image_height, image_width,
-                                              cfg.RANDOM_BBOX_SHIFT_EXTENT, rng)
-    img = image01
-    if rng.uniform() < float(cfg.get("DO_RANDOM_CROP", 0) or 0):                                 # inputs.py:272-285
-        H, W = img.shape[0], img.shape[1]
-        boxes = np.stack([ymin, xmin, ymax, xmax], 1) if n > 0 else np.zeros((0, 4), np.float32)
-        crop = sample_distorted_bounding_box(H, W, boxes, cfg.RANDOM_CROP_MIN_OBJECT_COVERED,
-                                             cfg.RANDOM_CROP_ASPECT_RATIO_RANGE, cfg.RANDOM_CROP_AREA_RANGE,
-                                             cfg.RANDOM_CROP_MAX_ATTEMPTS, rng)
-        y, x, ch, cw = crop
-        img = img[y:y + ch, x:x + cw]
-        xmin, ymin, xmax, ymax = crop_bboxes(xmin, ymin, xmax, ymax, image_height, image_width, crop,
-                                             cfg.RANDOM_CROP_MINIMUM_AREA)
-    img = RESIZE_METHODS[int(rng.randint(0, 4))](img, S, S)                                      # inputs.py:296-302
-    do_color = rng.uniform() < float(cfg.get("DO_COLOR_DISTORTION", 0) or 0)                     # inputs.py:312-320
-    fast = bool(cfg.get("COLOR_DISTORT_FAST", True))
-    ordering = 0 if fast else int(rng.randint(0, 4))
-    if do_color:
-        img = distort_color(img, ordering, fast, rng)
-    if cfg.get("DO_RANDOM_FLIP_LEFT_RIGHT", False) and rng.uniform() < 0.5:                      # inputs.py:323-327
-        img = img[:, ::-1]
-        xmin, xmax = np.float32(1.0) - xmax, np.float32(1.0) - xmin
-    return np.ascontiguousarray(img, np.float32), xmin, ymin, xmax, ymax
+    p = plan_augmentation(image01.shape[0], image01.shape[1], image_height, image_width, xmin, ymin, xmax, ymax, cfg, rng)
+    return apply_plan(image01, p, int(cfg.INPUT_SIZE)), p.xmin, p.ymin, p.xmax, p.ymax
 
 
 def _records_sharded(tfrecords, shard):
@@ -357,11 +400,19 @@ def _records_sharded(tfrecords, shard):
             i += 1
 
 
+def decode_image_u8(jpeg_bytes):
+    """tf.image.decode_jpeg(channels=3): [H,W,3] uint8."""
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(jpeg_bytes)).convert("RGB"), dtype=np.uint8)
+
+
 def train_examples(tfrecords, cfg, max_num_bboxes, num_epochs=None, seed=0, shuffle=False, capacity=1000,
-                   min_after_dequeue=96, shard=(0, 1)):
+                   min_after_dequeue=96, shard=(0, 1), device_augment=False):
     """Yield prepared training examples (image [S,S,3] float32 in [-1,1], bboxes [G,4] x1,y1,x2,y2, num_bboxes, image_id)
     of this shard of the records: decode + augmentation (inputs.py:200-351), then an optional shuffle pool
-    (tf.train.shuffle_batch-like: a random pick once more than min_after_dequeue examples wait)."""
+    (tf.train.shuffle_batch-like: a random pick once more than min_after_dequeue examples wait).
+    device_augment=True leaves the pixel work to the GPU (mbx_augment_batch): the first element is then
+    (cropped uint8 pixels [h,w,3], AugmentPlan) -- same draws, same boxes, same order of examples."""
     rng = np.random.RandomState(seed)
     pool = []
 
@@ -380,15 +431,20 @@ def train_examples(tfrecords, cfg, max_num_bboxes, num_epochs=None, seed=0, shuf
         for ex in examples():
             n = int(ex["image/object/bbox/count"][0])
             f = lambda k: np.array(ex.get(k, []), np.float32)[:n]
-            img, xmin, ymin, xmax, ymax = augment_example(
-                decode_image(ex["image/encoded"][0]), int(ex["image/height"][0]), int(ex["image/width"][0]),
-                f("image/object/bbox/xmin"), f("image/object/bbox/ymin"), f("image/object/bbox/xmax"),
-                f("image/object/bbox/ymax"), cfg, rng)
+            u8 = decode_image_u8(ex["image/encoded"][0])
+            p = plan_augmentation(u8.shape[0], u8.shape[1], int(ex["image/height"][0]), int(ex["image/width"][0]),
+                                  f("image/object/bbox/xmin"), f("image/object/bbox/ymin"), f("image/object/bbox/xmax"),
+                                  f("image/object/bbox/ymax"), cfg, rng)
             bb = np.zeros((max_num_bboxes, 4), np.float32)                                    # inputs.py:338-348
-            n = min(len(xmin), max_num_bboxes)
+            n = min(len(p.xmin), max_num_bboxes)
             if n > 0:
-                bb[:n] = np.stack([xmin, ymin, xmax, ymax], 1)[:n]
-            yield (img - np.float32(0.5)) * np.float32(2.0), bb, n, ex["image/id"][0].decode("utf-8")   # inputs.py:350-351
+                bb[:n] = np.stack([p.xmin, p.ymin, p.xmax, p.ymax], 1)[:n]
+            image_id = ex["image/id"][0].decode("utf-8")
+            if device_augment:
+                yield (np.ascontiguousarray(crop_pixels(u8, p)), p), bb, n, image_id
+                continue
+            img = apply_plan(u8.astype(np.float32) * np.float32(1.0 / 255.0), p, int(cfg.INPUT_SIZE))
+            yield (img - np.float32(0.5)) * np.float32(2.0), bb, n, image_id                 # inputs.py:350-351
 
     def shuffled():
         for item in prepared():

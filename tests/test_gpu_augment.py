@@ -1,0 +1,146 @@
+"""mbx_augment_batch (row F1 on the GPU) against the host restatement of the reference's augmentation ops
+(multibox_amd/inputs.py: apply_plan = crop, tf.image.resize_images with the drawn method, distort_color, flip).
+Resize-only items must be BIT-IDENTICAL to the host arithmetic; colour ops run in float64 on both sides and may differ
+through the summation order of the contrast mean only: |diff| <= 1e-6 on the [-1,1] output."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(method, color, flip, crop=None):
+    from multibox_amd import inputs as I
+    p = I.AugmentPlan()
+    p.crop, p.method, p.color, p.flip = crop, method, color, flip
+    return p
+
+
+def _host(u8, plan, S):
+    from multibox_amd import inputs as I
+    img = I.apply_plan(u8.astype(np.float32) * np.float32(1.0 / 255.0), plan, S)
+    return (img - np.float32(0.5)) * np.float32(2.0)
+
+
+def _run(cases, S):
+    import torch
+    from multibox_amd import inputs as I
+    from multibox_amd.augment import BatchAugmenter
+    aug = BatchAugmenter(len(cases), S, slot_bytes=1 << 21)
+    aug.begin()
+    for u8, plan in cases:
+        aug.add(I.crop_pixels(u8, plan), plan.method, plan.flip, plan.color)
+    out = aug.run()
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("S", [299, 64])
+def test_resize_methods_bit_identical_to_the_host_arithmetic(S):
+    rng = np.random.RandomState(3)
+    cases = []
+    for (h, w) in [(480, 640), (333, 500), (97, 61), (299, 299), (1000, 37), (20, 20), (640, 427)]:
+        u8 = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for method in range(4):
+            cases.append((u8, _plan(method, [], bool(rng.randint(2)))))
+    # crops: the worker hands over only the window
+    u8 = rng.randint(0, 256, (375, 500, 3)).astype(np.uint8)
+    for method in range(4):
+        cases.append((u8, _plan(method, [], False, crop=(31, 57, 201, 333))))
+    got = _run(cases, S)
+    for i, (u8, plan) in enumerate(cases):
+        want = _host(u8, plan, S)
+        assert got[i].shape == want.shape
+        if plan.method == 2:                                    # float64 taps: the device's fmul/fadd order is the host's,
+            np.testing.assert_allclose(got[i], want, rtol=0, atol=2.4e-7, err_msg="case %d" % i)   # 1 ulp at 2.0
+        else:
+            assert np.array_equal(got[i], want), "case %d method %d: max diff %g" % (
+                i, plan.method, np.abs(got[i] - want).max())
+
+
+def test_colour_orders_and_flip_match_the_host_arithmetic():
+    from multibox_amd import inputs as I
+    rng = np.random.RandomState(5)
+    S = 299
+    cases = []
+    for ordering in range(4):
+        for fast in (False, True):
+            u8 = rng.randint(0, 256, (rng.randint(100, 500), rng.randint(100, 500), 3)).astype(np.uint8)
+            if ordering == 3 and fast:
+                u8[:] = u8[:1, :1]                              # a flat picture: hue undefined (d = 0), saturation 0
+            color = I.color_ops(ordering, fast, rng)
+            cases.append((u8, _plan(int(rng.randint(4)), color, bool(rng.randint(2)))))
+    # extreme arguments: saturated brightness, hue wrap, contrast both ways
+    u8 = rng.randint(0, 256, (240, 320, 3)).astype(np.uint8)
+    cases.append((u8, _plan(0, [(I.COLOR_BRIGHTNESS, 32 / 255.), (I.COLOR_HUE, 0.2), (I.COLOR_CONTRAST, 1.5),
+                                (I.COLOR_SATURATION, 1.5)], True)))
+    cases.append((u8, _plan(2, [(I.COLOR_CONTRAST, 0.5), (I.COLOR_HUE, -0.2), (I.COLOR_BRIGHTNESS, -32 / 255.),
+                                (I.COLOR_SATURATION, 0.5)], False)))
+    got = _run(cases, S)
+    for i, (u8, plan) in enumerate(cases):
+        want = _host(u8, plan, S)
+        np.testing.assert_allclose(got[i], want, rtol=0, atol=1e-6, err_msg="case %d" % i)
+        assert got[i].min() >= -1.0 and got[i].max() <= 1.0     # distort_color clips to [0,1] (inputs.py:96-98)
+
+
+def test_prepared_pictures_pass_through_and_partial_batches():
+    import torch
+    from multibox_amd.augment import BatchAugmenter, METHOD_PREPARED
+    rng = np.random.RandomState(7)
+    S = 32
+    aug = BatchAugmenter(4, S, slot_bytes=4096)
+    aug.begin()
+    f = rng.rand(S, S, 3).astype(np.float32)
+    aug.add(f, METHOD_PREPARED, False, [])
+    u8 = rng.randint(0, 256, (S, S, 3)).astype(np.uint8)
+    aug.add(u8, 1, True, [])
+    out = aug.run()
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert out.shape == (2, S, S, 3)
+    assert np.array_equal(out[0], (f - np.float32(0.5)) * np.float32(2.0))
+    assert np.array_equal(out[1], ((u8.astype(np.float32) * np.float32(1 / 255.))[:, ::-1] - np.float32(0.5)) * np.float32(2.0))
+    with pytest.raises(ValueError):
+        aug.add(np.zeros((S, S), np.uint8), 0, False, [])
+    with pytest.raises(ValueError):
+        aug.add(u8, 7, False, [])
+
+
+def test_augment_batch_rejects_bad_arguments():
+    from multibox_amd import _lib
+    L = _lib.lib()
+    assert L.mbx_augment_batch(None, None, 2, 299, 0, None, None, None) == -1
+    assert L.mbx_augment_batch(None, None, 0, 299, 0, None, None, None) == 0
+    assert L.mbx_augment_workspace_bytes(64, 299) >= 64 * 299 * 299 * 3 * 4
+
+
+def test_worker_ring_to_device_batches_match_the_host_pipeline(tmp_path):
+    """ParallelTrainInput(device_augment=True) -> DevicePrefetcher (side-stream upload + mbx_augment_batch): the batches
+    on the device equal inputs.train_batches() of the same seed -- boxes and ids exactly, pixels within 1e-6."""
+    import torch
+    from multibox_amd import inputs as I
+    from multibox_amd.config import Cfg
+    from multibox_amd.input_workers import ParallelTrainInput, DevicePrefetcher
+    from tests.test_inputs_cpu import _make_records
+    path = str(tmp_path / "t.tfrecords")
+    _make_records(path, [(220 + 23 * i, 400 - 13 * i, [[.1, .2, .5, .6], [.3, .3, .9, .8]][: i % 3]) for i in range(12)])
+    cfg = Cfg(dict(INPUT_SIZE=299, DO_RANDOM_FLIP_LEFT_RIGHT=True, DO_COLOR_DISTORTION=0.7, COLOR_DISTORT_FAST=False,
+                   DO_RANDOM_CROP=0.6, RANDOM_CROP_MIN_OBJECT_COVERED=0.5, RANDOM_CROP_ASPECT_RATIO_RANGE=[0.7, 1.4],
+                   RANDOM_CROP_AREA_RANGE=[0.3, 1.0], RANDOM_CROP_MAX_ATTEMPTS=50, RANDOM_CROP_MINIMUM_AREA=10,
+                   DO_RANDOM_BBOX_SHIFT=0.5, RANDOM_BBOX_SHIFT_EXTENT=4))
+    ref = list(I.train_batches([path], cfg, 4, 5, num_epochs=1, seed=21))
+    src = ParallelTrainInput([path], cfg, 4, 5, num_workers=1, num_epochs=1, seed=21, shuffle=False,
+                             tmpdir=str(tmp_path), device_augment=True)
+    pre = DevicePrefetcher(src, 4, 299, 5, device="cuda", depth=2)
+    got = []
+    while True:
+        try:
+            images, bb, n, ids = pre.next()
+        except StopIteration:
+            break
+        torch.cuda.current_stream().synchronize()
+        got.append((images.cpu().numpy().copy(), bb.cpu().numpy().copy(), n.cpu().numpy().copy(), list(ids)))
+    pre.close()
+    assert len(got) == len(ref) == 3
+    for (a, b, n, ids), (ra, rb, rn, rids) in zip(got, ref):
+        assert ids == rids and np.array_equal(b, rb) and np.array_equal(n, rn)
+        np.testing.assert_allclose(a, ra, rtol=0, atol=1e-6)

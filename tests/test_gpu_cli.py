@@ -87,15 +87,18 @@ def test_train_then_detect(tmp_path):
     assert os.path.exists(log2 / "model.ckpt-1.pt")
 
 
-def test_train_from_tfrecords_with_input_workers(tmp_path):
+@pytest.mark.parametrize("on_device", ["true", "false"])
+def test_train_from_tfrecords_with_input_workers(tmp_path, on_device):
     """train.py --tfrecords: JPEG records -> NUM_INPUT_THREADS worker processes (multibox_amd/input_workers.py) ->
-    pinned buffers -> asynchronous H2D -> Trainer, six steps with every augmentation switched on."""
+    pinned buffers -> asynchronous H2D (-> mbx_augment_batch when INPUT_AUGMENT_ON_DEVICE) -> Trainer, six steps with
+    every augmentation switched on."""
     import __graft_entry__ as g
     g.build()
     from multibox_amd import priors as PR
     from tests.test_inputs_cpu import _make_records
     cfg = tmp_path / "config.yaml"
     cfg.write_text(CFG.replace("DETECTION :", """NUM_INPUT_THREADS : 3
+INPUT_AUGMENT_ON_DEVICE : ON_DEVICE
 QUEUE_CAPACITY : 24
 QUEUE_MIN : 8
 DO_RANDOM_FLIP_LEFT_RIGHT : true
@@ -109,7 +112,7 @@ RANDOM_CROP_MAX_ATTEMPTS : 100
 RANDOM_CROP_MINIMUM_AREA : 50
 DO_COLOR_DISTORTION : 0.5
 COLOR_DISTORT_FAST : false
-DETECTION :"""))
+DETECTION :""".replace("ON_DEVICE", on_device)))
     pri = tmp_path / "priors.pkl"
     PR.save_priors(str(pri), PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]))
     rec = str(tmp_path / "train.tfrecords")

@@ -236,3 +236,50 @@ def test_parallel_train_input_workers(tmp_path):
         seen += ids
     pre.close()
     assert len(seen) == 20 and sorted(seen) == sorted([str(1000 + i) for i in range(10)] * 2)
+
+
+def test_device_augment_workers_hand_over_the_same_plans(tmp_path):
+    """device_augment=True: workers ship cropped uint8 pixels + the draws; finishing those on the host (apply_plan) must
+    reproduce the host path's batches bit for bit -- same draws, same boxes, same example order.  A slot too small for a
+    crop makes the worker finish that picture itself (method 4, prepared)."""
+    from multibox_amd.input_workers import ParallelTrainInput
+    path = str(tmp_path / "t.tfrecords")
+    specs = [(200 + 17 * i, 310 - 9 * i, [[.1, .2, .5, .6], [.3, .3, .9, .8]] if i % 3 else []) for i in range(8)]
+    _make_records(path, specs)
+    cfg = Cfg(dict(INPUT_SIZE=64, DO_RANDOM_FLIP_LEFT_RIGHT=True, DO_COLOR_DISTORTION=0.7, COLOR_DISTORT_FAST=False,
+                   DO_RANDOM_CROP=0.6, RANDOM_CROP_MIN_OBJECT_COVERED=0.5, RANDOM_CROP_ASPECT_RATIO_RANGE=[0.7, 1.4],
+                   RANDOM_CROP_AREA_RANGE=[0.3, 1.0], RANDOM_CROP_MAX_ATTEMPTS=50, RANDOM_CROP_MINIMUM_AREA=10,
+                   DO_RANDOM_BBOX_SHIFT=0.5, RANDOM_BBOX_SHIFT_EXTENT=4))
+    ref = list(I.train_batches([path], cfg, 4, 5, num_epochs=1, seed=11))
+    assert len(ref) == 2
+
+    class HostFinisher:                                     # stands in for augment.BatchAugmenter without a GPU
+        prepared = 0
+
+        def begin(self):
+            self.images = []
+
+        def add(self, pixels, method, flip, color):
+            if method == 4:
+                self.prepared += 1
+                img = np.array(pixels, np.float32)
+            else:
+                p = I.AugmentPlan()
+                p.crop, p.method, p.flip, p.color = None, method, flip, color
+                img = I.apply_plan(np.asarray(pixels).astype(np.float32) * np.float32(1.0 / 255.0), p, 64)
+            self.images.append((img - np.float32(0.5)) * np.float32(2.0))
+
+    for max_px, want_prepared in ((1024 * 1024, False), (150 * 150, True)):
+        src = ParallelTrainInput([path], cfg, 4, 5, num_workers=1, num_epochs=1, seed=11, shuffle=False,
+                                 tmpdir=str(tmp_path), device_augment=True, max_source_pixels=max_px)
+        fin = HostFinisher()
+        for ra, rb, rn, rids in ref:
+            bb, nn, ids = src.next_into(fin)
+            assert ids == rids and np.array_equal(bb, rb) and np.array_equal(nn, rn)
+            assert np.array_equal(np.stack(fin.images), ra)
+        with pytest.raises(StopIteration):
+            src.next_into(fin)
+        with pytest.raises(TypeError):
+            next(src)
+        src.close()
+        assert (fin.prepared > 0) == want_prepared

@@ -107,7 +107,8 @@ def main():
         # NUM_INPUT_THREADS worker processes (inputs.py:353-371) -> shared-memory ring -> pinned buffers -> async H2D
         src = ParallelTrainInput(files, cfg, cfg.BATCH_SIZE, cfg.MAX_NUM_BBOXES, num_workers=int(cfg.get("NUM_INPUT_THREADS", 4)),
                                  num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + 1000 * rank, shuffle=True,   # train.py:214-225
-                                 capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)))
+                                 capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)),
+                                 device_augment=bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True)))   # resize / colour / flip on the GPU
         real = DevicePrefetcher(src, cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, device="cuda", depth=2)
 
     def next_real():
