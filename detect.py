@@ -87,14 +87,18 @@ def main():
                        image_hw=np.tile([[S, S]], (B, 1)), image_ids=list(range(start, start + B)))
     if args.tfrecords and not args.synthetic:
         from multibox_amd.inputs import detect_batches
-        batches = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch)
+        from multibox_amd.augment import PatchExtractor
+        # the host decodes and lays out the patches (detect.py:183-281); scaling + bilinear resize run on the GPU
+        on_device = bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True))
+        extractor = PatchExtractor(B, S) if on_device else None
+        batches = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch, device_patches=on_device)
     else:
         batches = synthetic_batches()
     for bi, batch in D.shard_batches(batches, rank, world):
         meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
                                  batch["max_to_keep"], batch["image_hw"])
         t = time.time()
-        net.set_input(torch.from_numpy(batch["images"]).cuda())
+        net.set_input(extractor(batch["sources"], batch["patches"]) if "sources" in batch else torch.from_numpy(batch["images"]).cuda())
         locs, logits = net.forward()
         _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "sigmoid")

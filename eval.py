@@ -56,9 +56,19 @@ def main():
                              np.tile([[0., 0., 1., 1.]], (B, 1)), np.full((B, 1), K), np.tile([[S, S]], (B, 1)))
     conf = torch.empty((B, net.P), dtype=torch.float32, device="cuda")
     gt_annotations, pred_annotations, gt_id, step = [], [], 1, 0
-    for images, gt, n_gt, areas, ids in eval_batches(args.tfrecords, cfg, B, cfg.MAX_NUM_BBOXES):
+    on_device = bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True))      # legacy bilinear resize + [-1,1] scaling on the GPU
+    if on_device:
+        from multibox_amd.augment import BatchAugmenter
+        aug = BatchAugmenter(B, S, slot_bytes=1024 * 1024 * 3)
+    for images, gt, n_gt, areas, ids in eval_batches(args.tfrecords, cfg, B, cfg.MAX_NUM_BBOXES, device_images=on_device):
         t = time.time()
-        net.set_input(torch.from_numpy(images).cuda())
+        if on_device:
+            aug.begin()
+            for u8 in images:
+                aug.add(u8, 0, False, [])
+            net.set_input(aug.run())
+        else:
+            net.set_input(torch.from_numpy(images).cuda())
         locs, logits = net.forward()
         _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "sigmoid")

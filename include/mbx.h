@@ -361,6 +361,22 @@ size_t mbx_augment_workspace_bytes(int B, int S);
 int mbx_augment_batch(const uint8_t* src /*device*/, const mbx_augment_item* items /*device, [B]*/, int B, int S,
                       int any_contrast, float* out /*[B,S,S,3]*/, void* workspace, mbx_stream_t stream);
 
+/* Detection input (row F3; detect.py:181-281): patch i is a win_h x win_w window at (win_y, win_x) of the decoded
+ * image [img_h][img_w][3] uint8 at src + src_offset -- of its left-right mirror image when flip_source -- scaled to
+ * [-1,1] first ((x/255 - 0.5) * 2, detect.py:181-182) and then resized to S x S with TF 0.11's legacy bilinear kernel
+ * (tf.image.resize_images, align_corners = False).  The whole image as one window gives the original / flipped
+ * original patches, the sliding windows of detect.extract_patches (detect.py:20-72) the crops.  The window must lie
+ * inside the image (the host checks).  out[i] = float32 [S][S][3]; bit-identical to the host arithmetic.          */
+typedef struct {
+  uint64_t src_offset;
+  int32_t img_h, img_w;
+  int32_t win_y, win_x, win_h, win_w;
+  int32_t flip_source;
+  int32_t pad_;
+} mbx_patch_item;                                     /* 40 bytes */
+int mbx_extract_patches(const uint8_t* src /*device*/, const mbx_patch_item* items /*device, [n]*/, int n, int S,
+                        float* out /*[n,S,S,3]*/, mbx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,7 @@ _SIGS = {
     "mbx_nms": (I, [P, P, P, P, I, I, C.c_double, P]),
     "mbx_augment_workspace_bytes": (SZ, [I, I]),
     "mbx_augment_batch": (I, [P, P, I, I, I, P, P, P]),
+    "mbx_extract_patches": (I, [P, P, I, I, P, P]),
     "mbx_conv_stats_rows": (I, [P]),
     "mbx_conv": (I, [P, P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),

@@ -3,7 +3,7 @@
 The reference runs crop / tf.image.resize_images(random method) / distort_color / random_flip_left_right / (x-0.5)*2
 (inputs.py:264-351) as TF CPU ops inside NUM_INPUT_THREADS queue runners.  Here the host (inputs.plan_augmentation)
 keeps the random draws, the box arithmetic and the JPEG decode; the pixel work of a whole batch is three HIP launches.
-`BatchAugmenter.stage()` packs the cropped uint8 pictures of a batch into one pinned buffer (one H2D copy) and
+`BatchAugmenter.add()` packs the cropped uint8 pictures of a batch into one pinned buffer (one H2D copy) and
 `run()` launches the kernels on the current stream.  There is no host fallback here: without libmbx this raises.
 """
 from __future__ import annotations
@@ -82,8 +82,14 @@ class BatchAugmenter:
                 raise ValueError("a source picture is uint8 [h,w,3]")
             h, w = pixels.shape[:2]
         raw = pixels.reshape(-1).view(np.uint8)
-        if self.used + raw.size > self.capacity:
-            raise ValueError("source pixels exceed the staging buffer (%d bytes)" % self.capacity)
+        if self.used + raw.size > self.capacity:                 # rare: pictures larger than the slots planned for
+            torch = self.torch
+            torch.cuda.synchronize()                             # earlier launches may still read the old buffers
+            self.capacity = max(2 * self.capacity, self.used + raw.size + ALIGN)
+            grown = torch.empty((self.capacity,), dtype=torch.uint8, pin_memory=True)
+            grown[:self.used] = self.h_pix[:self.used]
+            self.h_pix = grown
+            self.d_pix = torch.empty((self.capacity,), dtype=torch.uint8, device=self.d_pix.device)
         self.h_pix.numpy()[self.used:self.used + raw.size] = raw
         self.any_contrast |= fill_item(self.items[i], self.used, h, w, method, flip, color)
         self.used += (raw.size + ALIGN - 1) // ALIGN * ALIGN
@@ -101,3 +107,78 @@ class BatchAugmenter:
                                                 int(self.any_contrast), self.out.data_ptr(), self.workspace.data_ptr(),
                                                 torch.cuda.current_stream().cuda_stream), "mbx_augment_batch")
         return self.out[:n]
+
+
+PATCH_DTYPE = np.dtype([("src_offset", "<u8"), ("img_h", "<i4"), ("img_w", "<i4"), ("win_y", "<i4"), ("win_x", "<i4"),
+                        ("win_h", "<i4"), ("win_w", "<i4"), ("flip_source", "<i4"), ("pad_", "<i4")])
+assert PATCH_DTYPE.itemsize == 40                      # mbx_patch_item (include/mbx.h)
+
+
+class PatchExtractor:
+    """Detection input on the device (row F3): the decoded uint8 images of one batch are uploaded once, every patch
+    (original / flipped original / sliding-window crop, detect.py:183-281) is one item of mbx_extract_patches.
+    Padding entries (None) give all-zero pictures, like the host path of inputs.detect_batches."""
+
+    def __init__(self, batch_size, input_size, device="cuda", capacity_bytes=64 << 20):
+        import torch
+        self.torch = torch
+        self.B, self.S, self.device = int(batch_size), int(input_size), device
+        self.h_items = torch.empty((self.B * PATCH_DTYPE.itemsize,), dtype=torch.uint8, pin_memory=True)
+        self.items = self.h_items.numpy().view(PATCH_DTYPE)
+        self.d_items = torch.empty_like(self.h_items, device=device)
+        self.out = torch.empty((self.B, self.S, self.S, 3), dtype=torch.float32, device=device)
+        self._copied = None
+        self._reserve(capacity_bytes)
+
+    def _reserve(self, nbytes):
+        torch = self.torch
+        self.capacity = int(nbytes)
+        self.h_pix = torch.empty((self.capacity,), dtype=torch.uint8, pin_memory=True)
+        self.d_pix = torch.empty((self.capacity,), dtype=torch.uint8, device=self.device)
+
+    def __call__(self, sources, patches):
+        """sources: list of uint8 [H,W,3]; patches: B entries (source index, (y, x, h, w), flip_source) or None.
+        Returns the device tensor [B,S,S,3] in [-1,1] (valid until the next call)."""
+        torch = self.torch
+        if len(patches) != self.B:
+            raise ValueError("expected %d patches, got %d" % (self.B, len(patches)))
+        offsets, used = [], 0
+        for u8 in sources:
+            if u8.dtype != np.uint8 or u8.ndim != 3 or u8.shape[2] != 3:
+                raise ValueError("a source picture is uint8 [H,W,3]")
+            offsets.append(used)
+            used += source_bytes(u8.shape[0], u8.shape[1])
+        if self._copied is not None:
+            self._copied.synchronize()                          # the previous upload has left the pinned staging
+        if used > self.capacity:
+            torch.cuda.current_stream().synchronize()           # the previous batch may still read the old buffers
+            self._reserve(used * 2)
+        hp = self.h_pix.numpy()
+        for u8, off in zip(sources, offsets):
+            hp[off:off + u8.size] = np.ascontiguousarray(u8).reshape(-1)
+        real = []
+        for i, p in enumerate(patches):
+            if p is None:
+                continue
+            si, (y, x, h, w), fs = p
+            H, W = sources[si].shape[:2]
+            if not (0 <= y and 0 <= x and h > 0 and w > 0 and y + h <= H and x + w <= W):
+                raise ValueError("patch window %r outside its %dx%d image" % ((y, x, h, w), H, W))
+            it = self.items[len(real)]
+            it["src_offset"], it["img_h"], it["img_w"] = offsets[si], H, W
+            it["win_y"], it["win_x"], it["win_h"], it["win_w"], it["flip_source"] = y, x, h, w, int(bool(fs))
+            real.append(i)
+        n = len(real)
+        if real != list(range(n)):
+            raise ValueError("padding entries must come last")
+        if n < self.B:
+            self.out[n:].zero_()
+        if n:
+            self.d_pix[:used].copy_(self.h_pix[:used], non_blocking=True)
+            self.d_items.copy_(self.h_items, non_blocking=True)
+            self._copied = torch.cuda.Event()
+            self._copied.record(torch.cuda.current_stream())
+            _lib.check(_lib.lib().mbx_extract_patches(self.d_pix.data_ptr(), self.d_items.data_ptr(), n, self.S,
+                                                      self.out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "mbx_extract_patches")
+        return self.out

@@ -1,4 +1,5 @@
-// libmbx: the pixel half of the training input augmentation on the GPU.
+// libmbx: the pixel half of the training input augmentation and of the detection input (row F3)
+// on the GPU.
 //
 // The reference's input graph (inputs.py:264-351) crops, resizes with a randomly drawn tf.image.ResizeMethod,
 // distorts colours, flips and rescales every image with TF's CPU image ops.  The host side of this build
@@ -254,7 +255,52 @@ augment_color_kernel(const mbx_augment_item* __restrict__ items, int S, const fl
   for (int ch = 0; ch < 3; ++ch) o[ch] = __fmul_rn(__fsub_rn(v[ch], 0.5f), 2.0f);   // inputs.py:350-351
 }
 
+// Detection input (detect.py:181-281): every patch is a window of the decoded image -- or of its mirror image -- that
+// has been scaled to [-1,1] FIRST and is then resized with the legacy bilinear kernel.
+__global__ void __launch_bounds__(kThreads)
+extract_patches_kernel(const uint8_t* __restrict__ src, const mbx_patch_item* __restrict__ items, int S,
+                       float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * kThreads + threadIdx.x;
+  if (pix >= S * S) return;
+  const mbx_patch_item it = items[b];
+  const int oy = pix / S, ox = pix - oy * S;
+  const int H = it.win_h, W = it.win_w;
+  const uint8_t* p = src + it.src_offset;
+  const float sy = (float)((double)H / (double)S), sx = (float)((double)W / (double)S);
+  const float ys = __fmul_rn((float)oy, sy), xs = __fmul_rn((float)ox, sx);
+  const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float yl = __fsub_rn(ys, (float)y0), xl = __fsub_rn(xs, (float)x0);
+  const int gy0 = it.win_y + y0, gy1 = it.win_y + y1;
+  int gx0 = it.win_x + x0, gx1 = it.win_x + x1;
+  if (it.flip_source) { gx0 = it.img_w - 1 - gx0; gx1 = it.img_w - 1 - gx1; }      // image[:, ::-1]
+  float* o = out + ((size_t)b * S * S + pix) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto px = [&](int y, int x) {                                                  // (image - 0.5) * 2, detect.py:181-182
+      return __fmul_rn(__fsub_rn(src_px(p, it.img_w, y, x, c), 0.5f), 2.0f);
+    };
+    const float tl = px(gy0, gx0), tr = px(gy0, gx1), bl = px(gy1, gx0), br = px(gy1, gx1);
+    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), xl));
+    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), xl));
+    o[c] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), yl));
+  }
+}
+
 }  // namespace
+
+extern "C" int mbx_extract_patches(const uint8_t* src, const mbx_patch_item* items, int n, int S, float* out,
+                                   mbx_stream_t stream) {
+  if (n < 0 || S <= 0 || n > 65535) return MBX_ERR_INVALID_ARG;
+  if (n == 0) return MBX_OK;
+  if (!src || !items || !out) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(extract_patches_kernel, dim3((S * S + kThreads - 1) / kThreads, n), dim3(kThreads), 0, mbx_s(stream),
+                     src, items, S, out);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
 
 extern "C" size_t mbx_augment_workspace_bytes(int B, int S) {
   if (B <= 0 || S <= 0) return 0;

@@ -225,7 +225,8 @@ class DevicePrefetcher:
         self.q = queue.Queue(maxsize=self.depth)
         self.free = queue.Queue()
         for i in range(self.depth + 1):
-            self.free.put(i)
+            self.free.put((i, None))
+        self.copied = [None] * (self.depth + 1)                 # per buffer set: event after its last upload
         self.err = None
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
@@ -234,9 +235,12 @@ class DevicePrefetcher:
         torch = self.torch
         try:
             while True:
-                i = self.free.get()
-                if i is None:
+                item = self.free.get()
+                if item is None:
                     return
+                i, consumed = item
+                if self.copied[i] is not None:
+                    self.copied[i].synchronize()                # the pinned staging of set i is no longer being read
                 if self.augment:
                     hbb, hn = self.host[i]
                     bb, nn, ids = self.src.next_into(self.augs[i])
@@ -252,12 +256,15 @@ class DevicePrefetcher:
                 ev = None
                 if self.stream is not None:
                     with torch.cuda.stream(self.stream):
+                        if consumed is not None:
+                            self.stream.wait_event(consumed)    # the consumer's reads of set i's device buffers are done
                         if self.augment:
                             self.augs[i].run()                  # H2D of the pixels + the kernels, on the side stream
                         for h, d in zip(self.host[i], self.devb[i][-len(self.host[i]):]):
                             d.copy_(h, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
+                    self.copied[i] = ev
                 else:
                     for h, d in zip(self.host[i], self.devb[i][-len(self.host[i]):]):
                         d.copy_(h)
@@ -280,7 +287,13 @@ class DevicePrefetcher:
         if ev is not None:
             self.torch.cuda.current_stream().wait_event(ev)
         if getattr(self, "_last", None) is not None:
-            self.free.put(self._last)                           # the batch handed out before this one has been consumed
+            # the batch handed out before this one has been consumed -- by work ENQUEUED on the current stream, which the
+            # GPU may not have run yet (the host runs ahead of a graph-replayed step): the refill waits for this event
+            consumed = None
+            if ev is not None:
+                consumed = self.torch.cuda.Event()
+                consumed.record(self.torch.cuda.current_stream())
+            self.free.put((self._last, consumed))
         self._last = i
         return self.devb[i] + (ids,)
 

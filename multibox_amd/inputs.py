@@ -63,49 +63,115 @@ def _records(tfrecords):
             yield tfrecord.parse_example(payload)
 
 
-def detect_patches_for_image(image01, image_hw, cfg):
-    """All patches + metadata of ONE image (detect.py:183-281).  image01: decoded [H,W,3] in [0,1]."""
-    S = int(cfg.INPUT_SIZE)
+def patch_windows(H, W, patch_dims, strides, non_edge_restriction=0.1):
+    """The geometry of detect.extract_patches (detect.py:20-72) without the pixels: [(y, x)...] offsets and the
+    restriction rows, in its order (tests/test_inputs_cpu.py holds it against extract_patches)."""
+    ph, pw = int(patch_dims[0]), int(patch_dims[1])
+    offs, res = [], []
+    for h in range(0, H - ph + 1, int(strides[0])):
+        for w in range(0, W - pw + 1, int(strides[1])):
+            offs.append((h, w))
+            res.append((0.0 if w == 0 else non_edge_restriction, 0.0 if h == 0 else non_edge_restriction,
+                        1.0 if w + pw == W else 1.0 - non_edge_restriction,
+                        1.0 if h + ph == H else 1.0 - non_edge_restriction))
+    return offs, np.array(res, np.float32).reshape(-1, 4)
+
+
+def detect_patch_plan(H, W, image_hw, cfg):
+    """Every patch of ONE decoded H x W image (detect.py:183-281) as geometry: a list of
+    (window (y, x, h, w), flip_source, offset (y, x), dims (h, w), is_flipped, restrictions, max_to_keep); the pixels of
+    patch i are resize_bilinear(((image - 0.5) * 2)[:, ::-1 if flip_source][window], S, S)."""
     det = cfg.DETECTION
+    plan = []
+    if det.get("USE_ORIGINAL_IMAGE", False):
+        plan.append(((0, 0, H, W), 0, (0, 0), tuple(image_hw), 0, (0., 0., 1., 1.), int(det.ORIGINAL_IMAGE_MAX_TO_KEEP)))
+    if det.get("USE_FLIPPED_ORIGINAL_IMAGE", False):
+        plan.append(((0, 0, H, W), 1, (0, 0), tuple(image_hw), 1, (0., 0., 1., 1.), int(det.FLIPPED_IMAGE_MAX_TO_KEEP)))
+    for crop in det.get("CROPS", None) or []:
+        offs, res = patch_windows(H, W, (crop.HEIGHT, crop.WIDTH), (crop.HEIGHT_STRIDE, crop.WIDTH_STRIDE))
+        f = 1 if crop.FLIP else 0
+        for (y, x), r in zip(offs, res):
+            plan.append(((y, x, int(crop.HEIGHT), int(crop.WIDTH)), f, (y, x), (int(crop.HEIGHT), int(crop.WIDTH)), f,
+                         tuple(float(v) for v in r), int(crop.MAX_TO_KEEP)))
+    return plan
+
+
+def detect_patches_for_image(image01, image_hw, cfg):
+    """All patches + metadata of ONE image (detect.py:183-281) on the host.  image01: decoded [H,W,3] in [0,1]."""
+    S = int(cfg.INPUT_SIZE)
     image = (image01 - np.float32(0.5)) * np.float32(2.0)            # detect.py:181-182
     flipped = image[:, ::-1]
     patches, offs, dims, flips, rests, keeps = [], [], [], [], [], []
-
-    def add(p, o, d, f, r, k):
-        patches.append(p); offs.append(o); dims.append(d); flips.append(f); rests.append(r); keeps.append(k)
-    if det.get("USE_ORIGINAL_IMAGE", False):
-        add(resize_bilinear_tf(image, S, S), (0, 0), tuple(image_hw), 0, (0., 0., 1., 1.), int(det.ORIGINAL_IMAGE_MAX_TO_KEEP))
-    if det.get("USE_FLIPPED_ORIGINAL_IMAGE", False):
-        add(resize_bilinear_tf(flipped, S, S), (0, 0), tuple(image_hw), 1, (0., 0., 1., 1.), int(det.FLIPPED_IMAGE_MAX_TO_KEEP))
-    for crop in det.get("CROPS", None) or []:
-        src = flipped if crop.FLIP else image
-        cp, co, cr, n = extract_patches(src, (crop.HEIGHT, crop.WIDTH), (crop.HEIGHT_STRIDE, crop.WIDTH_STRIDE))
-        for i in range(int(n)):
-            add(resize_bilinear_tf(cp[i], S, S), tuple(co[i]), (crop.HEIGHT, crop.WIDTH), 1 if crop.FLIP else 0,
-                tuple(cr[i]), int(crop.MAX_TO_KEEP))
+    for (y, x, h, w), fs, o, d, f, r, k in detect_patch_plan(image.shape[0], image.shape[1], image_hw, cfg):
+        patches.append(resize_bilinear_tf((flipped if fs else image)[y:y + h, x:x + w], S, S))
+        offs.append(o); dims.append(d); flips.append(f); rests.append(r); keeps.append(k)
     return patches, offs, dims, flips, rests, keeps
 
 
-def detect_batches(tfrecords, cfg, batch_size, keep_partial=False):
+def _decoded_ahead(examples, threads, window=32):
+    """(example, decoded uint8 image) in record order, the JPEG decodes running `threads` at a time ahead of the
+    consumer (PIL releases the GIL while it decodes)."""
+    if threads <= 1:
+        for ex in examples:
+            yield ex, decode_image_u8(ex["image/encoded"][0])
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        pending = deque()
+        for ex in examples:
+            pending.append((ex, pool.submit(decode_image_u8, ex["image/encoded"][0])))
+            if len(pending) >= window:
+                e, f = pending.popleft()
+                yield e, f.result()
+        while pending:
+            e, f = pending.popleft()
+            yield e, f.result()
+
+
+def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patches=False, decode_threads=None):
     """Yield dicts of numpy arrays: images [B,S,S,3], offsets [B,2], dims [B,2], is_flipped [B,1],
-    restrictions [B,4], max_to_keep [B,1], image_hw [B,2], image_ids [B] -- the fetches of detect.py:398-406."""
+    restrictions [B,4], max_to_keep [B,1], image_hw [B,2], image_ids [B] -- the fetches of detect.py:398-406.
+    device_patches=True leaves the pixels to the GPU (mbx_extract_patches): instead of "images" a batch carries
+    "sources" (the decoded uint8 images it touches) and "patches" [(source index, window, flip_source) or None for
+    padding]: multibox_amd.augment.PatchExtractor turns them into the [B,S,S,3] tensor on the device.  The JPEGs are
+    then decoded by decode_threads threads (default NUM_INPUT_THREADS) ahead of the consumer, in record order."""
     buf = {k: [] for k in ("images", "offsets", "dims", "is_flipped", "restrictions", "max_to_keep", "image_hw", "image_ids")}
+    S = int(cfg.INPUT_SIZE)
 
     def emit():
-        out = dict(images=np.stack(buf["images"][:batch_size]).astype(np.float32),
-                   offsets=np.array(buf["offsets"][:batch_size], np.int32), dims=np.array(buf["dims"][:batch_size], np.int32),
+        out = dict(offsets=np.array(buf["offsets"][:batch_size], np.int32), dims=np.array(buf["dims"][:batch_size], np.int32),
                    is_flipped=np.array(buf["is_flipped"][:batch_size], np.int32).reshape(-1, 1),
                    restrictions=np.array(buf["restrictions"][:batch_size], np.float32),
                    max_to_keep=np.array(buf["max_to_keep"][:batch_size], np.int32).reshape(-1, 1),
                    image_hw=np.array(buf["image_hw"][:batch_size], np.int32), image_ids=list(buf["image_ids"][:batch_size]))
+        if device_patches:
+            sources, index, patches = [], {}, []
+            for item in buf["images"][:batch_size]:
+                if item is None:
+                    patches.append(None)
+                    continue
+                u8, window, fs = item
+                if id(u8) not in index:
+                    index[id(u8)] = len(sources)
+                    sources.append(u8)
+                patches.append((index[id(u8)], window, fs))
+            out["sources"], out["patches"] = sources, patches
+        else:
+            out["images"] = np.stack(buf["images"][:batch_size]).astype(np.float32)
         for k in buf:
             del buf[k][:batch_size]
         return out
-    for ex in _records(tfrecords):
-        img = decode_image(ex["image/encoded"][0])
+    threads = int(decode_threads if decode_threads is not None else cfg.get("NUM_INPUT_THREADS", 4)) if device_patches else 1
+    for ex, u8 in (_decoded_ahead(_records(tfrecords), threads) if device_patches else ((e, None) for e in _records(tfrecords))):
         hw = (int(ex["image/height"][0]), int(ex["image/width"][0]))
         image_id = ex["image/id"][0].decode("utf-8")
-        p, o, d, f, r, k = detect_patches_for_image(img, hw, cfg)
+        if device_patches:
+            plan = detect_patch_plan(u8.shape[0], u8.shape[1], hw, cfg)
+            p = [(u8, win, fs) for win, fs, _, _, _, _, _ in plan]
+            o, d, f, r, k = ([e[i] for e in plan] for i in (2, 3, 4, 5, 6))
+        else:
+            p, o, d, f, r, k = detect_patches_for_image(decode_image(ex["image/encoded"][0]), hw, cfg)
         buf["images"] += p; buf["offsets"] += o; buf["dims"] += d; buf["is_flipped"] += f
         buf["restrictions"] += r; buf["max_to_keep"] += k
         buf["image_hw"] += [hw] * len(p); buf["image_ids"] += [image_id] * len(p)
@@ -114,8 +180,7 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False):
     if keep_partial and buf["images"]:
         n = len(buf["images"])
         pad = batch_size - n
-        S = int(cfg.INPUT_SIZE)
-        buf["images"] += [np.zeros((S, S, 3), np.float32)] * pad
+        buf["images"] += [None if device_patches else np.zeros((S, S, 3), np.float32)] * pad
         buf["offsets"] += [(0, 0)] * pad; buf["dims"] += [(S, S)] * pad; buf["is_flipped"] += [0] * pad
         buf["restrictions"] += [(0., 0., 1., 1.)] * pad; buf["max_to_keep"] += [0] * pad      # keep nothing of the padding
         buf["image_hw"] += [(S, S)] * pad; buf["image_ids"] += [buf["image_ids"][-1]] * pad
@@ -469,11 +534,12 @@ def train_batches(tfrecords, cfg, batch_size, max_num_bboxes, num_epochs=None, s
             imgs, boxes, nums, ids = [], [], [], []
 
 
-def eval_batches(tfrecords, cfg, batch_size, max_num_bboxes):
+def eval_batches(tfrecords, cfg, batch_size, max_num_bboxes, device_images=False):
     """eval_inputs.input_nodes (eval_inputs.py:20-115): one epoch, no augmentation -- decode, legacy bilinear resize to
     INPUT_SIZE, boxes and their original-image areas ('image/object/area') padded to MAX_NUM_BBOXES, [-1,1] scaling;
     the incomplete last batch is dropped like tf.train.(shuffle_)batch at the end of the epoch.
-    Yields (images [B,S,S,3], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B], areas [B,G], image_ids)."""
+    Yields (images [B,S,S,3], bboxes [B,G,4] x1,y1,x2,y2, num_bboxes [B], areas [B,G], image_ids); with device_images
+    the first element is the list of decoded uint8 images instead (resize + scaling then run on the GPU)."""
     S = int(cfg.INPUT_SIZE)
     imgs, boxes, nums, areas, ids = [], [], [], [], []
     for ex in _records(tfrecords):
@@ -486,9 +552,13 @@ def eval_batches(tfrecords, cfg, batch_size, max_num_bboxes):
                                f("image/object/bbox/ymax")], 1)
             a = f("image/object/area")
             ar[:len(a)] = a
-        img = resize_bilinear_tf(decode_image(ex["image/encoded"][0]), S, S)
-        imgs.append((img - np.float32(0.5)) * np.float32(2.0))
+        if device_images:                                   # the GPU resizes and scales (augment.BatchAugmenter, method 0)
+            imgs.append(decode_image_u8(ex["image/encoded"][0]))
+        else:
+            img = resize_bilinear_tf(decode_image(ex["image/encoded"][0]), S, S)
+            imgs.append((img - np.float32(0.5)) * np.float32(2.0))
         boxes.append(bb); nums.append(n); areas.append(ar); ids.append(ex["image/id"][0].decode("utf-8"))
         if len(imgs) == batch_size:
-            yield np.stack(imgs).astype(np.float32), np.stack(boxes), np.array(nums, np.int32), np.stack(areas), ids
+            yield (imgs if device_images else np.stack(imgs).astype(np.float32)), np.stack(boxes), np.array(nums, np.int32), \
+                np.stack(areas), ids
             imgs, boxes, nums, areas, ids = [], [], [], [], []

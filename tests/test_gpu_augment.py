@@ -144,3 +144,54 @@ def test_worker_ring_to_device_batches_match_the_host_pipeline(tmp_path):
     for (a, b, n, ids), (ra, rb, rn, rids) in zip(got, ref):
         assert ids == rids and np.array_equal(b, rb) and np.array_equal(n, rn)
         np.testing.assert_allclose(a, ra, rtol=0, atol=1e-6)
+
+
+def test_detect_patches_on_the_device_are_bit_identical_to_the_host_input(tmp_path):
+    """mbx_extract_patches behind augment.PatchExtractor against inputs.detect_batches (detect.py:181-281: scale to
+    [-1,1], mirror, sliding windows, legacy bilinear resize): bit-identical pictures, padding entries all zero."""
+    import torch
+    from multibox_amd import inputs as I
+    from multibox_amd.augment import PatchExtractor
+    from multibox_amd.config import Cfg
+    from tests.test_inputs_cpu import _make_records
+    path = str(tmp_path / "d.tfrecords")
+    _make_records(path, [(320, 420, []), (300, 300, []), (412, 500, []), (640, 480, [])])
+    cfg = Cfg(dict(INPUT_SIZE=299, DETECTION=dict(
+        USE_ORIGINAL_IMAGE=True, ORIGINAL_IMAGE_MAX_TO_KEEP=200, USE_FLIPPED_ORIGINAL_IMAGE=True, FLIPPED_IMAGE_MAX_TO_KEEP=100,
+        CROPS=[dict(HEIGHT=299, WIDTH=299, HEIGHT_STRIDE=113, WIDTH_STRIDE=113, FLIP=False, MAX_TO_KEEP=50),
+               dict(HEIGHT=250, WIDTH=280, HEIGHT_STRIDE=60, WIDTH_STRIDE=90, FLIP=True, MAX_TO_KEEP=40)])))
+    B = 8
+    host = list(I.detect_batches([path], cfg, B, keep_partial=True))
+    dev = list(I.detect_batches([path], cfg, B, keep_partial=True, device_patches=True))
+    ex = PatchExtractor(B, 299, capacity_bytes=1 << 20)         # small: the first big batch makes it grow
+    assert len(host) == len(dev) >= 4
+    for hb, db in zip(host, dev):
+        got = ex(db["sources"], db["patches"])
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), hb["images"])
+    with pytest.raises(ValueError):
+        ex(db["sources"], [(0, (0, 0, 10 ** 6, 10), 0)] * B)
+
+
+def test_eval_images_on_the_device_are_bit_identical_to_the_host_input(tmp_path):
+    """eval_inputs.py:20-115 (decode, legacy bilinear resize, [-1,1]) through BatchAugmenter method 0."""
+    import torch
+    from multibox_amd import inputs as I
+    from multibox_amd.augment import BatchAugmenter
+    from multibox_amd.config import Cfg
+    from tests.test_inputs_cpu import _make_records
+    path = str(tmp_path / "e.tfrecords")
+    _make_records(path, [(320 + 30 * i, 420 - 25 * i, [[.1, .2, .5, .6]]) for i in range(6)])
+    cfg = Cfg(dict(INPUT_SIZE=299))
+    host = list(I.eval_batches([path], cfg, 3, 5))
+    dev = list(I.eval_batches([path], cfg, 3, 5, device_images=True))
+    aug = BatchAugmenter(3, 299, slot_bytes=1 << 16)            # too small on purpose: add() grows the staging
+    assert len(host) == len(dev) == 2
+    for (hi, hb, hn, ha, hids), (di, db, dn, da, dids) in zip(host, dev):
+        aug.begin()
+        for u8 in di:
+            aug.add(u8, 0, False, [])
+        got = aug.run()
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), hi)
+        assert np.array_equal(hb, db) and np.array_equal(hn, dn) and np.array_equal(ha, da) and hids == dids

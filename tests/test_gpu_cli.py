@@ -129,8 +129,10 @@ DETECTION :""".replace("ON_DEVICE", on_device)))
     assert "saved" in r.stdout
 
 
-def test_detect_from_tfrecords(tmp_path):
-    """detect.py --tfrecords: the reference's multi-crop input (detect.py:134-292) end to end on three JPEG images."""
+@pytest.mark.parametrize("on_device", ["true", "false"])
+def test_detect_from_tfrecords(tmp_path, on_device):
+    """detect.py --tfrecords: the reference's multi-crop input (detect.py:134-292) end to end on three JPEG images, the
+    patches cut and resized on the GPU (mbx_extract_patches) or on the host."""
     import __graft_entry__ as g
     g.build()
     import torch
@@ -139,7 +141,7 @@ def test_detect_from_tfrecords(tmp_path):
     from multibox_amd.trainer import Trainer
     from tests.test_inputs_cpu import _make_records
     cfg = tmp_path / "config.yaml"
-    cfg.write_text(CFG + """  USE_FLIPPED_ORIGINAL_IMAGE : true
+    cfg.write_text(CFG.replace("DETECTION :", "INPUT_AUGMENT_ON_DEVICE : %s\nDETECTION :" % on_device) + """  USE_FLIPPED_ORIGINAL_IMAGE : true
   FLIPPED_IMAGE_MAX_TO_KEEP : 100
   CROPS :
     - HEIGHT : 299

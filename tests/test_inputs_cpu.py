@@ -283,3 +283,41 @@ def test_device_augment_workers_hand_over_the_same_plans(tmp_path):
             next(src)
         src.close()
         assert (fin.prepared > 0) == want_prepared
+
+
+def test_detect_patch_geometry_matches_extract_patches(tmp_path):
+    """inputs.patch_windows is the geometry of detect.extract_patches (detect.py:20-72, pinned to the reference's goldens);
+    detect_batches(device_patches=True) carries the same metadata as the host batches, with windows instead of pixels."""
+    from multibox_amd.detect import extract_patches
+    rng = np.random.RandomState(0)
+    for (H, W, ph, pw, sh, sw) in [(480, 640, 299, 299, 113, 113), (300, 300, 299, 299, 50, 50), (412, 500, 200, 350, 71, 150),
+                                   (100, 100, 200, 200, 10, 10)]:
+        img = rng.rand(H, W, 3).astype(np.float32)
+        patches, offs, res, n = extract_patches(img, (ph, pw), (sh, sw))
+        o2, r2 = I.patch_windows(H, W, (ph, pw), (sh, sw))
+        assert len(o2) == int(n) and np.array_equal(np.array(o2, np.int32).reshape(-1, 2), offs) and np.array_equal(r2, res)
+        for (y, x), p in zip(o2, patches):
+            assert np.array_equal(img[y:y + ph, x:x + pw], p)
+    path = str(tmp_path / "d.tfrecords")
+    _make_records(path, [(320, 420, []), (300, 300, []), (412, 412, [])])
+    cfg = Cfg(dict(INPUT_SIZE=299, DETECTION=dict(
+        USE_ORIGINAL_IMAGE=True, ORIGINAL_IMAGE_MAX_TO_KEEP=200, USE_FLIPPED_ORIGINAL_IMAGE=True, FLIPPED_IMAGE_MAX_TO_KEEP=100,
+        CROPS=[dict(HEIGHT=299, WIDTH=299, HEIGHT_STRIDE=113, WIDTH_STRIDE=113, FLIP=False, MAX_TO_KEEP=50),
+               dict(HEIGHT=250, WIDTH=280, HEIGHT_STRIDE=60, WIDTH_STRIDE=90, FLIP=True, MAX_TO_KEEP=40)])))
+    host = list(I.detect_batches([path], cfg, 5, keep_partial=True))
+    dev = list(I.detect_batches([path], cfg, 5, keep_partial=True, device_patches=True))
+    assert len(host) == len(dev) > 2
+    for hb, db in zip(host, dev):
+        for k in ("offsets", "dims", "is_flipped", "restrictions", "max_to_keep", "image_hw"):
+            assert np.array_equal(hb[k], db[k])
+        assert hb["image_ids"] == db["image_ids"] and "images" not in db and len(db["patches"]) == 5
+        # finishing the windows on the host reproduces the host batch
+        for i, p in enumerate(db["patches"]):
+            if p is None:
+                assert not hb["images"][i].any() and int(db["max_to_keep"][i, 0]) == 0
+                continue
+            si, (y, x, h, w), fs = p
+            src = (db["sources"][si].astype(np.float32) * np.float32(1 / 255.) - np.float32(0.5)) * np.float32(2.0)
+            src = src[:, ::-1] if fs else src
+            assert np.array_equal(I.resize_bilinear_tf(src[y:y + h, x:x + w], 299, 299), hb["images"][i])
+    assert any(p is None for p in dev[-1]["patches"])
