@@ -87,11 +87,14 @@ class DetectPostprocess:
 
 def results_to_json_records(boxes, scores, count, image_ids):
     """detect.py:438-443: list of {"image_id", "bbox", "score"} in patch order."""
-    boxes, scores, count = boxes.cpu().numpy(), scores.cpu().numpy(), count.cpu().numpy()
+    as_np = lambda t: t if isinstance(t, np.ndarray) else t.cpu().numpy()
+    boxes, scores, count = as_np(boxes), as_np(scores), as_np(count)
     out = []
     for b in range(boxes.shape[0]):
-        for k in range(int(count[b])):
-            out.append({"image_id": image_ids[b], "bbox": boxes[b, k].tolist(), "score": float(scores[b, k])})
+        n = int(count[b])
+        image_id = image_ids[b]
+        out.extend({"image_id": image_id, "bbox": bb, "score": sc}
+                   for bb, sc in zip(boxes[b, :n].tolist(), scores[b, :n].tolist()))
     return out
 
 
