@@ -1,6 +1,9 @@
 // libmbx: conv_igemm5_kernel -- the persistent, loader / compute specialised implicit-GEMM convolution (round 2) -- and
 // its launcher.  Separate translation unit so that it compiles beside conv.hip.
 #include "conv_common.h"
+#ifndef MBX_I5_NST4
+#define MBX_I5_NST4 4
+#endif
 
 namespace {
 
@@ -28,8 +31,11 @@ struct Ig5 {
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   static constexpr int STAGE = (BM + BN) * 8;                       // 16-byte slots per ring stage
-  static constexpr int NST = 3;
   static constexpr int LDT = BN + 4;                                // floats per staged row
+  // ring depth: the loaders run NST - 1 K steps ahead.  Four stages where they fit beside a 16-row epilogue window
+  // (128x64, 128x128): the K loop is paced by the landing of the operand tiles (0.5 us per 32 KB step measured with
+  // timestamps inside the kernel, whatever the compute waves do), i.e. by the bytes in flight against the latency.
+  static constexpr int NST = (4 * STAGE * 16 + 16 * LDT * 4 <= 160 * 1024 - 64) ? MBX_I5_NST4 : 3;
   static constexpr int RING_BYTES = NST * STAGE * 16;
   static constexpr int CR = (RING_BYTES + 64 * LDT * 4 <= 160 * 1024 - 64) ? 64 : (RING_BYTES + 32 * LDT * 4 <= 160 * 1024 - 64) ? 32 : 16;
   static constexpr int EP_BYTES = CR * LDT * 4;
@@ -119,14 +125,19 @@ conv_igemm5_kernel(const ConvK p) {
     if (t_i < ntiles) {
       MBX5_SETUP_TILE();
       MBX5_ISSUE();                                                 // global step 0
-      if (t_i < ntiles) { MBX5_ISSUE(); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
+      bool full = true;
+#pragma unroll
+      for (int a = 1; a < NST - 1; ++a) {
+        if (t_i < ntiles) MBX5_ISSUE(); else full = false;
+      }
+      if (full) wait_vmcnt<(NST - 2) * NL>(); else wait_vmcnt<0>();
     }
     raw_barrier();                                                  // step 0 has landed
     for (int t = first; t < ntiles; t += gridDim.x) {
       for (int it = 0; it < nk; ++it) {
         const bool more = t_i < ntiles;                             // anything left to issue (this or a later tile)?
         if (more) MBX5_ISSUE();
-        if (more) wait_vmcnt<NL>(); else wait_vmcnt<0>();           // the NEXT step has landed (this wave's share)
+        if (more) wait_vmcnt<(NST - 2) * NL>(); else wait_vmcnt<0>();   // the NEXT step has landed (this wave's share)
         raw_barrier();
       }
 #pragma unroll 1
@@ -193,6 +204,35 @@ conv_igemm5_kernel(const ConvK p) {
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // The epilogue's global READS (residual skip / accumulate source / relu mask) are issued PFB passes ahead, the first
+    // batch before the first window is staged.  Loaded pass by pass each exposed a memory latency with one block per CU
+    // and nothing to overlap it (timestamps inside the kernel, 128x128 tile of block17's 1x1: epilogue 4.2 us with the
+    // residual read against 1.2 us for a plain store, the K loop 3.0 us).
+    constexpr int NQ = NCHUNK * NPASS;                              // passes of a tile, window after window
+    constexpr int PFW = (EV == 2 && MI * NI >= 12) ? 2 : 4;         // two reads per pass + 48-64 accumulators: stay under 128 VGPRs
+    constexpr int PFB = NQ < PFW ? NQ : PFW;
+    constexpr bool PRE = (EV == 2 || EV == 4);
+    int yoff[PFB];
+    u32x4 pre_a[PFB], pre_b[PFB];
+    auto prefetch = [&](int q0) {
+#pragma unroll
+      for (int i = 0; i < PFB; ++i) {
+        const int q = q0 + i;
+        const int m = m0 + (q / NPASS) * CR + (q % NPASS) * RP + r0;
+        yoff[i] = -1;
+        if (q < NQ && r0 < RP && m < p.M && cok) {
+          const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+          yoff[i] = img * p.y_img_stride + pix * p.ldy + c0;
+          if constexpr (EV == 4) {
+            pre_a[i] = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+          } else if constexpr (EV == 2) {
+            if (p.accumulate) pre_a[i] = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
+            if (p.skip) pre_b[i] = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
+          }
+        }
+      }
+    };
+    if constexpr (PRE) prefetch(0);
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
       // the accumulator blocks whose rows fall into this window (compile-time block index, run-time predicate)
@@ -209,19 +249,18 @@ conv_igemm5_kernel(const ConvK p) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int wrow = ps * RP + r0;                              // row inside the window
-        const int m = m0 + ch * CR + wrow;
-        if (r0 < RP && m < p.M && cok) {
-          const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
+        const int q = ch * NPASS + ps, qi = q % PFB;
+        if (q % PFB == 0 && (!PRE || q > 0)) prefetch(q);           // next batch (the first one is already in flight)
+        if (yoff[qi] >= 0) {
           const f32x4 t0 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8);
           const f32x4 t1 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8 + 4);
           float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-          unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + img * p.y_img_stride + pix * p.ldy + c0;
+          unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yoff[qi];
           if constexpr (EV == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
           } else if constexpr (EV == 4) {
-            const u32x4 sk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-            const unsigned w[4] = {sk.x, sk.y, sk.z, sk.w};
+            const unsigned w[4] = {pre_a[qi].x, pre_a[qi].y, pre_a[qi].z, pre_a[qi].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[2 * j]);
@@ -235,14 +274,12 @@ conv_igemm5_kernel(const ConvK p) {
           }
           if constexpr (EV == 2) {
             if (p.accumulate) {
-              const u32x4 old = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
-              const unsigned w[4] = {old.x, old.y, old.z, old.w};
+              const unsigned w[4] = {pre_a[qi].x, pre_a[qi].y, pre_a[qi].z, pre_a[qi].w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
             }
             if (p.skip) {                      // relu backward of the tensor this gradient belongs to
-              const u32x4 mk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-              const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
+              const unsigned w[4] = {pre_b[qi].x, pre_b[qi].y, pre_b[qi].z, pre_b[qi].w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
