@@ -26,6 +26,7 @@ SOURCES = {
     "augment.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("MBX_BUILD_DEFS", "").split()      # debug builds, e.g. -DMBX_I5_STAMPS (tools/i5_stamps.py); rebuild with force
 
 
 def _hipcc():

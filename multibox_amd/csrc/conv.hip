@@ -1177,6 +1177,14 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
   k.skip_taps = 0; k.parity = 0;
+#ifdef MBX_I5_STAMPS
+  {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
+    static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
+    k.stamps = reinterpret_cast<unsigned long long*>(sp);
+    static const int dbg5 = getenv("MBX_I5_DBG") ? atoi(getenv("MBX_I5_DBG")) : 0;
+    k.dbg = dbg5;
+  }
+#endif
   for (int c = 0; c < 4; ++c) { k.cls_m0[c] = 0; k.cls_hw[c] = 1; k.cls_w[c] = 1; }
   static int notap = -1;
   if (notap < 0) { const char* e = getenv("MBX_NO_TAP_SKIP"); notap = (e && e[0] == '1') ? 1 : 0; }

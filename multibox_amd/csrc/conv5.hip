@@ -137,6 +137,9 @@ conv_igemm5_kernel(const ConvK p) {
       for (int it = 0; it < nk; ++it) {
         const bool more = t_i < ntiles;                             // anything left to issue (this or a later tile)?
         if (more) MBX5_ISSUE();
+#ifdef MBX_I5_STAMPS
+        if (p.dbg & 2) { raw_barrier(); continue; }                 // timing probe: do not wait for the landing (wrong results)
+#endif
         if (more) wait_vmcnt<(NST - 2) * NL>(); else wait_vmcnt<0>();   // the NEXT step has landed (this wave's share)
         raw_barrier();
       }
@@ -159,12 +162,23 @@ conv_igemm5_kernel(const ConvK p) {
   for (int t = first; t < ntiles; t += gridDim.x) {
     const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+#ifdef MBX_I5_STAMPS
+    const int tnum = (t - first) / (int)gridDim.x;
+    const bool stamp = p.stamps && tid == 0 && tnum < 8 && blockIdx.x < 64;
+#define MBX5_STAMP(i) do { if (stamp) p.stamps[(blockIdx.x * 8 + tnum) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define MBX5_STAMP(i) do { } while (0)
+#endif
+    MBX5_STAMP(0);                                                  // tile start
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
       for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < nk; ++it) {
+#ifdef MBX_I5_STAMPS
+      if (p.dbg & 1) { st_comp = st_comp == NST - 1 ? 0 : st_comp + 1; raw_barrier(); continue; }   // timing probe: compute waves idle
+#endif
       const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
       const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
@@ -185,6 +199,7 @@ conv_igemm5_kernel(const ConvK p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS reads are done before the stage is reused
       raw_barrier();
     }
+    MBX5_STAMP(1);                                                  // K loop done
     // ---------------------------------------------------------------- epilogue: CR rows at a time through `ep`
     const int cg = tid % TPR, r0 = tid / TPR;                       // this thread's 8-channel group and row inside a pass
     const int c0 = n0 + cg * 8;
@@ -305,6 +320,7 @@ conv_igemm5_kernel(const ConvK p) {
       }
       lds_barrier();
     }
+    MBX5_STAMP(2);                                                  // rows written
     if constexpr (EV == 1) {
       // batch-norm statistics partials of this tile: per-thread sums over its rows -> over the row groups of a wave
       // (lanes TPR apart share a channel group; fixed order) -> over the 8 waves through the window
@@ -332,6 +348,7 @@ conv_igemm5_kernel(const ConvK p) {
       }
       lds_barrier();
     }
+#undef MBX5_STAMP
   }
 }
 

@@ -34,6 +34,10 @@ struct ConvK {
   int cls_m0[4], cls_hw[4], cls_w[4];  // first pixel index, pixels per image (Hc * Wc) and row length Wc per class
   int skip_taps;                       // C_in % 64 == 0: K tiles never straddle taps, whole taps can be skipped
   int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
+#ifdef MBX_I5_STAMPS
+  unsigned long long* stamps;          // debug build: wall_clock64() per tile phase of the first 8 tiles of 64 blocks
+  int dbg;                             // debug build: MBX_I5_DBG timing probes (bit 0: compute waves idle, bit 1: loaders do not wait)
+#endif
 };
 
 constexpr int kThreads = 256;

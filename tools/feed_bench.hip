@@ -22,7 +22,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // region: bytes every XCD's workgroups cycle through (L2 resident); all sizes in bytes
 template <int MODE, int DEPTH, int G>
 __global__ void __launch_bounds__(1024)
-feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, unsigned* __restrict__ sink) {
+feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, unsigned* __restrict__ sink, int pat, int row_stride) {
   extern __shared__ u32x4 lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const unsigned xcd = blockIdx.x & 7;
@@ -30,6 +30,11 @@ feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, u
   // every wave walks the region in 1 KB steps from its own start, wrapping
   unsigned pos = (unsigned)(((unsigned long long)((blockIdx.x >> 3) * waves + wave) * (region / 512u)) % region) & ~1023u;
   unsigned acc = 0;
+  // lane -> byte offset inside one wave-level load: 8 rows x 128 B (the conv tiles' shape); pat bit 0 = the XOR chunk
+  // swizzle of the LDS image applied on the source, row_stride = bytes between rows (128 = contiguous 1 KB)
+  const int lrow = lane >> 3, lchunk = (pat & 1) ? ((lane & 7) ^ (lrow & 7)) : (lane & 7);
+  const unsigned loff = (unsigned)(lrow * row_stride + lchunk * 16);
+  const unsigned adv = (unsigned)(8 * row_stride);
   constexpr int kStage = G * 64;                               // u32x4 per wave per stage
   if constexpr (MODE == 0) {
     u32x4* ring = lds + (size_t)wave * DEPTH * kStage;
@@ -38,8 +43,8 @@ feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, u
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(ring + stage * kStage + g * 64), 16,
-                                                 pos + lane * 16, 0, 0, 0);
-        pos += 1024; if (pos >= region) pos -= region;
+                                                 pos + loff, 0, 0, 0);
+        pos += adv; if (pos + adv >= region) pos = 0;
       }
     };
 #pragma unroll
@@ -59,8 +64,8 @@ feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, u
     auto issue = [&](int stage) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        regs[stage][g] = *reinterpret_cast<const u32x4*>(base + pos + lane * 16);
-        pos += 1024; if (pos >= region) pos -= region;
+        regs[stage][g] = *reinterpret_cast<const u32x4*>(base + pos + loff);
+        pos += adv; if (pos + adv >= region) pos = 0;
       }
     };
 #pragma unroll
@@ -81,7 +86,7 @@ feed_kernel(const unsigned char* __restrict__ src, unsigned region, int iters, u
 }
 
 template <int MODE, int DEPTH, int G>
-static void run(const unsigned char* src, unsigned region, unsigned* sink, int waves, int blocks) {
+static void run(const unsigned char* src, unsigned region, unsigned* sink, int waves, int blocks, int pat = 0, int row_stride = 128) {
   const int iters = 4096 / G / DEPTH * DEPTH;
   const size_t lds = (size_t)waves * (MODE == 0 ? DEPTH : 2) * G * 1024;
   if (lds > 160 * 1024) return;
@@ -90,7 +95,7 @@ static void run(const unsigned char* src, unsigned region, unsigned* sink, int w
   hipEventCreate(&a); hipEventCreate(&b);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(a, 0);
-    hipLaunchKernelGGL((feed_kernel<MODE, DEPTH, G>), dim3(blocks), dim3(waves * 64), lds, 0, src, region, iters, sink);
+    hipLaunchKernelGGL((feed_kernel<MODE, DEPTH, G>), dim3(blocks), dim3(waves * 64), lds, 0, src, region, iters, sink, pat, row_stride);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
   }
@@ -99,8 +104,8 @@ static void run(const unsigned char* src, unsigned region, unsigned* sink, int w
   hipEventElapsedTime(&ms, a, b);
   const double bytes = (double)blocks * waves * iters * G * 1024.0;
   const double inflight_kb = (double)waves * (DEPTH - 1) * G * (blocks > 256 ? 2 : 1);
-  printf("%-9s waves %2d x %d blk/CU  depth %d  stage %2d KB/wave  in flight %5.0f KB/CU  LDS %3zu KB/blk : %7.1f GB/s per CU  %6.2f TB/s chip\n",
-         MODE == 0 ? "LDS-DMA" : "registers", waves, blocks / 256, DEPTH, G, inflight_kb, lds / 1024, bytes / (ms * 1e-3) / 1e9 / 256, bytes / (ms * 1e-3) / 1e12);
+  printf("%-9s %s rows %4d B apart  waves %2d x %d blk/CU  depth %d  stage %2d KB/wave  in flight %5.0f KB/CU  LDS %3zu KB/blk : %7.1f GB/s per CU  %6.2f TB/s chip\n",
+         MODE == 0 ? "LDS-DMA" : "registers", (pat & 1) ? "swizzled" : "linear  ", row_stride, waves, blocks / 256, DEPTH, G, inflight_kb, lds / 1024, bytes / (ms * 1e-3) / 1e9 / 256, bytes / (ms * 1e-3) / 1e12);
 }
 
 int main(int argc, char** argv) {
@@ -111,6 +116,14 @@ int main(int argc, char** argv) {
   hipMalloc(&src, (size_t)region * 8);
   hipMalloc(&sink, 64);
   hipMemset(src, 1, (size_t)region * 8);
+  if (argc > 2 && atoi(argv[2]) == 2) {                        // access-pattern sweep: 8 rows x 128 B per wave-level load
+    for (int stride : {128, 256, 768, 2176, 4160})
+      for (int pat : {0, 1}) {
+        run<0, 3, 4>(src, region, sink, 8, 256, pat, stride);
+        run<1, 3, 4>(src, region, sink, 8, 256, pat, stride);
+      }
+    return 0;
+  }
   for (int blocks : {256, 512}) {
     for (int waves : {8, 16}) {
       if (blocks == 512 && waves == 16) continue;
