@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(kThreads)
 augment_sums_kernel(const mbx_augment_item* __restrict__ items, int S, const float* __restrict__ tmp,
                     double* __restrict__ partial /*[B][kSumBlocks][3]*/) {
   const int b = blockIdx.y;
-  const mbx_augment_item it = items[b];
-  const int ci = contrast_index(it);
+  const mbx_augment_item& it = items[b];                 // read in place (uniform scalar loads): a by-value copy indexed by a
+  const int ci = contrast_index(it);                     // run-time k lives in scratch memory
   if (ci < 0) return;
   double s[3] = {0.0, 0.0, 0.0};
   const float* img = tmp + (size_t)b * S * S * 3;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(kThreads)
 augment_color_kernel(const mbx_augment_item* __restrict__ items, int S, const float* __restrict__ tmp,
                      const double* __restrict__ partial, float* __restrict__ out) {
   const int b = blockIdx.y;
-  const mbx_augment_item it = items[b];
+  const mbx_augment_item& it = items[b];
   const int ci = contrast_index(it);
   __shared__ double mean[3];
   if (ci >= 0) {                                                   // uniform over the block: `it` is per image

@@ -867,17 +867,30 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 yf[A], xf[NX];
+        // 192 x 192 tiles: 72 accumulator + 36 fragment registers leave no room for nine loop-invariant fragment
+        // addresses under the 128-register budget of a 16-wave block (they spilled: the launch then needs scratch,
+        // which costs a ~0.1 ms stall per step when the queue sets it up) -- recompute them from lby instead
+        int lby_v = lby;
+        if constexpr (A * NX >= 18) asm volatile("" : "+v"(lby_v));
+        auto yoff = [&](int a) {
+          if constexpr (A * NX >= 18) { const int nb = wn * A + a; return (nb >> 2) * 8192 + lby_v + (((2 * (nb & 3) + (pp >> 1)) ^ sxy) << 4); }
+          else return yo[a];
+        };
+        auto xoff = [&](int b) {
+          if constexpr (A * NX >= 18) { const int kb = wk * NX + b; return (NY + (kb >> 2)) * 8192 + lby_v + (((2 * (kb & 3) + (pp >> 1)) ^ sxy) << 4); }
+          else return xo[b];
+        };
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yo[a] + kk * 4096 + 512));
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yoff(a) + kk * 4096));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + yoff(a) + kk * 4096 + 512));
           const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           yf[a] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
         for (int b = 0; b < NX; ++b) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 4096));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xo[b] + kk * 4096 + 512));
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xoff(b) + kk * 4096));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(base + xoff(b) + kk * 4096 + 512));
           const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           xf[b] = __builtin_bit_cast(bf16x8, v);
         }
