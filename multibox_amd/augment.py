@@ -95,18 +95,27 @@ class BatchAugmenter:
         self.used += (raw.size + ALIGN - 1) // ALIGN * ALIGN
         self.count += 1
 
-    def run(self):
-        """H2D copies + the three launches on the CURRENT stream; returns the device tensor [count,S,S,3]."""
-        torch = self.torch
+    def upload(self):
+        """The H2D copies of the staged pixels and items on the CURRENT stream."""
+        if self.count:
+            self.d_pix[:self.used].copy_(self.h_pix[:self.used], non_blocking=True)
+            self.d_items.copy_(self.h_items, non_blocking=True)
+
+    def launch(self):
+        """The three kernel launches on the CURRENT stream (after upload(), ordered by the caller if that ran on another
+        stream); returns the device tensor [count,S,S,3]."""
         n = self.count
         if n == 0:
             return self.out[:0]
-        self.d_pix[:self.used].copy_(self.h_pix[:self.used], non_blocking=True)
-        self.d_items.copy_(self.h_items, non_blocking=True)
         _lib.check(_lib.lib().mbx_augment_batch(self.d_pix.data_ptr(), self.d_items.data_ptr(), n, self.S,
                                                 int(self.any_contrast), self.out.data_ptr(), self.workspace.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream), "mbx_augment_batch")
+                                                self.torch.cuda.current_stream().cuda_stream), "mbx_augment_batch")
         return self.out[:n]
+
+    def run(self):
+        """upload() + launch() on the CURRENT stream."""
+        self.upload()
+        return self.launch()
 
 
 PATCH_DTYPE = np.dtype([("src_offset", "<u8"), ("img_h", "<i4"), ("img_w", "<i4"), ("win_y", "<i4"), ("win_x", "<i4"),

@@ -161,6 +161,21 @@ conv_igemm3_kernel(const ConvK p) {
       st_comp = st_comp == NSTG - 1 ? 0 : st_comp + 1;
     }
     if (NSTG == 3 && more) wait_vmcnt<NL>(); else wait_vmcnt<0>();   // tile it+1 landed (own DMAs), then everyone's
+#ifndef MBX_NO_LANDING_PROBE                      // (debug builds only: A/B of what the probe costs)
+    if constexpr (NSTG == 2) {
+      // 2-deep ring: the tile waited for here is read by OTHER waves right behind the barrier, with no K step of slack
+      // as in the 3-deep ring.  s_waitcnt vmcnt(0) + s_barrier turned out NOT to be enough for that: with another
+      // stream's kernels sharing the CUs (the input augmentation on a side stream; RCCL in data-parallel runs) a reader
+      // saw the slot's PREVIOUS contents about once in 10^5 launches -- one wave's 32 pixels x 1 channel of a 1x1
+      // layer's output NaN, then the whole stem (tools/side_stream_stress.py reproduces it in 25-75 steps; every
+      // 2-deep tile affected, no 3-deep one).  Reading back one own DMA destination before the barrier makes this
+      // wave's LDS-DMA writes drain through the LDS pipe first: 0 failures in 10 stress runs, +0.2 ms per step.
+      if (more) {
+        const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + st_comp * STAGE + wave * 64 + lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
+      }
+    }
+#endif
     raw_barrier();
   }
 #undef MBX_ISSUE_TILE

@@ -109,7 +109,19 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, u32x4* lds_dst,
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
 }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
-__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// Bare s_barrier (no vmcnt / lgkmcnt drain: LDS-DMA stays in flight across it), fenced for the COMPILER on both sides:
+// llvm.amdgcn.s.barrier is IntrNoMem, so without the fences nothing in the IR keeps the LDS accesses that follow it
+// from being scheduled above it.  (Not the cause of the round-2 side-stream corruption -- that was the 2-deep ring's
+// landing, see conv_igemm3_kernel -- but a hole of the same kind.)
+__device__ __forceinline__ void raw_barrier() {
+#ifndef MBX_UNFENCED_BARRIER                       // (debug builds only: the regression test's "does it catch the old form" check)
+  asm volatile("" ::: "memory");
+#endif
+  __builtin_amdgcn_s_barrier();
+#ifndef MBX_UNFENCED_BARRIER
+  asm volatile("" ::: "memory");
+#endif
+}
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's outstanding
 // vector-memory operations (fire-and-forget float atomics of the previous work item keep draining behind it)
 __device__ __forceinline__ void lds_barrier() {

@@ -438,6 +438,8 @@ class Net:
                 op.bn_ws_off = ws_floats
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
+        self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)
+        self._bn_flag_idx = None
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
         self.m12 = torch.zeros(2 * 2048, dtype=torch.float32, device=dev)
@@ -466,6 +468,8 @@ class Net:
             # there (the grouped weight gradient is persistent too, but its blocks pull work from queues and steal).
             if (self.bn_max_wg or os.environ.get("MBX_NO_I5") == "1") and d.tile_config > ops.I5_FLAG:
                 d.tile_config = ops._TUNED.get(repr(key) + "#i3", 0)       # the best igemm3 tile the tuner saw, else the rule
+            if os.environ.get("MBX_NO_2STAGE") == "1":                     # bisecting aid: 3-deep-ring twins of the 2-deep tiles
+                d.tile_config = {9: 7, 10: 2, 11: 5, 12: 2, 13: 8, 14: 1}.get(d.tile_config, d.tile_config)
         return d
 
     def _build_forward_launches(self):
@@ -755,18 +759,28 @@ class Net:
             total += f * (3.0 if (train and op.trainable) else 1.0)
         return total
 
-    def barrier_timeouts(self):
-        """Number of one-launch BN-backward kernels of the LAST backward pass whose grid barrier gave up (their
-        workgroups were not all resident); 0 in a healthy run.  Host sync."""
+    def _timeout_flags(self):
+        """Device tensor of the per-layer grid-barrier timeout flags of the LAST backward pass (or None)."""
         if self.mode != "train" or self.no_onepass:
-            return 0
-        ws = self.bn_ws.view(torch.int32)
-        idx = [op.bn_ws_off + 4 * 2 * op.K + 1 for op in self.convs if getattr(op, "bn_ws_off", -1) >= 0]
-        if not idx:
-            return 0
-        return int((ws[torch.tensor(idx, device=ws.device)] != 0).sum())
+            return None
+        if self._bn_flag_idx is None:
+            idx = [op.bn_ws_off + 4 * 2 * op.K + 1 for op in self.convs if getattr(op, "bn_ws_off", -1) >= 0]
+            self._bn_flag_idx = torch.tensor(idx, device=self.bn_ws.device) if idx else False
+        if self._bn_flag_idx is False:
+            return None
+        return self.bn_ws.view(torch.int32)[self._bn_flag_idx]
+
+    def barrier_timeouts(self):
+        """Number of one-launch BN-backward launches whose grid barrier gave up (their workgroups were not all resident)
+        SINCE THE NET WAS BUILT: the per-step flags are folded into a running total before the workspace is cleared, so a
+        timeout between two health checks is not lost.  0 in a healthy run.  Host sync."""
+        f = self._timeout_flags()
+        return int(self.bn_timeouts_total) + (int((f != 0).sum()) if f is not None else 0)
 
     def zero_grads(self):
+        f = self._timeout_flags()
+        if f is not None:
+            self.bn_timeouts_total += (f != 0).sum()            # (device-side: no sync)
         self.Wg.zero_()
         self.Btg.zero_()
         self.bn_ws.zero_()          # accumulators / arrival counters of the one-launch BN backward

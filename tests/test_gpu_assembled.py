@@ -222,3 +222,20 @@ def test_soak_400_steps_host_running_ahead(torch_cuda):
     assert j["matching_ok"] and j["grid_barrier_timeouts"] == 0
     assert all(np.isfinite(fl[k]) for k in ("location", "confidence", "regularization")), fl
     assert fl["confidence"] < 3000, fl                      # training on the fixed batch has made progress (starts near 8000)
+
+
+def test_training_step_survives_side_stream_kernels(torch_cuda):
+    """Regression (round 2): with another stream's kernels sharing the CUs all the time -- the input augmentation on the
+    prefetcher's stream, RCCL's kernels in data-parallel runs -- the 2-deep-ring convolution tiles read a ring slot's
+    previous contents about once in 10^5 launches (s_waitcnt vmcnt(0) + s_barrier does not order another wave's read
+    behind an LDS-DMA that has only just retired): NaN in one wave's outputs, then in every parameter of the stem within
+    25-75 steps, in 6 of 6 runs.  The tiles now read back one of their own DMA destinations before the barrier.
+    tools/side_stream_stress.py trains on a fixed batch with the augmentation kernels looping on a second stream."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "side_stream_stress.py"), "150"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    import json
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["noise_launches"] > 1000, j                     # the second stream really was busy
+    assert j["first_non_finite_check"] is None and j["barrier_timeouts"] == 0, j
+    assert all(np.isfinite(v) for v in j["losses"]), j

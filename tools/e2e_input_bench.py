@@ -20,6 +20,7 @@ LOG_EVERY_N_STEPS : 50
 SAVE_INTERVAL_SECS : 100000
 NUM_INPUT_THREADS : %d
 INPUT_AUGMENT_ON_DEVICE : %s
+INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM : %s
 QUEUE_CAPACITY : 1000
 QUEUE_MIN : 96
 DO_RANDOM_FLIP_LEFT_RIGHT : true
@@ -50,9 +51,9 @@ def main():
         _make_records(rec, [(480, 640, [[.1, .2, .5, .6], [.3, .3, .9, .8]][: i % 3]) for i in range(256)])
     pri = os.path.join(tmp, "e2e_priors.pkl")
     PR.save_priors(pri, PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]))
-    for on_device in ("true", "false"):
+    for on_device, side in (("true", "true"), ("true", "false"), ("false", "true")):
         cfg = os.path.join(tmp, "e2e_%s.yaml" % on_device)
-        open(cfg, "w").write(CFG % (workers, on_device))
+        open(cfg, "w").write(CFG % (workers, on_device, side))
         logdir = os.path.join(tmp, "e2e_log_%s" % on_device)
         subprocess.run(["rm", "-rf", logdir])
         n = steps if on_device == "true" else max(steps // 3, 100)
@@ -63,8 +64,10 @@ def main():
             print(r.stdout[-1500:], r.stderr[-1500:])
             raise SystemExit(1)
         recs = [json.loads(l) for l in open(os.path.join(logdir, "train_log.jsonl"))]
-        print("augmentation on the %s, %d workers: images/s per 50-step window = %s" % (
-            "GPU" if on_device == "true" else "host", workers, [round(x["images_per_sec"]) for x in recs]), flush=True)
+        import math
+        print("augmentation on the %s%s, %d workers: images/s per 50-step window = %s; non-finite total_loss in %d of %d windows" % (
+            "GPU" if on_device == "true" else "host", (" (kernels on the %s stream)" % ("side" if side == "true" else "training")) if on_device == "true" else "",
+            workers, [round(x["images_per_sec"]) for x in recs][:12], sum(not math.isfinite(x["total_loss"]) for x in recs), len(recs)), flush=True)
 
 
 if __name__ == "__main__":

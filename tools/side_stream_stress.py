@@ -1,0 +1,69 @@
+"""Training steps with ANOTHER stream's kernels sharing the CUs all the time (the situation of data-parallel runs, where
+RCCL's kernels overlap the backward pass, and of the input augmentation on a side stream): every parameter must stay
+finite.  Round 2 found the step's LDS-ring kernels reading a ring slot's previous contents about once in 10^5 launches
+under exactly this contention (bare s_barrier without compiler fences); tests/test_gpu_assembled.py runs this.
+usage: python tools/side_stream_stress.py [steps]      prints one JSON line"""
+import json
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import inputs as I, priors as PR
+    from multibox_amd.augment import BatchAugmenter
+    from multibox_amd.engine import Net
+    from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+    from multibox_amd.trainer import Trainer
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    B, S, k = 64, 299, 5
+    net = Net(batch=B, input_size=S, k=k, mode="train", seed=2)
+    pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], S).astype(np.float32)
+    tr = Trainer(net, pri, max_num_bboxes=13, location_loss_alpha=1000.0)
+    images, gt, n = synthetic_batch(B, S, 13, seed=0)
+    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    # the noise: the input-augmentation kernels (long fp64 elementwise launches that fill every CU) in a tight loop
+    rng = np.random.RandomState(0)
+    aug = BatchAugmenter(B, S, slot_bytes=480 * 640 * 3)
+    aug.begin()
+    u8 = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    for i in range(B):
+        aug.add(u8, i % 4, i % 2, I.color_ops(i % 4, False, rng))
+    aug.upload()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    stop = threading.Event()
+    launched = [0]
+
+    def noise():
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(8):
+                    aug.launch()
+                launched[0] += 8
+                side.synchronize()
+    th = threading.Thread(target=noise, daemon=True)
+    th.start()
+    first_bad = None
+    for step in range(1, steps + 1):
+        tr.step()
+        if step % 25 == 0:
+            torch.cuda.current_stream().synchronize()
+            if not (bool(torch.isfinite(net.W).all()) and bool(torch.isfinite(net.Bt).all())):
+                first_bad = step
+                break
+    stop.set()
+    th.join()
+    torch.cuda.synchronize()
+    print(json.dumps({"steps": steps, "first_non_finite_check": first_bad, "noise_launches": launched[0],
+                      "losses": [float(v) for v in tr.losses()], "barrier_timeouts": int(net.barrier_timeouts())}))
+
+
+if __name__ == "__main__":
+    main()

@@ -109,7 +109,10 @@ def main():
                                  num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + 1000 * rank, shuffle=True,   # train.py:214-225
                                  capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)),
                                  device_augment=bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True)))   # resize / colour / flip on the GPU
-        real = DevicePrefetcher(src, cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, device="cuda", depth=2)
+        # INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM: the augmentation kernels overlap the step on the prefetcher's stream
+        # (default) or are launched in front of each step on the training stream
+        real = DevicePrefetcher(src, cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, device="cuda", depth=2,
+                                kernels_on_main=not bool(cfg.get("INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM", True)))
 
     def next_real():
         # an exhausted / empty file shard on ONE rank must stop every rank, not leave the others in all_reduce
