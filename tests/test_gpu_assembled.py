@@ -239,3 +239,16 @@ def test_training_step_survives_side_stream_kernels(torch_cuda):
     assert j["noise_launches"] > 1000, j                     # the second stream really was busy
     assert j["first_non_finite_check"] is None and j["barrier_timeouts"] == 0, j
     assert all(np.isfinite(v) for v in j["losses"]), j
+
+
+def test_deterministic_steps_bit_identical_under_side_stream_kernels(torch_cuda):
+    """The stronger form of the test above: in MBX_DETERMINISTIC=1 mode 40 training steps leave bit-identical parameters
+    whether or not another stream's kernels share the CUs -- a ring slot read too early would show even if the stale
+    bytes happened to be finite."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "side_stream_stress.py"), "40", "compare"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, MBX_DETERMINISTIC="1"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    import json
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["noise_launches"] > 500 and j["first_non_finite_check"] is None, j
+    assert j["bit_identical_to_quiet_run"] is True, j

@@ -22,6 +22,8 @@ def main():
     from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
     from multibox_amd.trainer import Trainer
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    quiet_first = len(sys.argv) > 2 and sys.argv[2] == "compare"   # MBX_DETERMINISTIC=1 ... <steps> compare: the same steps
+    #   without and with the noise must leave bit-identical parameters (finite-but-stale reads would show here)
     B, S, k = 64, 299, 5
     net = Net(batch=B, input_size=S, k=k, mode="train", seed=2)
     pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], S).astype(np.float32)
@@ -48,6 +50,20 @@ def main():
                     aug.launch()
                 launched[0] += 8
                 side.synchronize()
+    reference = None
+    if quiet_first:
+        w0, b0 = net.W.clone(), net.Bt.clone()
+        snap = {k: getattr(tr, k).clone() for k in ("Wms", "Btms", "Wema", "Btema") if getattr(tr, k, None) is not None}
+        mm0, mv0, gs0 = net.MM.clone(), net.MV.clone(), tr.global_step
+        for _ in range(steps):
+            tr.step()
+        torch.cuda.synchronize()
+        reference = (net.W.clone(), net.Bt.clone())
+        net.W.copy_(w0); net.Bt.copy_(b0); net.MM.copy_(mm0); net.MV.copy_(mv0); tr.global_step = gs0
+        for k, v in snap.items():
+            getattr(tr, k).copy_(v)
+        net.Wb.copy_(net.W.to(torch.bfloat16)); net.prepare_filters()
+        torch.cuda.synchronize()
     th = threading.Thread(target=noise, daemon=True)
     th.start()
     first_bad = None
@@ -61,7 +77,13 @@ def main():
     stop.set()
     th.join()
     torch.cuda.synchronize()
-    print(json.dumps({"steps": steps, "first_non_finite_check": first_bad, "noise_launches": launched[0],
+    same = None
+    if reference is not None:
+        same = bool(torch.equal(net.W, reference[0]) and torch.equal(net.Bt, reference[1]))
+        if not same:
+            d = (net.W != reference[0])
+            print("parameters that differ:", int(d.sum()), "first index", int(d.nonzero()[0]) if d.any() else None, file=sys.stderr)
+    print(json.dumps({"steps": steps, "first_non_finite_check": first_bad, "noise_launches": launched[0], "bit_identical_to_quiet_run": same,
                       "losses": [float(v) for v in tr.losses()], "barrier_timeouts": int(net.barrier_timeouts())}))
 
 
