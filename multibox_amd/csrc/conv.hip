@@ -489,6 +489,10 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradK2& q, u32x4* smem, c
       st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
     }
     wait_vmcnt<0>();
+    if (it + 1 < nsteps) {            // 2-deep ring: landing probe, as in conv_igemm3_kernel (NSTG == 2)
+      const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
+    }
     raw_barrier();
   }
 #undef MBX_ISSUE_STEP
@@ -672,6 +676,10 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem,
       st_comp = st_comp == NST - 1 ? 0 : st_comp + 1;
     }
     wait_vmcnt<0>();
+    if (it + 1 < nsteps) {            // 2-deep ring: landing probe, as in conv_igemm3_kernel (NSTG == 2)
+      const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
+    }
     raw_barrier();
   }
 #undef MBX_ISSUE_STEP
