@@ -56,7 +56,7 @@ def main():
         open(cfg, "w").write(CFG % (workers, on_device, side))
         logdir = os.path.join(tmp, "e2e_log_%s" % on_device)
         subprocess.run(["rm", "-rf", logdir])
-        n = steps if on_device == "true" else max(steps // 3, 100)
+        n = steps if on_device == "true" else min(max(steps // 3, 100), 600)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", pri, "--logdir", logdir,
                             "--config", cfg, "--tfrecords", rec, "--max_number_of_steps", str(n)],
                            capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
@@ -67,7 +67,7 @@ def main():
         import math
         print("augmentation on the %s%s, %d workers: images/s per 50-step window = %s; non-finite total_loss in %d of %d windows" % (
             "GPU" if on_device == "true" else "host", (" (kernels on the %s stream)" % ("side" if side == "true" else "training")) if on_device == "true" else "",
-            workers, [round(x["images_per_sec"]) for x in recs][:12], sum(not math.isfinite(x["total_loss"]) for x in recs), len(recs)), flush=True)
+            workers, [round(x["images_per_sec"]) for x in recs][:8] + ['...'] + [round(x["images_per_sec"]) for x in recs][-2:], sum(not math.isfinite(x["total_loss"]) for x in recs), len(recs)), flush=True)
 
 
 if __name__ == "__main__":
