@@ -252,3 +252,14 @@ def test_deterministic_steps_bit_identical_under_side_stream_kernels(torch_cuda)
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["noise_launches"] > 500 and j["first_non_finite_check"] is None, j
     assert j["bit_identical_to_quiet_run"] is True, j
+
+
+def test_detect_forward_bit_identical_under_side_stream_kernels(torch_cuda):
+    """The detect path's forward (256 patches, k = 7, folded batch norm) repeated with another stream's kernels sharing
+    the CUs reproduces the quiet forward bit for bit (tools/side_stream_stress.py infer)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "side_stream_stress.py"), "60", "infer"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    import json
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["noise_launches"] > 500 and j["elements_that_differ"] == 0, j

@@ -22,6 +22,8 @@ def main():
     from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
     from multibox_amd.trainer import Trainer
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    if len(sys.argv) > 2 and sys.argv[2] == "infer":
+        return infer_mode(steps)
     quiet_first = len(sys.argv) > 2 and sys.argv[2] == "compare"   # MBX_DETERMINISTIC=1 ... <steps> compare: the same steps
     #   without and with the noise must leave bit-identical parameters (finite-but-stale reads would show here)
     B, S, k = 64, 299, 5
@@ -85,6 +87,55 @@ def main():
             print("parameters that differ:", int(d.sum()), "first index", int(d.nonzero()[0]) if d.any() else None, file=sys.stderr)
     print(json.dumps({"steps": steps, "first_non_finite_check": first_bad, "noise_launches": launched[0], "bit_identical_to_quiet_run": same,
                       "losses": [float(v) for v in tr.losses()], "barrier_timeouts": int(net.barrier_timeouts())}))
+
+
+def infer_mode(reps):
+    """The detect path (inference-mode forward at 256 patches, k = 7 + decode / filter / top-K): `reps` forwards with the
+    noise running must reproduce the quiet forward bit for bit (nothing in it is order-dependent)."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import _lib, inputs as I, priors as PR, detect as D
+    from multibox_amd.augment import BatchAugmenter
+    from multibox_amd.engine import Net
+    from multibox_amd.synth import DEFAULT_ASPECT_RATIOS
+    B, S, k = 256, 299, 7
+    net = Net(batch=B, input_size=S, k=k, mode="infer", seed=3)
+    net.fold_bn()
+    x = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (B, S, S, 3)).astype(np.float32)).cuda()
+    net.set_input(x)
+    locs, logits = net.forward()
+    torch.cuda.synchronize()
+    ref = (locs.clone(), logits.clone())
+    rng = np.random.RandomState(0)
+    aug = BatchAugmenter(64, S, slot_bytes=480 * 640 * 3)
+    aug.begin()
+    u8 = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    for i in range(64):
+        aug.add(u8, i % 4, i % 2, I.color_ops(i % 4, False, rng))
+    aug.upload()
+    torch.cuda.synchronize()
+    side, stop, launched = torch.cuda.Stream(), threading.Event(), [0]
+
+    def noise():
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(8):
+                    aug.launch()
+                launched[0] += 8
+                side.synchronize()
+    th = threading.Thread(target=noise, daemon=True)
+    th.start()
+    bad = 0
+    diff = torch.zeros((), dtype=torch.int64, device="cuda")
+    for _ in range(reps):
+        net.set_input(x)
+        locs, logits = net.forward()
+        diff += (locs != ref[0]).sum() + (logits != ref[1]).sum()
+    torch.cuda.synchronize()
+    stop.set(); th.join()
+    print(json.dumps({"mode": "infer", "forwards": reps, "noise_launches": launched[0], "elements_that_differ": int(diff)}))
 
 
 if __name__ == "__main__":
