@@ -167,6 +167,14 @@ typedef struct {
      from y itself.  Lets the residual trunk gradient of model.py:21 be built out of place, G[i-1] = G[i] + dgrad,
      so that G[i] survives for the deferred weight gradient of block i's 1x1 "up" convolution.          */
   const void* acc_src; int64_t acc_img_stride; int32_t ld_acc;
+  /* Persistent launches (tile_config > 32: conv_igemm5_kernel, one workgroup per CU that walks several tiles): DEVICE
+     int32 that is ZERO at launch, or NULL.  With it, a workgroup takes its first tile by position and every further
+     tile from this counter (one atomic per tile, fetched two tiles ahead), so a workgroup that starts late -- its CU
+     held by another stream's kernels, e.g. RCCL in a data-parallel run -- simply takes fewer tiles; with NULL the tiles
+     are dealt statically (first, first + grid, ...) and a late workgroup finishes its share late.  The launch leaves
+     the counter advanced: clear it before the next launch that uses it (one fill per step covers a whole table of
+     them).  Results are identical either way.                                                                     */
+  int32_t* work_counter;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 
@@ -189,7 +197,8 @@ int mbx_conv_wgrad(const mbx_conv_desc* desc /*HOST: x, geometry, C_out*/, const
  * MBX_WGRAD_DETERMINISTIC forbids every split (bit-reproducible dw).  Semantics per job = mbx_conv_wgrad_scaled,
  * with one difference: dw / db MUST be zero before the launch and each job needs its own dw -- a tile whose pixel
  * reduction is not split is written with plain stores (one adder: nothing to add to), split tiles add atomically.
- * The launch is PERSISTENT: one 768-thread workgroup per CU (8 MFMA waves + 4 LDS-DMA loader waves) pulls work items
+ * The launch is PERSISTENT: one 1024-thread workgroup per CU (8 MFMA waves + 8 LDS-DMA loader waves, 128 VGPRs per lane,
+ * 144 KB + 16 B of dynamic LDS: three ring stages of up to six 8 KB sub-images; nothing else fits beside it) pulls work items
  * from per-XCD queues inside the image (the queue heads start at zero in the image and the kernel's last block
  * resets them, so the same image serves every launch; one launch of an image at a time).
  * mbx_wgrad_plan writes a HOST image of mbx_wgrad_plan_bytes() bytes; copy it to 16-byte aligned device memory
@@ -205,6 +214,8 @@ typedef struct {
   int64_t layers_off, items_off;   /* byte offsets of the two tables inside the image */
   int64_t queues_off, heads_off;   /* per-XCD work queues: item ranges, and the queue heads the launch advances */
   double flops;                    /* 2 * M * C_out * R*S*C_in summed over the jobs */
+  int64_t tally_off;               /* two uint64 the launches only ever add to: work items processed, launches completed;
+                                      after a synchronise items == launches * n_items, or a launch has skipped work */
 } mbx_wgrad_plan_info;
 #define MBX_WGRAD_DETERMINISTIC 1
 #define MBX_WGRAD_SCATTER 2        /* A/B knob: deal single items round-robin to the queues (no L2 panel sharing) */
@@ -268,12 +279,15 @@ int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int rel
  * a workgroup that timed out also writes NaN into its part of dy (and dbeta), so a step cannot continue silently on
  * partial totals.  dbeta [C] += sum g (may be NULL).  max_workgroups: 0 = one
  * workgroup per CU; a smaller positive number leaves CUs free for a concurrent stream (e.g. an RCCL
- * all-reduce in flight), whose kernels would otherwise delay the barrier until they finish.              */
+ * all-reduce in flight), whose kernels would otherwise delay the barrier until they finish.
+ * step_poison (float32 scalar, may be NULL): += 1 per workgroup that timed out -- the first word of the step control
+ * block that mbx_rmsprop_ema_step / mbx_ema_update test (skip_ctl), so that a poisoned step is never applied.      */
 size_t mbx_bn_bwd_onepass_workspace_bytes(int C);
 int mbx_bn_bwd_onepass_supported(int64_t M, int C, int max_workgroups);
 int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64_t M, int C,
                        const float* mean, const float* rstd, const float* beta, float* dbeta /*[C] +=*/,
-                       void* dy /*bf16 [M,C]*/, void* ws, int max_workgroups, mbx_stream_t stream);
+                       void* dy /*bf16 [M,C]*/, void* ws, int max_workgroups, float* step_poison /*or NULL*/,
+                       mbx_stream_t stream);
 
 /* ---------------------------------------------------------------------- pooling (K9)
  * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap
@@ -328,12 +342,17 @@ int mbx_filter_prepare(const void* w_bf16, void* w_dgrad, const mbx_filter_entry
  *   w -= mom ; w_bf16 = bf16(w)
  * reg_loss (float32 scalar, may be NULL) += wd/2 * sum w^2 (the value before the update:
  * slim's regularization loss in total_loss, train.py:246).  `trainable` = 0 skips the
- * update (frozen variables still get EMA, regulariser and bf16 refresh).                   */
+ * update (frozen variables still get EMA, regulariser and bf16 refresh).
+ * skip_ctl (DEVICE, two float32, may be NULL): the step control block -- [0] barrier timeouts of this step's
+ * one-launch BN backward (mbx_bn_bwd_onepass step_poison), [1] ranks that asked to stop; data-parallel callers sum
+ * it over ranks together with the gradients.  If either word is non-zero the launch does NOTHING (no update, no
+ * EMA, no regulariser, no bf16 refresh): the step is skipped identically on every rank.      */
 int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* mom /*NULL if momentum==0*/,
                          float* ema /*or NULL*/, void* w_bf16 /*or NULL*/, int64_t n, float lr,
                          float decay, float momentum, float eps, float wd, float ema_decay,
-                         int trainable, float* reg_loss, mbx_stream_t stream);
-int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, mbx_stream_t stream);
+                         int trainable, float* reg_loss, const float* skip_ctl, mbx_stream_t stream);
+int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, const float* skip_ctl /*as above*/,
+                   mbx_stream_t stream);
 
 /* ------------------------------------------------------------ training input augmentation (row F1)
  * The pixel half of the reference's training input graph (inputs.py:264-351: crop, tf.image.resize_images with a

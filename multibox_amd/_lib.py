@@ -56,7 +56,7 @@ _SIGS = {
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
     "mbx_bn_bwd_onepass_workspace_bytes": (C.c_size_t, [I]),
     "mbx_bn_bwd_onepass_supported": (I, [C.c_int64, I, I]),
-    "mbx_bn_bwd_onepass": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P]),
+    "mbx_bn_bwd_onepass": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P, P]),
     "mbx_bn_bwd_reduce": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P]),
     "mbx_bn_bwd_finalize": (I, [P, I, I, C.c_int64, P, P, P]),
     "mbx_bn_bwd_apply": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),
@@ -69,8 +69,8 @@ _SIGS = {
     "mbx_head_gather": (I, [P, I, I, I, I, I, I, P, P, P]),
     "mbx_head_scatter": (I, [P, P, I, I, I, I, I, P, I, P]),
     "mbx_filter_prepare": (I, [P, P, P, I, I, P]),
-    "mbx_rmsprop_ema_step": (I, [P, P, P, P, P, P, C.c_int64, F, F, F, F, F, F, I, P, P]),
-    "mbx_ema_update": (I, [P, P, C.c_int64, F, P]),
+    "mbx_rmsprop_ema_step": (I, [P, P, P, P, P, P, C.c_int64, F, F, F, F, F, F, I, P, P, P]),
+    "mbx_ema_update": (I, [P, P, C.c_int64, F, P, P]),
 }
 
 _lib = None

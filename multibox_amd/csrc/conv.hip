@@ -135,15 +135,41 @@ conv_igemm3_kernel(const ConvK p) {
   } while (0)
 
   static_assert(NSTG == 2 || NSTG == 3, "ring depth");
+  // LANDING HAND-OFF (every ring in this file and in conv5.hip).  A K tile staged by LDS-DMA is read by OTHER waves.
+  // `s_waitcnt vmcnt` (the issuing wave's DMAs have retired) + `s_barrier` turned out NOT to order those reads behind
+  // the DMA's LDS write: with another stream's kernels sharing the CUs (input augmentation on a side stream, RCCL in
+  // data-parallel runs) a reader saw a slot's PREVIOUS contents about once in 10^5 launches of the 2-deep tiles
+  // (round 2: one wave's 32 pixels x 1 channel NaN, then the whole stem; tools/side_stream_stress.py).  The 3-deep
+  // rings had the same wait -> barrier -> read distance and were only protected by their DMA being issued a K step
+  // earlier -- a timing margin, not an ordering.  The rule now, everywhere: a wave publishes a tile only after it has
+  // READ BACK one of its own DMA destinations of that tile (its last piece) and that read has returned
+  // (`lgkmcnt(0)`) -- its LDS-DMA writes drain through the LDS pipe in front of the read -- and only then joins the
+  // barrier behind which the other waves read.  In the deep rings the wait + read-back of tile it+1 sit in the MIDDLE of
+  // step `it` (behind the first half of its MFMAs / of the loaders' DMA issue) so that the read's round trip is hidden;
+  // the 2-deep rings, which wait for the tile they have just issued, pay it at the end of the step (+0.2 ms per step).
+  u32x4* const probe_base = smem + (PI + WI - 1) * NT + wave * 64 + lane;   // this lane's slot of the wave's LAST piece
   MBX_ISSUE_TILE(0);
   if (NSTG == 3 && nk > 1) { MBX_ISSUE_TILE(1); wait_vmcnt<NL>(); } else wait_vmcnt<0>();
+  lds_readback_wait(lds_readback_issue(probe_base));
   raw_barrier();
   for (int it = 0; it < nk; ++it) {
     const bool more = it + NSTG - 1 < nk;
     if (more) MBX_ISSUE_TILE(it + NSTG - 1);
-    {                                                   // MFMA on tile `it` (ring slot st_comp)
-      const u32x4* cP = smem + st_comp * STAGE + (wm * TM) * 8;
-      const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
+    st_comp = st_comp == NSTG - 1 ? 0 : st_comp + 1;    // now the slot of tile it+1; tile `it` is in st_prev
+    const int st_prev = st_comp == 0 ? NSTG - 1 : st_comp - 1;
+#ifndef MBX_NO_LANDING_PROBE                      // (debug builds only: A/B of what the hand-off costs)
+    unsigned probe;
+    if constexpr (NSTG == 3) {
+      // 3-deep: tile it+1 was issued a whole step ago: wait for it HERE (tile it+2 is in flight meanwhile) and start
+      // the read-back; it returns while this step's fragments are read and multiplied.  (No control flow may sit
+      // inside the MFMA block below: the accumulators would leave the accumulator registers.)
+      if (more) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+      probe = lds_readback_issue(probe_base + st_comp * STAGE);
+    }
+#endif
+    {                                                   // MFMA on tile `it`
+      const u32x4* cP = smem + st_prev * STAGE + (wm * TM) * 8;
+      const u32x4* cW = smem + st_prev * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int fr = kk ? fr1 : fr0;
@@ -158,23 +184,15 @@ conv_igemm3_kernel(const ConvK p) {
           for (int b = 0; b < MI; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
       }
-      st_comp = st_comp == NSTG - 1 ? 0 : st_comp + 1;
     }
-    if (NSTG == 3 && more) wait_vmcnt<NL>(); else wait_vmcnt<0>();   // tile it+1 landed (own DMAs), then everyone's
-#ifndef MBX_NO_LANDING_PROBE                      // (debug builds only: A/B of what the probe costs)
+#ifndef MBX_NO_LANDING_PROBE
     if constexpr (NSTG == 2) {
-      // 2-deep ring: the tile waited for here is read by OTHER waves right behind the barrier, with no K step of slack
-      // as in the 3-deep ring.  s_waitcnt vmcnt(0) + s_barrier turned out NOT to be enough for that: with another
-      // stream's kernels sharing the CUs (the input augmentation on a side stream; RCCL in data-parallel runs) a reader
-      // saw the slot's PREVIOUS contents about once in 10^5 launches -- one wave's 32 pixels x 1 channel of a 1x1
-      // layer's output NaN, then the whole stem (tools/side_stream_stress.py reproduces it in 25-75 steps; every
-      // 2-deep tile affected, no 3-deep one).  Reading back one own DMA destination before the barrier makes this
-      // wave's LDS-DMA writes drain through the LDS pipe first: 0 failures in 10 stress runs, +0.2 ms per step.
-      if (more) {
-        const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + st_comp * STAGE + wave * 64 + lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
-      }
+      wait_vmcnt<0>();                                  // tile it+1 (issued at the top of this step) has retired
+      probe = lds_readback_issue(probe_base + st_comp * STAGE);
     }
+    lds_readback_wait(probe);                           // the read-back has returned: publish
+#else
+    if (NSTG == 3 && more) wait_vmcnt<NL>(); else wait_vmcnt<0>();
 #endif
     raw_barrier();
   }
@@ -490,8 +508,7 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradK2& q, u32x4* smem, c
     }
     wait_vmcnt<0>();
     if (it + 1 < nsteps) {            // 2-deep ring: landing probe, as in conv_igemm3_kernel (NSTG == 2)
-      const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
+      lds_readback_wait(lds_readback_issue(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane));
     }
     raw_barrier();
   }
@@ -677,8 +694,7 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgradK2& q, u32x4* smem,
     }
     wait_vmcnt<0>();
     if (it + 1 < nsteps) {            // 2-deep ring: landing probe, as in conv_igemm3_kernel (NSTG == 2)
-      const unsigned probe = *reinterpret_cast<volatile unsigned*>(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(probe) : "memory");
+      lds_readback_wait(lds_readback_issue(smem + (grp * NST + (st_issue ^ 1)) * STAGE + wave * 64 + lane));
     }
     raw_barrier();
   }
@@ -790,15 +806,22 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
       ow = pix - oh * p.W_out;
     }
     int st_issue = 0, st_bias = 0;
-#define MBX_ISSUE_STEP5()                                                                                      \
+// one pixel step's LDS-DMA in two halves (dy sub-images; x sub-images + cursor advance): the landing hand-off of the
+// NEXT step (wait + read-back, see conv_igemm3_kernel) sits between them, its LDS round trip covered by the second half
+#define MBX_ISSUE_STEP5_Y()                                                                                    \
+  do {                                                                                                         \
+    u32x4* d = smem + st_issue * STAGE + lw * 64;                                                              \
+    const bool mv = m_run < blk_end;                                                                           \
+    const int yb = q.ydense ? m_run * ldy2 : (img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2;      \
+    _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                             \
+      glds16(yr, d + j * 512, (mv && ycol[j] >= 0) ? yb + ycol[j] : (int)kOOB);                                \
+  } while (0)
+#define MBX_ISSUE_STEP5_X()                                                                                    \
   do {                                                                                                         \
     u32x4* d = smem + st_issue * STAGE + lw * 64;                                                              \
     const bool mv = m_run < blk_end;                                                                           \
     const int h0 = oh * p.stride - p.pad_t, w0 = ow * p.stride - p.pad_l;                                      \
     const int rb = (img * p.x_img_stride + (h0 * p.W_in + w0) * p.ldx) * 2;                                    \
-    const int yb = q.ydense ? m_run * ldy2 : (img * p.dy_img_stride + (oh * p.W_out + ow) * p.ld_dy) * 2;      \
-    _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                             \
-      glds16(yr, d + j * 512, (mv && ycol[j] >= 0) ? yb + ycol[j] : (int)kOOB);                                \
     _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                           \
       const bool ok = mv && ((unsigned)(h0 + tr[j]) < (unsigned)p.H_in) && ((unsigned)(w0 + ts[j]) < (unsigned)p.W_in); \
       glds16(xr, d + (NY + j) * 512, ok ? rb + toff[j] : (int)kOOB);                                           \
@@ -809,9 +832,12 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
     while (oh >= p.H_out) { oh -= p.H_out; ++img; }                                                            \
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                         \
   } while (0)
+#define MBX_ISSUE_STEP5() do { MBX_ISSUE_STEP5_Y(); MBX_ISSUE_STEP5_X(); } while (0)
 
     if (nsteps > 0) MBX_ISSUE_STEP5();
     if (nsteps > 1) { MBX_ISSUE_STEP5(); wait_vmcnt<NSUB>(); } else wait_vmcnt<0>();
+    int st_pub = 0;                                       // ring slot of the step published next
+    lds_readback_wait(lds_readback_issue(smem + (NSUB - 1) * 512 + lw * 64 + lane));   // this lane's slot of the wave's last piece
     raw_barrier();                                        // step 0 has landed
     const int lt = threadIdx.x - 512;                     // 0..511: bias sums of slot lt (row lt >> 3) of every dy image
     float bs[NY][8];
@@ -821,7 +847,10 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
       for (int e = 0; e < 8; ++e) bs[j][e] = 0.f;
     for (int it = 0; it < nsteps; ++it) {
       const bool more = it + 2 < nsteps;
-      if (more) MBX_ISSUE_STEP5();
+      st_pub = st_pub == NST - 1 ? 0 : st_pub + 1;        // slot of step it+1
+      if (more) { MBX_ISSUE_STEP5_Y(); wait_vmcnt<NY>(); } else wait_vmcnt<0>();   // step it+1 has retired (this wave's share)
+      const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NSUB - 1) * 512 + lw * 64 + lane);
+      if (more) MBX_ISSUE_STEP5_X();
       if (bias) {                                         // dy images of the step being multiplied (landed, read-only now)
         const u32x4* img_y = smem + st_bias * STAGE;
 #pragma unroll
@@ -833,9 +862,11 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
         }
         st_bias = st_bias == NST - 1 ? 0 : st_bias + 1;
       }
-      if (more) wait_vmcnt<NSUB>(); else wait_vmcnt<0>(); // step it+1 has landed (this wave's share), then everyone's
+      lds_readback_wait(probe);                           // read-back returned: publish step it+1
       raw_barrier();
     }
+#undef MBX_ISSUE_STEP5_X
+#undef MBX_ISSUE_STEP5_Y
 #undef MBX_ISSUE_STEP5
     if (bias) {                                           // 64 rows per channel -> LDS -> one adder per channel
       lds_barrier();                                      // (the compute waves are past their last LDS read)
@@ -982,11 +1013,11 @@ conv_wgrad2n_kernel(const WgradK2 q) {
 struct WgradLayer { WgradK2 q; int narrow, lin, pad0, pad1; };
 struct WgradItem { int layer, tile_n, tile_k, m_begin, m_end, single, cfg, pad2; };   // single: the only adder of its dw tile;
                                                                                          // cfg: tile shape, index into kWgCfgs
-constexpr int kWgradLds = 3 * 3 * 16384;               // wgrad5: three stages x (dy | x 0..127 | x 128..255) x 16 KB
+constexpr int kWgradLds = 3 * 3 * 16384;               // wgrad5: three stages x up to six 8 KB sub-images (NY dy + NX x) = 144 KB
 constexpr int kQueues = 8;                             // one work queue per XCD
 constexpr int kCounterStride = 32;                     // ints: every queue head on its own 128-byte line
 
-// PERSISTENT: one 512-thread block per CU; a block reads the id of the XCD it runs on and pulls items from THAT
+// PERSISTENT: one 1024-thread block per CU (8 MFMA + 8 loader waves, 144 KB + 16 B of LDS); a block reads the id of the XCD it runs on and pulls items from THAT
 // XCD's queue (one returning atomic per item), then steals from the other queues.  The host deals whole panel groups
 // -- all output tiles of one (layer, pixel range), which stream the same dy / x rows -- to one queue, so the ~32
 // blocks that share an L2 walk the same pixels at the same time and all but the first read of a row is an L2 hit
@@ -1002,6 +1033,7 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   volatile int* s_idx = reinterpret_cast<volatile int*>(smem + kWgradLds / 16);     // one word past the rings
   const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (kQueues - 1);         // HW_REG_XCC_ID[3:0]
+  int n_done = 0;                                        // work items this block has processed (block-uniform)
   for (int q = 0; q < kQueues; ++q) {
     const int qx = (xcd + q) & (kQueues - 1);
     const int qb = qrange[qx], qe = qrange[kQueues + qx];
@@ -1023,18 +1055,25 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
         default: break;
       }
 #undef MBX_WG_CASE
+      ++n_done;
     }
   }
   // Leave the queue heads at zero for the next launch: the LAST block to get here (every other block has left its
   // dequeue loops) resets them.  (A hipMemsetAsync in front of the kernel did this first; as a memset NODE of a captured
   // graph replayed hundreds of times with the host far ahead it ended in GPU memory-access faults, 4 of 10 400-step
   // runs -- the launch now carries no memset.)
+  // The tally line behind the counters is never reset: [0] work items processed, [1] launches completed, both cumulative.
+  // The host checks items == launches x n_items at its health checks (ops.WgradGroup.completed_ok): a launch that found
+  // stale heads (after an aborted launch) would otherwise compute nothing -- dW all zeros -- without any error.
   lds_barrier();
   if (threadIdx.x == 0) {
+    unsigned long long* tally = reinterpret_cast<unsigned long long*>(heads + (kQueues + 1) * kCounterStride);
+    if (n_done) atomicAdd(tally, (unsigned long long)n_done);
     int* exits = heads + kQueues * kCounterStride;
     if (atomicAdd(exits, 1) == (int)gridDim.x - 1) {
       for (int q = 0; q < kQueues; ++q) atomicExch(heads + q * kCounterStride, 0);
       atomicExch(exits, 0);
+      atomicAdd(tally + 1, 1ull);
     }
   }
 }
@@ -1213,6 +1252,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
   k.skip_taps = 0; k.parity = 0;
+  k.work_counter = d->work_counter;
 #ifdef MBX_I5_STAMPS
   {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
@@ -1491,7 +1531,8 @@ static void plan_queues(const mbx_wgrad_job* jobs, int n_jobs, int flags, const 
   }
 }
 
-static size_t plan_image_bytes(int n_jobs, size_t n_items, int64_t* items_off, int64_t* queues_off, int64_t* heads_off) {
+static size_t plan_image_bytes(int n_jobs, size_t n_items, int64_t* items_off, int64_t* queues_off, int64_t* heads_off,
+                               int64_t* tally_off = nullptr) {
   size_t o = sizeof(WgradLayer) * (size_t)n_jobs;
   if (items_off) *items_off = (int64_t)o;
   o += sizeof(WgradItem) * n_items;
@@ -1500,6 +1541,8 @@ static size_t plan_image_bytes(int n_jobs, size_t n_items, int64_t* items_off, i
   o += 128;                                            // qrange: 2 x kQueues ints
   if (heads_off) *heads_off = (int64_t)o;
   o += (size_t)(kQueues + 1) * kCounterStride * sizeof(int);            // queue heads + the exit counter, a line each
+  if (tally_off) *tally_off = (int64_t)o;
+  o += (size_t)kCounterStride * sizeof(int);                            // tally line: items processed | launches completed (uint64)
   return o;
 }
 
@@ -1521,8 +1564,8 @@ extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, 
   int qrange[2 * kQueues];
   plan_jobs(jobs, n_jobs, flags, pj);
   plan_queues(jobs, n_jobs, flags, pj, items, qrange);
-  int64_t items_off, queues_off, heads_off;
-  const size_t need = plan_image_bytes(n_jobs, items.size(), &items_off, &queues_off, &heads_off);
+  int64_t items_off, queues_off, heads_off, tally_off;
+  const size_t need = plan_image_bytes(n_jobs, items.size(), &items_off, &queues_off, &heads_off, &tally_off);
   if (bytes < need || items.size() >= (1ull << 30)) return MBX_ERR_WORKSPACE;
   memset(host_image, 0, need);
   char* base = reinterpret_cast<char*>(host_image);
@@ -1546,6 +1589,7 @@ extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, 
   info->items_off = items_off;
   info->queues_off = queues_off;
   info->heads_off = heads_off;
+  info->tally_off = tally_off;
   info->flops = flops;
   return MBX_OK;
 }

@@ -39,7 +39,7 @@ struct Ig5 {
   static constexpr int RING_BYTES = NST * STAGE * 16;
   static constexpr int CR = (RING_BYTES + 64 * LDT * 4 <= 160 * 1024 - 64) ? 64 : (RING_BYTES + 32 * LDT * 4 <= 160 * 1024 - 64) ? 32 : 16;
   static constexpr int EP_BYTES = CR * LDT * 4;
-  static constexpr int LDS_BYTES = RING_BYTES + EP_BYTES;
+  static constexpr int LDS_BYTES = RING_BYTES + EP_BYTES + 16;      // + four tile ids of the queued assignment
   static constexpr int NCHUNK = BM / CR;                            // epilogue passes through the window
   static_assert(TM % 16 == 0 && TN % 16 == 0 && WM * WN == 8, "wave grid");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -59,12 +59,22 @@ conv_igemm5_kernel(const ConvK p) {
   constexpr int NBAR = 2 * NCHUNK + (EV == 1 ? 2 : 0);              // barriers of one tile's epilogue
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   float* const ep = reinterpret_cast<float*>(smem + NST * STAGE);
+  // QUEUED tile assignment (p.work_counter): tile sequence of this workgroup = its first tile by position, then
+  // gridDim.x + (values of the counter).  Lane 0 of compute wave 0 fetches the id of tile j+2 when tile j starts (a
+  // returning atomic, in flight during the K loop -- the compute waves issue no other vector-memory instruction there)
+  // and publishes it through s_ids[(j + 2) & 3] in tile j's epilogue, barriers before anyone needs it: the loaders read
+  // the id of tile j+1 while they are still inside tile j (they run NST - 1 K steps ahead, hence the nk >= NST condition;
+  // shorter K loops fall back to the static deal).  Same tiles, same arithmetic: results do not depend on the mode.
+  // (an explicit LDS pointer: through a generic or volatile one hipcc emits FLAT accesses, which count on vmcnt too)
+  typedef __attribute__((address_space(3))) int* lds_int_ptr;
+  const lds_int_ptr s_ids = (lds_int_ptr)(ep + CR * LDT);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int ntiles = p.tiles_m * p.tiles_n;
   const int first = xcd_remap(blockIdx.x, gridDim.x);               // tiles first, first + grid, ...
   const int nk = (p.Ktot + 63) >> 6;
+  const bool queued = p.work_counter != nullptr && nk >= NST;       // (uniform)
 
   if (wave >= 8) {
     // -------------------------------------------------------------------------------------------- loader waves
@@ -75,7 +85,7 @@ conv_igemm5_kernel(const ConvK p) {
     const int chunk = (lane & 7) ^ r8;                              // source chunk of this lane's slot (row & 7 == r8)
     const int ldx2 = p.ldx * 2;
     // issue cursor: (tile, K step) two steps ahead of the compute waves; row state of THAT tile
-    int t_i = first, it_i = 0, st_issue = 0;
+    int t_i = first, it_i = 0, st_issue = 0, j_i = 0;               // j_i: index of the issue tile in this workgroup's sequence
     int hb[MY], wb[MY], ro[MY], wo[NW];
     int kc = 0, kr = 0, ks = 0;
 #define MBX5_SETUP_TILE()                                                                                     \
@@ -98,7 +108,11 @@ conv_igemm5_kernel(const ConvK p) {
     kc = chunk * 8; kr = 0; ks = 0;                                                                           \
     while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
   } while (0)
-#define MBX5_ISSUE()                                                                                          \
+// One K step's LDS-DMA in two halves (pixel rows, then filter rows + cursor advance): the loaders wait for and read
+// back the NEXT step's tile between the halves (landing hand-off, see conv_igemm3_kernel), so that the read-back's LDS
+// round trip is covered by the issue of the second half instead of sitting on the loaders' critical path (as a
+// wait + read-back behind the whole issue it cost 1.5 ms per step in round 2).
+#define MBX5_ISSUE_A()                                                                                        \
   do {                                                                                                        \
     u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
     const bool kv = kr < p.R;                                                                                 \
@@ -113,15 +127,28 @@ conv_igemm5_kernel(const ConvK p) {
         glds16(xr, sp + i * 512, ok ? (ro[i] + toff) : (int)kOOB);                                            \
       }                                                                                                       \
     }                                                                                                         \
+  } while (0)
+#define MBX5_ISSUE_B()                                                                                        \
+  do {                                                                                                        \
+    u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
+    const bool kv = kr < p.R;                                                                                 \
     const int kb = (it_i * 64 + chunk * 8) * 2;                                                               \
     _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                            \
       glds16(wr, sp + (MY + i) * 512, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                         \
     kc += 64;                                                                                                 \
     while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
-    if (++it_i == nk) { it_i = 0; t_i += gridDim.x; if (t_i < ntiles) MBX5_SETUP_TILE(); }                    \
+    if (++it_i == nk) {                                                                                       \
+      it_i = 0; ++j_i;                                                                                        \
+      t_i = queued ? s_ids[j_i & 3] : t_i + (int)gridDim.x;                                                   \
+      if (t_i < ntiles) MBX5_SETUP_TILE();                                                                    \
+    }                                                                                                         \
   } while (0)
+#define MBX5_ISSUE() do { MBX5_ISSUE_A(); MBX5_ISSUE_B(); } while (0)
+    // read-back of this lane's slot of the wave's LAST piece (filter piece NW - 1) of ring slot `st_pub`, returned
+#define MBX5_READBACK() lds_readback_wait(lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane))
 
+    int st_pub = 0;                                                 // ring slot of the step published next
     if (t_i < ntiles) {
       MBX5_SETUP_TILE();
       MBX5_ISSUE();                                                 // global step 0
@@ -131,21 +158,31 @@ conv_igemm5_kernel(const ConvK p) {
         if (t_i < ntiles) MBX5_ISSUE(); else full = false;
       }
       if (full) wait_vmcnt<(NST - 2) * NL>(); else wait_vmcnt<0>();
+      MBX5_READBACK();
     }
-    raw_barrier();                                                  // step 0 has landed
-    for (int t = first; t < ntiles; t += gridDim.x) {
+    raw_barrier();                                                  // step 0 has landed (and s_ids[0..1] are written)
+    int jc = 0;                                                     // index of the tile the compute waves are on
+    for (int t = first; t < ntiles; t = queued ? s_ids[++jc & 3] : t + (int)gridDim.x) {
       for (int it = 0; it < nk; ++it) {
         const bool more = t_i < ntiles;                             // anything left to issue (this or a later tile)?
-        if (more) MBX5_ISSUE();
+        st_pub = st_pub == NST - 1 ? 0 : st_pub + 1;                // the NEXT step's slot
+        if (more) MBX5_ISSUE_A();
 #ifdef MBX_I5_STAMPS
-        if (p.dbg & 2) { raw_barrier(); continue; }                 // timing probe: do not wait for the landing (wrong results)
+        if (p.dbg & 2) { if (more) MBX5_ISSUE_B(); raw_barrier(); continue; }   // timing probe: do not wait for the landing (wrong results)
 #endif
-        if (more) wait_vmcnt<(NST - 2) * NL>(); else wait_vmcnt<0>();   // the NEXT step has landed (this wave's share)
+        // the NEXT step (steps s+1 .. s+NST-2 are outstanding, + the MY pieces just issued) has retired: this wave's share
+        if (more) wait_vmcnt<(NST - 3) * NL + MY>(); else wait_vmcnt<0>();
+        const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane);
+        if (more) MBX5_ISSUE_B();
+        lds_readback_wait(probe);                                   // read-back returned: publish
         raw_barrier();
       }
 #pragma unroll 1
       for (int b = 0; b < NBAR; ++b) raw_barrier();                 // the compute waves' epilogue (own LDS window)
     }
+#undef MBX5_READBACK
+#undef MBX5_ISSUE_B
+#undef MBX5_ISSUE_A
 #undef MBX5_ISSUE
 #undef MBX5_SETUP_TILE
     return;
@@ -158,8 +195,17 @@ conv_igemm5_kernel(const ConvK p) {
   const int fr0 = frow * 8 + (fch ^ (frow & 7));
   const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
   int st_comp = 0;
+  const bool fetcher = queued && tid == 0;
+  auto fetch_tile = [&]() -> int {                                  // next id off the counter (>= ntiles: none left)
+    const int v = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+    return v < ntiles ? v : ntiles;
+  };
+  if (fetcher) { s_ids[0] = first; s_ids[1] = fetch_tile(); }
   raw_barrier();                                                    // step 0 has landed
-  for (int t = first; t < ntiles; t += gridDim.x) {
+  int jt = 0;
+  for (int t = first; t < ntiles; t = queued ? s_ids[++jt & 3] : t + (int)gridDim.x) {
+    int next2 = ntiles;
+    if (fetcher) next2 = fetch_tile();                              // id of tile jt + 2: returns during the K loop
     const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef MBX_I5_STAMPS
@@ -248,6 +294,7 @@ conv_igemm5_kernel(const ConvK p) {
       }
     };
     if constexpr (PRE) prefetch(0);
+    if (fetcher) s_ids[(jt + 2) & 3] = next2;                       // visible behind the epilogue's barriers
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
       // the accumulator blocks whose rows fall into this window (compile-time block index, run-time predicate)

@@ -34,6 +34,7 @@ struct ConvK {
   int cls_m0[4], cls_hw[4], cls_w[4];  // first pixel index, pixels per image (Hc * Wc) and row length Wc per class
   int skip_taps;                       // C_in % 64 == 0: K tiles never straddle taps, whole taps can be skipped
   int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
+  int* work_counter;                   // igemm5: tiles after a workgroup's first come from this counter (NULL: static)
 #ifdef MBX_I5_STAMPS
   unsigned long long* stamps;          // debug build: wall_clock64() per tile phase of the first 8 tiles of 64 blocks
   int dbg;                             // debug build: MBX_I5_DBG timing probes (bit 0: compute waves idle, bit 1: loaders do not wait)
@@ -132,5 +133,22 @@ __device__ __forceinline__ void lds_barrier() {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LANDING READ-BACK of an LDS-DMA destination.  Deliberately a FLAT load through the LDS aperture, not a ds_read: it
+// travels the vector-memory path (TA -> LDS) that the wave's `buffer_load ... lds` writes took, so it cannot overtake
+// them; its return (lgkmcnt) therefore says that every LDS-DMA this wave had retired by `s_waitcnt vmcnt` before
+// issuing it has reached the LDS array.  Round 2's fix was this instruction without knowing it: hipcc compiled the
+// `volatile unsigned*` read of the ring to `flat_load_dword ... sc0 sc1` followed by `s_waitcnt vmcnt(0) lgkmcnt(0)`
+// (a FLAT access counts on both counters) -- correct, but the vmcnt(0) drained the DMA queue, which is what made the
+// same probe cost 1.5 ms per step in the loader waves of the deep rings.  Written as inline asm the compiler adds no
+// wait: the issue is free-standing and lds_readback_wait() waits on lgkmcnt only.  (The flat load also holds a vmcnt
+// slot until it returns; a counted vmcnt wait issued after it can only become more conservative by that one.)
+__device__ __forceinline__ unsigned lds_readback_issue(const void* lds_slot) {
+  unsigned v;
+  const unsigned long long a = reinterpret_cast<unsigned long long>(lds_slot);    // generic address: shared aperture | offset
+  asm volatile("flat_load_dword %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_readback_wait(unsigned v) { asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(v) : "memory"); }
 
 }  // namespace

@@ -375,7 +375,8 @@ __global__ void __launch_bounds__(kObT)
 bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ y,
                       long long M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ beta, float* __restrict__ dbeta, unsigned short* __restrict__ dy,
-                      float* __restrict__ ws, int rpi, int rpb, float inv_M, unsigned spin_limit, int fault) {
+                      float* __restrict__ ws, int rpi, int rpb, float inv_M, unsigned spin_limit, int fault,
+                      float* __restrict__ step_poison) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16] partial sums, then [2C] totals
   __shared__ int s_timeout;                                      // this workgroup gave up on the grid barrier
   const int C8 = C >> 3;
@@ -486,7 +487,11 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
         // cannot happen when the grid is resident.  If it does (CUs taken by another stream's kernels), the totals
         // below are partial: raise the flag AND poison this workgroup's outputs with NaN, so that the step cannot
         // silently train on a wrong gradient (the host also checks the flag: Trainer.check_health)
-        if (++spins > spin_limit) { ctl[1] = 1u; s_timeout = 1; break; }
+        if (++spins > spin_limit) {
+          ctl[1] = 1u; s_timeout = 1;
+          if (step_poison) atomicAdd(step_poison, 1.0f);    // the optimiser skips a step whose control word is non-zero
+          break;
+        }
       }
     }
     if (b == 0) ctl[0] = G;
@@ -861,7 +866,12 @@ filter_prepare_kernel(const unsigned short* __restrict__ w, unsigned short* __re
 __global__ void __launch_bounds__(kT)
 rmsprop_ema_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms, float* __restrict__ mom,
                    float* __restrict__ ema, unsigned short* __restrict__ wb, long long n, float lr, float decay,
-                   float momentum, float eps, float wd, float ema_decay, int trainable, float* __restrict__ reg_loss) {
+                   float momentum, float eps, float wd, float ema_decay, int trainable, float* __restrict__ reg_loss,
+                   const float* __restrict__ skip_ctl) {
+  // step control block (two floats, summed over ranks with the beta gradients): [0] grid-barrier timeouts of this
+  // step's one-launch BN backward (its gradients are poisoned), [1] ranks that asked to stop (input exhausted).
+  // Either non-zero: the step is NOT applied -- no update, no EMA, nothing written (uniform branch).
+  if (skip_ctl && (skip_ctl[0] != 0.f || skip_ctl[1] != 0.f)) return;
   float sq = 0.f;
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
     float wi = w[i];
@@ -892,7 +902,9 @@ rmsprop_ema_kernel(float* __restrict__ w, const float* __restrict__ g, float* __
 }
 
 __global__ void __launch_bounds__(kT)
-ema_update_kernel(float* __restrict__ ema, const float* __restrict__ v, long long n, float d) {
+ema_update_kernel(float* __restrict__ ema, const float* __restrict__ v, long long n, float d,
+                  const float* __restrict__ skip_ctl) {
+  if (skip_ctl && (skip_ctl[0] != 0.f || skip_ctl[1] != 0.f)) return;       // as rmsprop_ema_kernel
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
     const float e = ema[i];
     ema[i] = e - (1.0f - d) * (e - v[i]);
@@ -1022,7 +1034,7 @@ extern "C" int mbx_bn_bwd_onepass_supported(int64_t M, int C, int max_workgroups
 
 extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64_t M, int C, const float* mean,
                                   const float* rstd, const float* beta, float* dbeta, void* dy, void* ws,
-                                  int max_workgroups, mbx_stream_t stream) {
+                                  int max_workgroups, float* step_poison, mbx_stream_t stream) {
   if (!da || !y || !mean || !rstd || (relu && !beta) || !dy || !ws || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || !al16(da) ||
       !al16(y) || !al16(dy) || !al16(ws) || !al16(mean) || !al16(rstd) || (relu && !al16(beta)))
     return MBX_ERR_INVALID_ARG;
@@ -1038,7 +1050,7 @@ extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const voi
 #define MBX_OB(NV, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_bwd_onepass_kernel<NV, RELU>), dim3(g.G), dim3(kObT), lds, mbx_s(stream), (cus)da, ld_da,      \
                      (cus)y, (long long)M, C, mean, rstd, beta, dbeta, (us)dy, (float*)ws, g.rpi, g.rpb,               \
-                     (float)(1.0 / (double)M), spin_limit, fault)
+                     (float)(1.0 / (double)M), spin_limit, fault, step_poison)
 #define MBX_OB_NV(NV) do { if (relu) MBX_OB(NV, true); else MBX_OB(NV, false); } while (0)
   if (g.nv <= 2) MBX_OB_NV(2);
   else if (g.nv <= 4) MBX_OB_NV(4);
@@ -1162,20 +1174,21 @@ extern "C" int mbx_filter_prepare(const void* w_bf16, void* w_dgrad, const mbx_f
 
 extern "C" int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* mom, float* ema, void* w_bf16, int64_t n,
                                     float lr, float decay, float momentum, float eps, float wd, float ema_decay,
-                                    int trainable, float* reg_loss, mbx_stream_t stream) {
+                                    int trainable, float* reg_loss, const float* skip_ctl, mbx_stream_t stream) {
   if (!w || n <= 0 || (trainable && (!g || !ms))) return MBX_ERR_INVALID_ARG;
   if (trainable && momentum != 0.f && !mom) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   hipLaunchKernelGGL(rmsprop_ema_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), w, g, ms, momentum != 0.f ? mom : nullptr,
-                     ema, (us)w_bf16, (long long)n, lr, decay, momentum, eps, wd, ema_decay, trainable, reg_loss);
+                     ema, (us)w_bf16, (long long)n, lr, decay, momentum, eps, wd, ema_decay, trainable, reg_loss, skip_ctl);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
 
-extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, mbx_stream_t stream) {
+extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float ema_decay, const float* skip_ctl,
+                              mbx_stream_t stream) {
   if (!ema || !value || n <= 0) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), ema, value, (long long)n, ema_decay);
+  hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), ema, value, (long long)n, ema_decay, skip_ctl);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

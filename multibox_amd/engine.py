@@ -85,6 +85,10 @@ class Net:
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
         self.bn_max_wg = int(os.environ.get("MBX_BN_MAX_WG", "0")) or (bn_max_workgroups or 0)
+        # work counters of the persistent igemm5 launches (mbx_conv_desc.work_counter): one per launch, cleared together
+        # at the start of every pass (forward() / backward())
+        self.i5_counters = torch.zeros(2048, dtype=torch.int32, device=device)
+        self._i5_used = 0
         self.convs, self.fwd, self.bwd = [], [], []
         self.grad_alias = {}       # id(activation buffer) -> gradient buffer
         self.written = set()       # gradient regions already written in the backward pass (build time)
@@ -372,7 +376,11 @@ class Net:
         self.init_weights(seed)
         if self.mode == "train":
             self.Wg = torch.zeros(self.nW, **f32)
-            self.Btg = torch.zeros(self.nBt, **f32)
+            # beta gradients + the STEP CONTROL BLOCK (8 floats behind them; zeroed with the gradients, summed over ranks
+            # with them): [0] grid-barrier timeouts of this step's one-launch BN backward, [1] ranks asking to stop.
+            # The optimiser launches test it (skip_ctl, include/mbx.h) and leave a flagged step un-applied.
+            self.Btg = torch.zeros(self.nBt + 8, **f32)
+            self.step_ctl = self.Btg[self.nBt:self.nBt + 8]
         self._alloc_scratch()
         self._build_backward()
         if torch.device(self.dev).type == "cuda":
@@ -462,12 +470,16 @@ class Net:
         self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
             ops.autotune(d, key)
-            # Data-parallel runs (bn_max_wg > 0: RCCL kernels of the bucket in flight hold CUs for milliseconds): the
-            # persistent igemm5 launch assigns its tiles to blocks STATICALLY and needs a whole CU per block, so a block
-            # that cannot start until an RCCL block leaves would finish its share late.  Use the library's igemm3 pick
-            # there (the grouped weight gradient is persistent too, but its blocks pull work from queues and steal).
-            if (self.bn_max_wg or os.environ.get("MBX_NO_I5") == "1") and d.tile_config > ops.I5_FLAG:
+            if os.environ.get("MBX_NO_I5") == "1" and d.tile_config > ops.I5_FLAG:   # A/B knob
                 d.tile_config = ops._TUNED.get(repr(key) + "#i3", 0)       # the best igemm3 tile the tuner saw, else the rule
+            # The persistent igemm5 launch needs a whole CU per workgroup; in data-parallel runs RCCL's kernels hold CUs
+            # for milliseconds, and a workgroup that starts late would finish a STATIC share of the tiles late.  Every
+            # igemm5 launch therefore gets a work counter (tiles after a workgroup's first are pulled from it, like the
+            # items of the grouped weight gradient) -- the same kernels with and without torch.distributed.
+            if d.tile_config > ops.I5_FLAG and os.environ.get("MBX_I5_STATIC") != "1":
+                assert self._i5_used < self.i5_counters.numel()
+                d.work_counter = self.i5_counters.data_ptr() + 4 * self._i5_used
+                self._i5_used += 1
             if os.environ.get("MBX_NO_2STAGE") == "1":                     # bisecting aid: 3-deep-ring twins of the 2-deep tiles
                 d.tile_config = {9: 7, 10: 2, 11: 5, 12: 2, 13: 8, 14: 1}.get(d.tile_config, d.tile_config)
         return d
@@ -628,7 +640,7 @@ class Net:
                     _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, int(op.relu), op.y.data_ptr(), M, K, mean.data_ptr(),
                                                     rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
                                                     op.dy.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
-                                                    self.bn_max_wg, s),
+                                                    self.bn_max_wg, self.step_ctl.data_ptr(), s),
                                "bn_bwd_onepass")
 
                 def pre(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, K=K, M=M):
@@ -641,8 +653,11 @@ class Net:
                     _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                   op.dy.data_ptr(), s), "bn_bwd_apply")
-                if op.bn_ws_off >= 0 and not self.no_onepass:
-                    pre = pre_onepass
+                if op.bn_ws_off >= 0:
+                    # chosen at CALL time: Trainer.check_health() falls back to the three launches (and re-captures its
+                    # graphs) when a grid barrier has timed out -- e.g. RCCL kernels holding more CUs than bn_max_wg allows for
+                    def pre(s, one=pre_onepass, three=pre):
+                        (three if self.no_onepass else one)(s)
             ddesc = None
             if op.need_dx:
                 gx = self._gview(op.x)
@@ -704,6 +719,8 @@ class Net:
                                              self.images.buf.data_ptr(), torch.cuda.current_stream().cuda_stream), "pack_input")
 
     def forward(self):
+        if self._i5_used:
+            self.i5_counters.zero_()               # (forward AND backward launches of this pass)
         for f in self.fwd_launches:
             f()
         return self.locs, self.logits
@@ -788,6 +805,8 @@ class Net:
     def backward(self):
         """d_locs / d_logits must hold the loss gradients; fills Wg / Btg.  (Eager form: all data-gradient launches,
         then the deferred weight gradients in four grouped launches; the Trainer interleaves them per segment.)"""
+        if self._i5_used:
+            self.i5_counters.zero_()
         for f in self.bwd_launches:
             f()
         self.run_deferred_wgrad()

@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("stats_partial", C.c_void_p),
         ("tile_config", C.c_int32),
         ("acc_src", C.c_void_p), ("acc_img_stride", C.c_int64), ("ld_acc", C.c_int32),
+        ("work_counter", C.c_void_p),
     ]
 
 
@@ -42,7 +43,7 @@ class WgradJob(C.Structure):
 class WgradPlanInfo(C.Structure):
     """mbx_wgrad_plan_info (include/mbx.h)."""
     _fields_ = [("n_layers", C.c_int32), ("n_items", C.c_int32), ("layers_off", C.c_int64), ("items_off", C.c_int64),
-                ("queues_off", C.c_int64), ("heads_off", C.c_int64), ("flops", C.c_double)]
+                ("queues_off", C.c_int64), ("heads_off", C.c_int64), ("flops", C.c_double), ("tally_off", C.c_int64)]
 
 
 class View:
@@ -247,3 +248,19 @@ class WgradGroup:
     def launch(self):
         _lib.check(_lib.lib().mbx_conv_wgrad_grouped(self.image.data_ptr(), C.byref(self.info), _stream()),
                    "mbx_conv_wgrad_grouped")
+
+    def tally(self):
+        """(work items processed, launches completed) since the image was uploaded -- host sync."""
+        o = int(self.info.tally_off)
+        t = self.image[o:o + 16].cpu().numpy().view("<u8")
+        return int(t[0]), int(t[1])
+
+    def completed_ok(self):
+        """Every completed launch processed all of its work items (a launch that finds stale queue heads processes
+        none and would leave dW at zero without any error)."""
+        items, launches = self.tally()
+        return items == launches * int(self.info.n_items)
+
+    def reset(self):
+        """Re-upload the plan image (queue heads, exit counter and tally back to zero)."""
+        self.image.copy_(torch.from_numpy(self.host_image))

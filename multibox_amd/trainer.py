@@ -74,6 +74,9 @@ class Trainer:
             net.fold_bn()
         self.use_graph = use_graph
         self.graphs = None
+        self.events = []                               # things a log should show (BN-backward fall-back, ...)
+        self._timeouts_seen = 0
+        self._stop_flag = torch.zeros((), **f32)       # request_stop(): copied into the step control block every step
         # backward segments = gradient buckets: data-parallel runs use more of them, so that the bucket that can only
         # start after the LAST backward launch (nothing left to overlap it with) is small
         if n_segments is None:
@@ -146,23 +149,56 @@ class Trainer:
                 net.fold_bn()
         self.refresh_frozen_reg()
 
+    def request_stop(self):
+        """Data-parallel runs: this rank cannot go on (its input is exhausted).  Raises word [1] of the step control block;
+        from the next step on the optimiser launches of EVERY rank skip the update (the word is summed over ranks with
+        the beta gradients) and check_health() reports `stop` on every rank at the next logging interval -- no per-step
+        host synchronisation (train.py used to all-reduce an `ok` flag and read it back before every step)."""
+        self._stop_flag.fill_(1.0)
+
     def check_health(self):
-        """Raise if the last step cannot be trusted, on ANY rank: a grid barrier of the one-launch batch-norm backward
-        timed out (its outputs were poisoned with NaN) or the matching failed (non-finite predictions / more boxes than
-        predictions -- the reference's py_func raises there, loss.py:82).  Host sync; call it at logging intervals."""
-        bad = torch.tensor([self.net.barrier_timeouts(), int(self.match_status().max() != 0)], dtype=torch.int32,
-                           device=self.net.W.device)
+        """Host sync; call it at logging intervals.  Verdict over ALL ranks on the steps since the last call:
+          * matching failed (non-finite predictions / more boxes than predictions; the reference's py_func raises there,
+            loss.py:82) -> raises;
+          * a grouped weight-gradient launch did not process every work item (stale queue heads after an aborted
+            launch would make every later launch compute NOTHING, silently) -> re-uploads the plan image and raises;
+          * a grid barrier of the one-launch batch-norm backward timed out (workgroups not co-resident: another
+            stream's kernels held more CUs than bn_max_workgroups left).  Those steps poisoned their gradients AND
+            raised word [0] of the step control block, so the optimiser did not apply them on any rank.  The trainer
+            falls back to the three-launch BN backward (no grid barrier), drops its captured graphs (re-captured in
+            this process by the next step()) and carries on; the event is recorded in self.events.  Raises only if
+            timeouts are seen after the fallback.
+        Returns {"stop": a rank called request_stop(), "fallback": this call switched the BN backward}."""
+        net = self.net
+        wg_bad = sum(0 if g.completed_ok() else 1 for g in getattr(self, "wgrad_groups", []))
+        bad = torch.tensor([net.barrier_timeouts() - self._timeouts_seen, int(self.match_status().max() != 0), wg_bad,
+                            int(float(net.step_ctl[1]) != 0.0 or float(self._stop_flag) != 0.0)], dtype=torch.int32, device=net.W.device)
         if self.pg is not None:
             import torch.distributed as dist
             if dist.get_world_size(self.pg) > 1:
                 dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.pg)
-        t, m = int(bad[0]), int(bad[1])
-        if t:
-            raise RuntimeError("batch-norm backward: %d grid-barrier timeout(s) (workgroups not co-resident); "
-                               "gradients of this step are poisoned -- lower MBX_BN_MAX_WG or set MBX_NO_BN_ONEPASS=1" % t)
+        t, m, w, stop = (int(v) for v in bad.tolist())
         if m:
             raise RuntimeError("bipartite matching failed on %d rank(s) (non-finite predictions or n_gt > P)" % m)
-        return True
+        if w:
+            for g in self.wgrad_groups:
+                g.reset()
+            raise RuntimeError("grouped weight gradient: %d launch group(s) did not process all their work items "
+                               "(queue heads re-uploaded)" % w)
+        out = {"stop": bool(stop), "fallback": False}
+        if t:
+            self._timeouts_seen = net.barrier_timeouts()
+            if net.no_onepass:
+                raise RuntimeError("batch-norm backward: %d grid-barrier timeout(s) AFTER the fall-back to the three-launch form" % t)
+            import sys
+            net.no_onepass = True                      # backward launches pick their BN form at call time (engine.py)
+            self.graphs = None                         # re-captured by the next step(), in this process
+            self.events.append({"event": "bn_backward_fallback", "global_step": self.global_step, "barrier_timeouts": t})
+            print("[multibox_amd] step %d: %d grid-barrier timeout(s) in the one-launch BN backward (workgroups not co-resident); "
+                  "the affected steps were NOT applied; continuing with the three-launch BN backward" % (self.global_step, t),
+                  file=sys.stderr)
+            out["fallback"] = True
+        return out
 
     # ------------------------------------------------------------------ segments / buckets
     def _make_segments(self, n):
@@ -250,7 +286,9 @@ class Trainer:
                 for f in fns:
                     f()
                 red.reduce_async(net.Wg, lo, hi)
-        red.reduce_async(net.Btg, self.bt_lo, net.nBt)
+        if red.enabled:
+            net.step_ctl[1:2].copy_(self._stop_flag)   # (Btg was zeroed inside the step: control word [1] = this rank's request)
+        red.reduce_async(net.Btg, self.bt_lo, net.nBt + 8)          # beta gradients + the step control block
         red.wait()
         self._optimizer()
         self.global_step += 1
@@ -271,6 +309,7 @@ class Trainer:
         self.lr = lr
         net.reg_loss.zero_()
         P = lambda t_, off=0: None if t_ is None else t_.data_ptr() + 4 * off
+        ctl = net.step_ctl.data_ptr()                  # non-zero -> every launch below is a no-op (poisoned step / stop request)
         for buf, lo, hi, on in self.opt_ranges:
             n = hi - lo
             if n <= 0:
@@ -278,13 +317,13 @@ class Trainer:
             if buf == "W":
                 _lib.check(l.mbx_rmsprop_ema_step(P(net.W, lo), P(net.Wg, lo), P(self.Wms, lo), P(self.Wmom, lo), P(self.Wema, lo),
                                                   net.Wb.data_ptr() + 2 * lo, n, lr, self.rms_decay, self.momentum, self.eps,
-                                                  WEIGHT_DECAY, d, on, net.reg_loss.data_ptr(), s), "rmsprop W")
+                                                  WEIGHT_DECAY, d, on, net.reg_loss.data_ptr(), ctl, s), "rmsprop W")
             else:
                 _lib.check(l.mbx_rmsprop_ema_step(P(net.Bt, lo), P(net.Btg, lo), P(self.Btms, lo), P(self.Btmom, lo), P(self.Btema, lo),
-                                                  None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, on, None, s), "rmsprop beta")
+                                                  None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, on, None, ctl, s), "rmsprop beta")
         lo, n = self.bt_lo, net.nBt - self.bt_lo
-        _lib.check(l.mbx_ema_update(P(self.MMema, lo), P(net.MM, lo), n, d, s), "ema moving_mean")
-        _lib.check(l.mbx_ema_update(P(self.MVema, lo), P(net.MV, lo), n, d, s), "ema moving_var")
+        _lib.check(l.mbx_ema_update(P(self.MMema, lo), P(net.MM, lo), n, d, ctl, s), "ema moving_mean")
+        _lib.check(l.mbx_ema_update(P(self.MVema, lo), P(net.MV, lo), n, d, ctl, s), "ema moving_var")
         net.prepare_filters()
 
     def losses(self):

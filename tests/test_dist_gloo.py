@@ -23,17 +23,17 @@ def _worker(rank, world, port, fine_tune, q):
     segs = tr._make_segments(4)
     gen = torch.Generator().manual_seed(rank)
     net.Wg.copy_(torch.randn(net.nW, generator=gen))
-    net.Btg.copy_(torch.randn(net.nBt, generator=gen))
+    net.Btg.copy_(torch.randn(net.nBt + 8, generator=gen))     # beta gradients + the step control block (engine.py)
     mine_w, mine_b = net.Wg.clone(), net.Btg.clone()
     red = BucketReducer(dist.group.WORLD)
     assert red.enabled
     for _, lo, hi in segs:
         red.reduce_async(net.Wg, lo, hi)
-    red.reduce_async(net.Btg, tr.bt_lo, net.nBt)
+    red.reduce_async(net.Btg, tr.bt_lo, net.nBt + 8)
     red.wait()
     other = torch.Generator().manual_seed(1 - rank)
     ow = torch.randn(net.nW, generator=other)
-    ob = torch.randn(net.nBt, generator=other)
+    ob = torch.randn(net.nBt + 8, generator=other)
     ok = torch.allclose(net.Wg[tr.w_lo:], (mine_w + ow)[tr.w_lo:]) and torch.allclose(net.Btg[tr.bt_lo:], (mine_b + ob)[tr.bt_lo:])
     ok = ok and torch.equal(net.Wg[:tr.w_lo], mine_w[:tr.w_lo])            # frozen range untouched
     ok = ok and shard_range(10, rank, world) == ((0, 5) if rank == 0 else (5, 10))
@@ -111,11 +111,22 @@ def _bcast_worker(rank, world, port, q):
     ref = Net(batch=1, input_size=299, k=5, mode="train", device="cpu", seed=2)
     ok = torch.equal(net.W, ref.W) and torch.equal(tr.Wema, ref.W) and float(tr.Wms[0]) == 1.0 and tr.global_step == 10
     ok = ok and (rank == 0 or not torch.equal(w_before, ref.W))
+    tr._timeouts_seen, tr._stop_flag, tr.events, tr.wgrad_groups = 0, torch.zeros(()), [], []
+    net.no_onepass = True                          # barrier_timeouts() -> 0 on CPU
+    # health: a stop request on ONE rank (its input is exhausted) is reported on EVERY rank, without raising
+
+    class OkLoss:
+        status = torch.zeros(2, dtype=torch.int32)
+    tr.loss = OkLoss()
+    ok = ok and tr.check_health() == {"stop": False, "fallback": False}
+    if rank == 1:
+        tr.request_stop()
+    ok = ok and tr.check_health()["stop"] is True
     # health: rank 1 reports a failed matching, both ranks must raise
+
     class FakeLoss:
         status = torch.tensor([0, 2 if rank == 1 else 0], dtype=torch.int32)
     tr.loss = FakeLoss()
-    net.no_onepass = True                          # barrier_timeouts() -> 0 on CPU
     try:
         tr.check_health()
         raised = False

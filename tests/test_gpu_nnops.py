@@ -135,7 +135,7 @@ def test_bn_backward_onepass(T, M, Cc, relu):
         ws = torch.zeros(nws, device="cuda")
         dbeta.fill_(1.0)
         _lib.check(l.mbx_bn_bwd_onepass(dav.ptr, dav.ld, relu, y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
-                                        beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), max_wg, S()))
+                                        beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), max_wg, None, S()))
         torch.cuda.synchronize()
         flags = ws[4 * 2 * Cc:4 * 2 * Cc + 2].view(torch.int32).tolist()
         assert flags[1] == 0, "grid barrier timed out"
@@ -313,7 +313,7 @@ def test_rmsprop_ema_step(T):
     reg = torch.zeros(1, device="cuda")
     for _ in range(2):
         _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), dg.data_ptr(), dms.data_ptr(), None, dema.data_ptr(), wb.data_ptr(), n,
-                                          lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), S()))
+                                          lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), None, S()))
     reg_ref = 0.0
     for _ in range(2):
         reg_ref += 0.5 * wd * float((w.astype(np.float64) ** 2).sum())
@@ -327,5 +327,17 @@ def test_rmsprop_ema_step(T):
     assert torch.equal(wb.float().cpu(), dw.to(torch.bfloat16).float().cpu())
     # frozen range: no update, EMA + bf16 refresh only
     w0 = dw.clone()
-    _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), None, None, None, dema.data_ptr(), wb.data_ptr(), n, lr, decay, 0.0, eps, wd, d, 0, None, S()))
+    _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), None, None, None, dema.data_ptr(), wb.data_ptr(), n, lr, decay, 0.0, eps, wd, d, 0, None, None, S()))
     assert torch.equal(dw, w0)
+    # step control block: a non-zero word (barrier timeouts | stop requests) makes the launch a no-op
+    for ctl in ([1.0, 0.0], [0.0, 2.0]):
+        skip = torch.tensor(ctl, device="cuda")
+        before = [t.clone() for t in (dw, dms, dema, wb, reg)]
+        _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), dg.data_ptr(), dms.data_ptr(), None, dema.data_ptr(), wb.data_ptr(), n,
+                                          lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), skip.data_ptr(), S()))
+        _lib.check(l.mbx_ema_update(dema.data_ptr(), dw.data_ptr(), n, d, skip.data_ptr(), S()))
+        assert all(torch.equal(a, b) for a, b in zip(before, (dw, dms, dema, wb, reg)))
+    skip = torch.zeros(2, device="cuda")
+    _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), dg.data_ptr(), dms.data_ptr(), None, dema.data_ptr(), wb.data_ptr(), n,
+                                      lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), skip.data_ptr(), S()))
+    assert not torch.equal(dw, w0)

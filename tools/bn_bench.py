@@ -27,7 +27,7 @@ for M, C in shapes:
 
     def one():
         ws.zero_()
-        _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, 1, y.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), 0, S()))
+        _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, 1, y.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), 0, None, S()))
 
     res = []
     for f in (three, one):

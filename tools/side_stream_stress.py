@@ -2,13 +2,46 @@
 RCCL's kernels overlap the backward pass, and of the input augmentation on a side stream): every parameter must stay
 finite.  Round 2 found the step's LDS-ring kernels reading a ring slot's previous contents about once in 10^5 launches
 under exactly this contention (bare s_barrier without compiler fences); tests/test_gpu_assembled.py runs this.
-usage: python tools/side_stream_stress.py [steps]      prints one JSON line"""
+usage: python tools/side_stream_stress.py [steps] [compare|infer] [saturate]      prints one JSON line
+  compare   (with MBX_DETERMINISTIC=1) the same steps without and with the noise must leave bit-identical parameters
+  saturate  noise = tools/noise.hip instead of the augmentation kernels: a 1 GB streaming copy (HBM), a float-atomics
+            storm (memory-side atomic units) and an L2 -> LDS LDS-DMA hammer, 1024 blocks each, looping on the second
+            stream with every CU oversubscribed -- the memory system as a 240 MB RCCL all-reduce leaves it"""
 import json
 import os
 import sys
 import threading
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def saturating_noise(torch):
+    """Returns launch(): one round of the three tools/noise.hip kernels on the CURRENT stream."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "_bin", "libnoise.so")
+    src = os.path.join(here, "noise.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.noise_launch.restype = C.c_int
+    lib.noise_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_void_p]
+    nbytes = 1 << 30
+    a = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+    b = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+    table = torch.zeros(1 << 24, dtype=torch.float32, device="cuda")          # 64 MB of atomic targets
+    l2 = torch.zeros(1 << 19, dtype=torch.int32, device="cuda")               # 2 MB: L2-resident source of the LDS-DMA hammer
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    keep = (a, b, table, l2, sink)
+
+    def launch(_keep=keep):
+        rc = lib.noise_launch(a.data_ptr(), b.data_ptr(), nbytes, table.data_ptr(), 1 << 24, l2.data_ptr(), 1 << 21,
+                              sink.data_ptr(), 7, 1, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+    return launch
 
 
 def main():
@@ -24,6 +57,7 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     if len(sys.argv) > 2 and sys.argv[2] == "infer":
         return infer_mode(steps)
+    saturate = "saturate" in sys.argv[2:]
     quiet_first = len(sys.argv) > 2 and sys.argv[2] == "compare"   # MBX_DETERMINISTIC=1 ... <steps> compare: the same steps
     #   without and with the noise must leave bit-identical parameters (finite-but-stale reads would show here)
     B, S, k = 64, 299, 5
@@ -45,12 +79,14 @@ def main():
     stop = threading.Event()
     launched = [0]
 
+    noise_launch = saturating_noise(torch) if saturate else aug.launch
+
     def noise():
         with torch.cuda.stream(side):
             while not stop.is_set():
-                for _ in range(8):
-                    aug.launch()
-                launched[0] += 8
+                for _ in range(2 if saturate else 8):
+                    noise_launch()
+                launched[0] += 6 if saturate else 8
                 side.synchronize()
     reference = None
     if quiet_first:
@@ -85,7 +121,9 @@ def main():
         if not same:
             d = (net.W != reference[0])
             print("parameters that differ:", int(d.sum()), "first index", int(d.nonzero()[0]) if d.any() else None, file=sys.stderr)
-    print(json.dumps({"steps": steps, "first_non_finite_check": first_bad, "noise_launches": launched[0], "bit_identical_to_quiet_run": same,
+    print(json.dumps({"steps": steps, "noise": "saturate (HBM copy + atomics + L2->LDS DMA)" if saturate else "augmentation kernels",
+                      "deterministic": bool(net.deterministic), "igemm5_launches": sum(1 for _, d, _ in net.tune_registry if d.tile_config > 32),
+                      "first_non_finite_check": first_bad, "noise_launches": launched[0], "bit_identical_to_quiet_run": same,
                       "losses": [float(v) for v in tr.losses()], "barrier_timeouts": int(net.barrier_timeouts())}))
 
 

@@ -109,37 +109,54 @@ def main():
                                  num_epochs=None, seed=int(cfg.get("RANDOM_SEED", 1)) + 1000 * rank, shuffle=True,   # train.py:214-225
                                  capacity=int(cfg.get("QUEUE_CAPACITY", 1000)), min_after_dequeue=int(cfg.get("QUEUE_MIN", 96)),
                                  device_augment=bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True)))   # resize / colour / flip on the GPU
-        # INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM: the augmentation kernels overlap the step on the prefetcher's stream
-        # (default) or are launched in front of each step on the training stream
+        # The augmentation kernels are launched in front of each step on the TRAINING stream (0.26 ms per batch; only the
+        # H2D upload rides the prefetcher's side stream).  INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM: true is an explicit opt-in
+        # to overlapping them with the step: they then compete for CUs with the one-workgroup-per-CU grid barrier of the
+        # BN backward (a timeout falls back to the three-launch form, Trainer.check_health) -- +0.5 % throughput at best.
         real = DevicePrefetcher(src, cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, device="cuda", depth=2,
-                                kernels_on_main=not bool(cfg.get("INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM", True)))
+                                kernels_on_main=not bool(cfg.get("INPUT_AUGMENT_KERNELS_ON_SIDE_STREAM", False)))
+
+    exhausted = [False]
 
     def next_real():
-        # an exhausted / empty file shard on ONE rank must stop every rank, not leave the others in all_reduce
-        try:
-            b = real.next()
-        except StopIteration:
-            b = None
-        if world > 1:
-            ok = torch.tensor([int(b is not None)], dtype=torch.int32, device="cuda")
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-            if int(ok) == 0:
-                b = None
-        if b is None:
-            real.close()
-            raise SystemExit("input exhausted on at least one rank at step %d" % tr.global_step)
-        return b
+        # An exhausted / empty file shard on ONE rank must stop every rank, not leave the others in all_reduce -- without
+        # a host sync per step: the rank raises the stop word of the step control block (Trainer.request_stop), which
+        # is summed over ranks with the gradients and makes every rank's optimiser skip from that step on; all ranks
+        # learn of it at the next health check (LOG_EVERY_N_STEPS) and leave together.  Until then this rank re-runs
+        # its last batch (the steps are not applied).
+        if not exhausted[0]:
+            try:
+                return real.next()
+            except StopIteration:
+                exhausted[0] = True
+                if world == 1:
+                    real.close()
+                    raise SystemExit("input exhausted at step %d" % tr.global_step)
+                tr.request_stop()
+        return None
 
     while tr.global_step < cfg.NUM_TRAIN_ITERATIONS:
         if real is not None:
-            images, gt, n, _ = next_real()                      # already on the device (prefetched two batches ahead)
-            tr.set_batch(images, gt, n)
+            b = next_real()                                     # already on the device (prefetched two batches ahead)
+            if b is not None:
+                tr.set_batch(b[0], b[1], b[2])
         else:
             images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
             tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
         tr.step()
-        if tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
-            tr.check_health()        # every rank: matching status (py_func error -> abort, loss.py:82) + barrier timeouts
+        if tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:       # (a collective: the same steps on every rank)
+            # every rank: matching status (py_func error -> abort, loss.py:82), barrier timeouts (-> in-process fall-back
+            # to the three-launch BN backward), weight-gradient work tallies, stop requests
+            health = tr.check_health()
+            if log is not None:
+                while tr.events:
+                    log.write(json.dumps(tr.events.pop(0)) + "\n")
+            if health["stop"]:
+                if real is not None:
+                    real.close()
+                if world > 1:
+                    torch.distributed.destroy_process_group()
+                raise SystemExit("input exhausted on at least one rank; stopped at step %d" % tr.global_step)
         if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
             loc, conf, reg, total = tr.losses()
             now = time.time()
