@@ -105,11 +105,12 @@ def timed_eager_pass(run, entry_points=None):
     """HIP events around every call of the listed libmbx entry points during run() (an eager pass on the current
     stream), the GPU parked behind a spin kernel while the host queues ahead.  What the event markers themselves add is
     MEASURED, not assumed: the same pass is timed once more WITHOUT the per-launch events (one event pair around the whole
-    pass, GPU parked the same way); (instrumented - plain) / pairs is subtracted from every interval, so the per-class
-    times add up to the GPU time of the un-instrumented pass -- which is what a rocprofv3 kernel trace of the same build
-    sums to (profiles/README.md, round 3; round 2 subtracted the 5 us of an EMPTY event pair, which over-corrected by
-    ~2.5 us per launch: 0.163 printed against 0.145 from the trace).  Returns ({class: dict(ms, raw_ms, work, calls,
-    bound)}, overhead per pair in ms, plain pass in ms)."""
+    pass, GPU parked the same way).  (instrumented - plain) / (2 x pairs) is the cost of ONE marker packet; the interval
+    between a launch's two timestamps holds the kernel (dispatch to completion: what a rocprofv3 kernel trace reports)
+    plus exactly one marker's processing, so one marker cost is subtracted from every interval.  Checked against the
+    rocprofv3 kernel trace of the same build (profiles/README.md, round 3).  Round 2 subtracted the 5 us an EMPTY event
+    pair reads, which over-corrected by ~1.3 us per launch: 0.163 printed against 0.145 from the trace.
+    Returns ({class: dict(ms, raw_ms, work, calls, bound)}, cost of one marker in ms, plain pass in ms)."""
     import torch
     from multibox_amd import _lib
     l = _lib.lib()
@@ -150,7 +151,7 @@ def timed_eager_pass(run, entry_points=None):
     finally:
         for n in names:
             setattr(l, n, orig[n])
-    pair_ms = max(inst_ms - plain_ms, 0.0) / max(len(recs), 1)
+    pair_ms = max(inst_ms - plain_ms, 0.0) / max(2 * len(recs), 1)       # one marker
     out = {}
     for cls, bound, work, a, b in recs:
         o = out.setdefault(cls, dict(ms=0.0, raw_ms=0.0, work=0.0, calls=0, bound=bound))
@@ -214,9 +215,10 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
             "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
             "ms_per_step": round(d["ms"], 3),
-            "timing": "HIP events around every launch of one eager pass, minus the MEASURED cost of the event markers: "
-                      "(instrumented pass - plain pass) / pairs; per-class times add up to the plain pass",
-            "event_pair_overhead_us": round(1e3 * pair_ms, 2), "eager_pass_ms": round(plain_ms, 3),
+            "timing": "HIP events around every launch of one eager pass; each interval = kernel (dispatch to completion, as "
+                      "in a rocprofv3 kernel trace) + one marker packet, whose MEASURED cost is subtracted: "
+                      "(instrumented pass - plain pass) / (2 x event pairs)",
+            "event_marker_us": round(1e3 * pair_ms, 2), "eager_pass_ms": round(plain_ms, 3),
             "frac_raw_event_intervals": round(d["work"] / (d["raw_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
             "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 3)}
     if whole_step_tflops is not None:

@@ -91,9 +91,13 @@ def main():
         # the host decodes and lays out the patches (detect.py:183-281); scaling + bilinear resize run on the GPU
         on_device = bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True))
         extractor = PatchExtractor(B, S) if on_device else None
-        batches = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch, device_patches=on_device)
+        # rank-sharded INPUT: this rank decodes only the records that feed its own batches
+        in_stats = {}
+        batches = ((b["batch_index"], b) for b in detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch,
+                                                                device_patches=on_device, rank=rank, world=world, stats=in_stats))
     else:
-        batches = synthetic_batches()
+        in_stats = None
+        batches = D.shard_batches(synthetic_batches(), rank, world)
     # Software pipeline: batch i+1 (input upload, patch extraction, forward, decode / filter / top-K, D2H of its results
     # into pinned buffers) is ENQUEUED before the host turns batch i's results into records, so the Python loop of
     # detect.py:408-443 runs while the GPU works.  Events, not synchronize(), bound each batch.
@@ -103,16 +107,30 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]      # start, forward, post-process, copied
     pending = None
 
+    # The record text (float repr of ~17 000 numbers per batch: ~10 ms of pure host work) is produced by worker
+    # PROCESSES (NUM_RECORD_WORKERS, default 3; spawned: no fork after the GPU is initialised; numpy + json only), so this
+    # thread only feeds the GPU.  0 = in this process.
+    n_workers = int(cfg.get("NUM_RECORD_WORKERS", 3))
+    pool = None
+    if n_workers > 0:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        pool = ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn"))
+    from multibox_amd import records as REC
+
     def finish(p):
         slot, bi_, ids_ = p
         ev[slot][3].synchronize()
         hb, hs, hc = host_out[slot]
-        results.append((bi_, D.results_to_json_records(hb.numpy(), hs.numpy(), hc.numpy(), ids_)))
+        if pool is not None:
+            results.append((bi_, pool.submit(REC.batch_chunk, hb.numpy().copy(), hs.numpy().copy(), hc.numpy().copy(), ids_)))
+        else:
+            results.append((bi_, REC.batch_chunk(hb.numpy(), hs.numpy(), hc.numpy(), ids_)))
         print("Step: %d, Time/image (ms): %.1f, Post-process/image (ms): %.3f" % (
             len(results), ev[slot][0].elapsed_time(ev[slot][1]) / B, ev[slot][1].elapsed_time(ev[slot][2]) / B))
 
     t_all = time.time()
-    for bi, batch in D.shard_batches(batches, rank, world):
+    for bi, batch in batches:
         meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
                                  batch["max_to_keep"], batch["image_hw"])
         slot = step % 2
@@ -137,15 +155,27 @@ def main():
     if pending is not None:
         finish(pending)
     if step:
-        print("rank %d: %d patches in %.2f s (%.0f patches/s, input + forward + post-process + records)" % (
-            rank, step * B, time.time() - t_all, step * B / max(time.time() - t_all, 1e-9)))
+        print("rank %d: %d patches in %.2f s (%.0f patches/s, input + forward + post-process + records)%s" % (
+            rank, step * B, time.time() - t_all, step * B / max(time.time() - t_all, 1e-9),
+            "" if not in_stats else "; decoded %d of %d records" % (in_stats.get("decoded", 0), in_stats.get("records", 0))))
+    n_records = 0
+    for i, (bi_, r) in enumerate(results):           # collect the workers' chunks: (batch index, [records joined with ", "])
+        n, text = r.result() if pool is not None else r
+        n_records += n
+        results[i] = (bi_, [text])
+    if pool is not None:
+        pool.shutdown()
     results = D.gather_results(results)
+    if world > 1:
+        cnt = torch.tensor([n_records], dtype=torch.int64)
+        torch.distributed.all_reduce(cnt)
+        n_records = int(cnt)
     if rank == 0:
         os.makedirs(args.save_dir, exist_ok=True)
         save_path = os.path.join(args.save_dir, "results-dense-%d.json" % global_step)
         with open(save_path, "w") as f:
-            f.write(json.dumps(results))       # same text as json.dump(results, f), through the C encoder (6x faster at 350k records)
-        print("wrote", save_path, len(results), "detections")
+            f.write(D.records_to_json(results))        # the same text as json.dump(list of record dicts, f)
+        print("wrote", save_path, n_records, "detections")
     if world > 1:
         torch.distributed.destroy_process_group()
 

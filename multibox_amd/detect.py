@@ -98,6 +98,9 @@ def results_to_json_records(boxes, scores, count, image_ids):
     return out
 
 
+from .records import results_to_json_text, batch_chunk, records_to_json      # noqa: E402,F401  (torch-free: run in worker processes)
+
+
 # ----------------------------------------------------------------------------- multi-GPU detect
 # Patches are independent (per-patch loop, detect.py:408): ranks take disjoint batches, NO collective on the data
 # path; at the end rank 0 concatenates the per-rank result lists into the one JSON of detect.py:458-460.

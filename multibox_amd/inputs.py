@@ -108,30 +108,63 @@ def detect_patches_for_image(image01, image_hw, cfg):
     return patches, offs, dims, flips, rests, keeps
 
 
-def _decoded_ahead(examples, threads, window=32):
-    """(example, decoded uint8 image) in record order, the JPEG decodes running `threads` at a time ahead of the
-    consumer (PIL releases the GIL while it decodes)."""
+def _decoded_ahead(planned, threads, window=32):
+    """(example, plan, mine, decoded uint8 image or None) in record order for _planned_examples() items: the JPEGs of the
+    records this rank needs are decoded `threads` at a time ahead of the consumer (PIL releases the GIL while it
+    decodes); the others pass through undecoded."""
     if threads <= 1:
-        for ex in examples:
-            yield ex, decode_image_u8(ex["image/encoded"][0])
+        for ex, plan, mine in planned:
+            yield ex, plan, mine, (decode_image_u8(ex["image/encoded"][0]) if mine else None)
         return
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=threads) as pool:
         pending = deque()
-        for ex in examples:
-            pending.append((ex, pool.submit(decode_image_u8, ex["image/encoded"][0])))
+        for ex, plan, mine in planned:
+            pending.append((ex, plan, mine, pool.submit(decode_image_u8, ex["image/encoded"][0]) if mine else None))
             if len(pending) >= window:
-                e, f = pending.popleft()
-                yield e, f.result()
+                e, pl, m, f = pending.popleft()
+                yield e, pl, m, (f.result() if f is not None else None)
         while pending:
-            e, f = pending.popleft()
-            yield e, f.result()
+            e, pl, m, f = pending.popleft()
+            yield e, pl, m, (f.result() if f is not None else None)
 
 
-def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patches=False, decode_threads=None):
+def jpeg_size(jpeg_bytes):
+    """(height, width) from the JPEG header alone (PIL parses the header on open; nothing is decoded)."""
+    from PIL import Image
+    with Image.open(io.BytesIO(jpeg_bytes)) as im:
+        w, h = im.size
+    return int(h), int(w)
+
+
+def _planned_examples(examples, cfg, batch_size, rank, world, stats):
+    """(example, patch plan, mine) in record order.  `mine`: at least one patch of the record falls into a batch this
+    rank owns (batch i of the global patch stream belongs to rank i % world).  The plan only needs the picture's size,
+    which comes from the JPEG header: records that are not `mine` are never decoded."""
+    g = 0
+    for ex in examples:
+        hw = (int(ex["image/height"][0]), int(ex["image/width"][0]))
+        H, W = jpeg_size(ex["image/encoded"][0])
+        plan = detect_patch_plan(H, W, hw, cfg)
+        n = len(plan)
+        mine = world == 1 or (n > 0 and any(b % world == rank for b in range(g // batch_size, (g + n - 1) // batch_size + 1)))
+        g += n
+        if stats is not None:
+            stats["records"] = stats.get("records", 0) + 1
+            stats["decoded"] = stats.get("decoded", 0) + int(mine)
+        yield ex, plan, mine
+
+
+def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patches=False, decode_threads=None, rank=0,
+                   world=1, stats=None):
     """Yield dicts of numpy arrays: images [B,S,S,3], offsets [B,2], dims [B,2], is_flipped [B,1],
-    restrictions [B,4], max_to_keep [B,1], image_hw [B,2], image_ids [B] -- the fetches of detect.py:398-406.
+    restrictions [B,4], max_to_keep [B,1], image_hw [B,2], image_ids [B] -- the fetches of detect.py:398-406 -- plus
+    "batch_index", the batch's position in the single-process stream (tf.train.batch order, detect.py:283-292).
+    rank / world (ranks write disjoint result lists): only the batches with batch_index % world == rank are
+    yielded, and only the records that contribute a patch to one of them are DECODED -- the others are walked by their
+    header (size -> number of patches) so that the batching stays exactly the single-process one.  stats (a dict)
+    counts "records" seen and "decoded".
     device_patches=True leaves the pixels to the GPU (mbx_extract_patches): instead of "images" a batch carries
     "sources" (the decoded uint8 images it touches) and "patches" [(source index, window, flip_source) or None for
     padding]: multibox_amd.augment.PatchExtractor turns them into the [B,S,S,3] tensor on the device.  The JPEGs are
@@ -163,20 +196,42 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patche
             del buf[k][:batch_size]
         return out
     threads = int(decode_threads if decode_threads is not None else cfg.get("NUM_INPUT_THREADS", 4)) if device_patches else 1
-    for ex, u8 in (_decoded_ahead(_records(tfrecords), threads) if device_patches else ((e, None) for e in _records(tfrecords))):
+    planned = _planned_examples(_records(tfrecords), cfg, batch_size, rank, world, stats)
+    if world == 1 and not device_patches:
+        decoded = ((ex, plan, True, None) for ex, plan, _ in planned)
+    else:
+        decoded = _decoded_ahead(planned, threads)
+    next_index = [0]
+
+    def emit_mine():
+        """Cut the next batch off the buffers; None if another rank owns it (its pixels were never produced)."""
+        i = next_index[0]
+        next_index[0] += 1
+        if i % world != rank:
+            for k in buf:
+                del buf[k][:batch_size]
+            return None
+        out = emit()
+        out["batch_index"] = i
+        return out
+    for ex, plan, mine, u8 in decoded:
         hw = (int(ex["image/height"][0]), int(ex["image/width"][0]))
         image_id = ex["image/id"][0].decode("utf-8")
-        if device_patches:
-            plan = detect_patch_plan(u8.shape[0], u8.shape[1], hw, cfg)
+        o, d, f, r, k = ([e[i] for e in plan] for i in (2, 3, 4, 5, 6))
+        if not mine:
+            p = [None] * len(plan)                     # placeholders: these patches only ever land in other ranks' batches
+        elif device_patches:
             p = [(u8, win, fs) for win, fs, _, _, _, _, _ in plan]
-            o, d, f, r, k = ([e[i] for e in plan] for i in (2, 3, 4, 5, 6))
         else:
-            p, o, d, f, r, k = detect_patches_for_image(decode_image(ex["image/encoded"][0]), hw, cfg)
+            image01 = (u8.astype(np.float32) * np.float32(1.0 / 255.0)) if u8 is not None else decode_image(ex["image/encoded"][0])
+            p, o, d, f, r, k = detect_patches_for_image(image01, hw, cfg)
         buf["images"] += p; buf["offsets"] += o; buf["dims"] += d; buf["is_flipped"] += f
         buf["restrictions"] += r; buf["max_to_keep"] += k
         buf["image_hw"] += [hw] * len(p); buf["image_ids"] += [image_id] * len(p)
         while len(buf["images"]) >= batch_size:
-            yield emit()
+            b = emit_mine()
+            if b is not None:
+                yield b
     if keep_partial and buf["images"]:
         n = len(buf["images"])
         pad = batch_size - n
@@ -184,7 +239,9 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patche
         buf["offsets"] += [(0, 0)] * pad; buf["dims"] += [(S, S)] * pad; buf["is_flipped"] += [0] * pad
         buf["restrictions"] += [(0., 0., 1., 1.)] * pad; buf["max_to_keep"] += [0] * pad      # keep nothing of the padding
         buf["image_hw"] += [(S, S)] * pad; buf["image_ids"] += [buf["image_ids"][-1]] * pad
-        yield emit()
+        b = emit_mine()
+        if b is not None:
+            yield b
 
 
 # ------------------------------------------------------------------ other resize methods (legacy TF kernels)

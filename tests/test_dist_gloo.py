@@ -71,14 +71,48 @@ def _detect_worker(rank, world, port, q):
     if rank == 0:
         single = D.merge_results([[(bi, [{"image_id": i, "bbox": [0.0, 0.0, 1.0, 1.0], "score": 1.0 / (1 + i)} for i in b["ids"]])
                                    for bi, b in enumerate(batches)]])
-        q.put((rank, merged == single and [r["image_id"] for r in merged] == list(range(28)), len(local)))
+        ok = merged == single and [r["image_id"] for r in merged] == list(range(28))
     else:
-        q.put((rank, merged is None, len(local)))
+        ok = merged is None
+    # ---- the INPUT is sharded too: from real JPEG records, each rank decodes only the records that feed
+    # its own batches; the merged result text is byte-identical to the single-process file
+    import json
+    import numpy as np
+    from multibox_amd import inputs as I, records as REC
+    from multibox_amd.config import Cfg
+    path = os.path.join(os.environ["MBX_TEST_TMP"], "shard.tfrecords")
+    cfg = Cfg(dict(INPUT_SIZE=64, DETECTION=dict(USE_ORIGINAL_IMAGE=True, ORIGINAL_IMAGE_MAX_TO_KEEP=5, USE_FLIPPED_ORIGINAL_IMAGE=True,
+                   FLIPPED_IMAGE_MAX_TO_KEEP=5, CROPS=[dict(HEIGHT=48, WIDTH=48, HEIGHT_STRIDE=40, WIDTH_STRIDE=40, FLIP=False, MAX_TO_KEEP=3)])))
+
+    def fake_results(b):
+        """Deterministic 'detections' of a batch from its own pixels and metadata (stands in for the GPU forward)."""
+        B = len(b["image_ids"])
+        px = np.stack([b["images"][i][:2, :2, 0].reshape(-1) for i in range(B)]).astype(np.float64)      # [B, 4]
+        boxes = np.repeat(px[:, None, :], 5, 1) + b["offsets"][:, None, :1] + np.arange(5)[None, :, None] * 0.125
+        scores = (boxes[:, :, 0] * 0.01).astype(np.float32)
+        count = np.minimum(b["max_to_keep"].reshape(-1), 5).astype(np.int32)
+        ids = [int(i) for i in b["image_ids"]]
+        return REC.batch_chunk(boxes, scores, count, ids)
+    st = {}
+    mine = [(b["batch_index"], [fake_results(b)[1]]) for b in I.detect_batches([path], cfg, 4, keep_partial=True, rank=rank, world=world, stats=st)]
+    merged2 = D.gather_results(mine)
+    if rank == 0:
+        st1 = {}
+        single2 = [fake_results(b)[1] for b in I.detect_batches([path], cfg, 4, keep_partial=True, stats=st1)]
+        text_single = REC.records_to_json(single2)
+        ok = ok and REC.records_to_json(merged2) == text_single and len(json.loads(text_single)) > 20
+        ok = ok and st1 == {"records": 6, "decoded": 6}
+    ok = ok and st["records"] == 6 and 0 < st["decoded"] < 6          # this rank skipped whole records without decoding them
+    q.put((rank, bool(ok), len(local), st["decoded"]))
     dist.destroy_process_group()
 
 
-def test_detect_sharding_world2():
+def test_detect_sharding_world2(tmp_path):
     import torch.multiprocessing as mp
+    from tests.test_inputs_cpu import _make_records
+    # six pictures of different sizes: 2 + (number of 48x48 windows at stride 40) patches each, batches of 4
+    _make_records(str(tmp_path / "shard.tfrecords"), [(64, 64, []), (100, 140, []), (90, 90, []), (64, 200, []), (130, 64, []), (70, 75, [])])
+    os.environ["MBX_TEST_TMP"] = str(tmp_path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)
@@ -88,7 +122,8 @@ def test_detect_sharding_world2():
     res = sorted(q.get(timeout=300) for _ in ps)
     for p in ps:
         p.join(60)
-    assert res == [(0, True, 4), (1, True, 3)]
+    assert [r[:3] for r in res] == [(0, True, 4), (1, True, 3)], res
+    assert all(0 < r[3] < 6 for r in res), res                      # decode counts: nobody decoded every record
 
 
 def _bcast_worker(rank, world, port, q):

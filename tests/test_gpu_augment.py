@@ -1,7 +1,11 @@
-"""mbx_augment_batch (row F1 on the GPU) against the host restatement of the reference's augmentation ops
-(multibox_amd/inputs.py: apply_plan = crop, tf.image.resize_images with the drawn method, distort_color, flip).
-Resize-only items must be BIT-IDENTICAL to the host arithmetic; colour ops run in float64 on both sides and may differ
-through the summation order of the contrast mean only: |diff| <= 1e-6 on the [-1,1] output."""
+"""mbx_augment_batch (row F1 on the GPU).
+(1) Against the ORACLE, oracle/ref_inputs.py -- the independent per-pixel restatement of the reference's augmentation ops
+    (crop, tf.image.resize_images with the drawn method, distort_color, flip, scaling; inputs.py:44-98, 272-351): bilinear /
+    nearest bit-exact (TF's float32 kernel order is the definition), bicubic / area / colour within 2e-6 on [-1, 1]
+    (float64 on both sides, different summation orders) -- test_device_path_against_the_oracle.
+(2) Against the product's own HOST path (multibox_amd/inputs.py apply_plan), which the workers run when
+    INPUT_AUGMENT_ON_DEVICE is false: the two product paths must agree bit for bit on resize-only items and within
+    1e-6 with colour ops, at full picture sizes the per-pixel oracle is too slow for."""
 import numpy as np
 import pytest
 
@@ -32,6 +36,35 @@ def _run(cases, S):
     out = aug.run()
     torch.cuda.synchronize()
     return out.cpu().numpy()
+
+
+def test_device_path_against_the_oracle():
+    from multibox_amd import inputs as I
+    from oracle import ref_inputs as O
+    rng = np.random.RandomState(21)
+    S = 48
+    cases = []
+    for (h, w) in [(97, 61), (48, 48), (30, 130), (75, 40)]:
+        u8 = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for method in range(4):
+            cases.append((u8, _plan(method, [], bool(rng.randint(2)))))
+    u8 = rng.randint(0, 256, (90, 120, 3)).astype(np.uint8)
+    for method in range(4):                                   # crops: the worker hands over only the window
+        cases.append((u8, _plan(method, [], False, crop=(11, 17, 61, 83))))
+    for ordering in range(4):                                 # the four colour orders of inputs.py:71-91, then the fast ones
+        u8 = rng.randint(0, 256, (rng.randint(40, 90), rng.randint(40, 90), 3)).astype(np.uint8)
+        cases.append((u8, _plan(ordering, I.color_ops(ordering, False, rng), bool(ordering & 1))))
+    for ordering in range(2):
+        u8 = rng.randint(0, 256, (50, 70, 3)).astype(np.uint8)
+        cases.append((u8, _plan(0, I.color_ops(ordering, True, rng), False)))
+    got = _run(cases, S)
+    for i, (u8, plan) in enumerate(cases):
+        want = O.augment_pixels(u8.astype(np.float32) * np.float32(1.0 / 255.0), plan.crop, plan.method, plan.color, plan.flip,
+                                S, scale_to_pm1=True)
+        if plan.method in (O.BILINEAR, O.NEAREST) and not plan.color:
+            assert np.array_equal(got[i], want), "case %d method %d: max diff %g" % (i, plan.method, np.abs(got[i] - want).max())
+        else:
+            np.testing.assert_allclose(got[i], want, rtol=0, atol=2e-6, err_msg="case %d" % i)
 
 
 @pytest.mark.parametrize("S", [299, 64])

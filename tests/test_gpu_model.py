@@ -358,3 +358,85 @@ def test_overfits_one_batch(env):
     assert int(tr.match_status().max()) == 0 and net.barrier_timeouts() == 0
     assert np.isfinite(last[3]) and last[3] < first[3] / 8.0, (first, last)
     assert last[0] < first[0] / 8.0 and last[1] < first[1] / 4.0, (first, last)      # both terms of loss.py:100-101
+
+
+def test_full_depth_backward_frozen_statistics():
+    """ONE tight end-to-end check of the assembled full-depth (10 / 20 / 9) backward pass -- all 409
+    convolution launches, the out-of-place trunk gradients, the deferred grouped weight gradients reading every kept dy.
+    Batch-statistics BN makes a random-init 100-layer network chaotic (the two torch oracles agree with each other only to
+    cos 0.57 there), so this test uses the engine's test-only `bn_frozen_stats` mode: batch norm normalises with FIXED
+    statistics (calibrated once: the batch statistics of this very batch, so activations are O(1) at every depth) while
+    every layer stays trainable and gradients flow through the normalisation -- exactly what oracle/torch_model.py
+    computes with bn_training=False.  No batch reduction anywhere => well-posed.  MBX_DETERMINISTIC=1 (no atomics).
+    Stated tolerance, per variable whose gradient is not negligible (norm > 1e-3 of the median): cosine >= 0.999 and
+    relative L2 error <= 2e-2 against the bf16-emulating oracle on the same weights, batch and matching."""
+    import os
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd.engine import Net
+    from multibox_amd import priors as PR
+    from multibox_amd.loss import MultiboxLoss
+    from oracle.torch_model import Model, q_bf16, multibox_loss
+    B = 8
+    old = os.environ.get("MBX_DETERMINISTIC")
+    os.environ["MBX_DETERMINISTIC"] = "1"
+    try:
+        net = Net(batch=B, input_size=299, k=5, mode="train", seed=5, bn_frozen_stats=True)
+    finally:
+        if old is None:
+            os.environ.pop("MBX_DETERMINISTIC")
+        else:
+            os.environ["MBX_DETERMINISTIC"] = old
+    assert net.deterministic and net.bn_frozen_stats and net.repeats == (10, 20, 9)
+    gen = torch.Generator().manual_seed(11)
+    net.Bt.copy_((torch.randn(net.nBt, generator=gen) * 0.1).cuda())
+    images = torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1
+    priors = np.array(PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]), np.float32)
+    rng = np.random.RandomState(4)
+    n_gt = np.array([3, 0, 13, 1, 5, 2, 7, 4], np.int32)
+    gt = np.zeros((B, 13, 4), np.float32)
+    for b in range(B):
+        xy = rng.uniform(0, .7, (n_gt[b], 2)); wh = rng.uniform(.05, .3, (n_gt[b], 2))
+        gt[b, :n_gt[b], :2] = xy; gt[b, :n_gt[b], 2:] = xy + wh
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    # ---- calibration: this batch's statistics become the (fixed) moving statistics of both models
+    P0 = oracle_params(torch, net)
+    with torch.no_grad():
+        cal = Model(P0, k=5, bn_training=True, q=q_bf16, bn_decay=0.0)       # decay 0: new moving value = batch value
+        cal.build(images)
+    for scope, (mean, var) in cal.new_moving.items():
+        net.set_param(scope + "/BatchNorm/moving_mean", mean)
+        net.set_param(scope + "/BatchNorm/moving_variance", var)
+        P0[scope + "/BatchNorm/moving_mean"], P0[scope + "/BatchNorm/moving_variance"] = mean.clone(), var.clone()
+    net.load_frozen_stats()
+    # ---- engine: forward, matching + loss, backward
+    net.set_input(images.cuda())
+    net.forward()
+    ml = MultiboxLoss(priors, B, 13, 1000.0)
+    ml.d_locs, ml.d_logits = net.d_locs, net.d_logits
+    ml.forward_backward(net.locs, net.logits, torch.from_numpy(gt).cuda(), torch.from_numpy(n_gt).cuda())
+    net.zero_grads()
+    net.backward()
+    torch.cuda.synchronize()
+    assert int(ml.status.max()) == 0
+    match = ml.match.cpu().numpy()
+    # ---- oracle in the same mode, same matching
+    P = {k_: v.clone().requires_grad_(True) for k_, v in P0.items()}
+    m = Model(P, k=5, bn_training=False, q=q_bf16)
+    rl, rz = m.build(images)
+    loc, conf = multibox_loss(rl, rz, torch.from_numpy(priors), torch.from_numpy(gt), match, 1000.0)
+    (loc + conf).backward()
+    # forward first (a wrong forward would make the gradient comparison meaningless)
+    assert rel_l2(net.locs.cpu(), rl.detach()) < 2e-2 and rel_l2(net.logits.cpu(), rz.detach()) < 2e-2
+    names = [n for n in net.param_index if n.endswith(("/weights", "/biases", "/beta"))]
+    gq = {n: P[n].grad for n in names}
+    ge = {n: net.get_param(n, "grad").detach().float().cpu() for n in names}
+    assert all(bool(torch.isfinite(ge[n]).all()) for n in names)
+    med = np.median([float(gq[n].norm()) for n in names])
+    big = [n for n in names if float(gq[n].norm()) > 1e-3 * med]
+    assert len(big) > 0.9 * len(names), (len(big), len(names))
+    worst_cos = min(((_cos(ge[n], gq[n]), n) for n in big))
+    worst_l2 = max(((rel_l2(ge[n], gq[n]), n) for n in big))
+    assert worst_cos[0] >= 0.999, worst_cos
+    assert worst_l2[0] <= 2e-2, worst_l2

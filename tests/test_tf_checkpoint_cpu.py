@@ -1,6 +1,7 @@
 """TF V1 checkpoint reader / writer and the restore modes of train.py:15-90.
 No TF-written file exists in this environment (parity unpinned, see multibox_amd/tf_checkpoint.py): the reader is
 checked against hand-built byte strings of the public formats and against the module's own writer."""
+import os
 import struct
 import types
 
@@ -181,3 +182,49 @@ def test_export_restore_modes(tmp_path, nets):
     with pytest.raises(ValueError) as ei:
         T.restore(None, dst, tensors=bad)
     assert "Conv2d_1a_3x3" in str(ei.value)
+
+
+def test_reader_against_an_independently_written_checkpoint(tmp_path):
+    """Row F2's pin: tests/golden/tf_v1_fixture.ckpt is a V1 checkpoint written from TensorFlow's
+    PUBLISHED format by tools/make_tf_ckpt_fixture.py, which shares no code with the reader -- protobufs serialised by
+    the google.protobuf runtime from the published field numbers, OrderedCode slice keys, leveldb blocks WITH prefix
+    compression, shortened index separators, snappy-compressed and raw blocks, masked crc32c.  It holds float / double /
+    int32 / int64 tensors, scalars and two PARTITIONED variables (rows 0:4 | 4:8 and columns 0:192 | 192:400).
+    NO TF-WRITTEN FILE EXISTS IN THIS IMAGE (the reference ships none; TF 0.11 cannot be installed): this is an
+    independent implementation of the same specification, not TensorFlow's own bytes."""
+    import subprocess
+    import sys
+    from multibox_amd import tf_checkpoint as TF
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    got = TF.load(os.path.join(gold, "tf_v1_fixture.ckpt"), verify=True)          # every block checksum verified
+    want = {k.replace("|", "/"): v for k, v in np.load(os.path.join(gold, "tf_v1_fixture.npz")).items()}
+    assert sorted(got) == sorted(want) and len(want) == 14
+    for k, w in want.items():
+        assert got[k].shape == w.shape and got[k].dtype == w.dtype and np.array_equal(got[k], w), k
+    assert got["global_step"].shape == () and int(got["global_step"]) == 123456
+    assert np.array_equal(got["fixture/partitioned"], np.arange(48, dtype=np.float32).reshape(8, 6) * 0.5)
+    # the table really exercises what the reader's own writer never produces: shared key prefixes and snappy blocks
+    raw = open(os.path.join(gold, "tf_v1_fixture.ckpt"), "rb").read()
+    kinds, shared = set(), 0
+    buf = memoryview(raw)
+    footer = buf[-48:]
+    _, i = TF._varint(footer, 0); _, i = TF._varint(footer, i)
+    ioff, i = TF._varint(footer, i); isize, i = TF._varint(footer, i)
+    for _, handle in TF._block_entries(TF._read_block(buf, ioff, isize, True)):
+        boff, j = TF._varint(handle, 0); bsize, j = TF._varint(handle, j)
+        kinds.add(raw[boff + bsize])
+        blk = TF._read_block(buf, boff, bsize, True)
+        k = 0
+        s, k = TF._varint(blk, 0)
+        end = len(blk) - 4 - 4 * struct.unpack("<I", blk[-4:])[0]
+        pos = 0
+        while pos < end:
+            sh, pos = TF._varint(blk, pos); ns, pos = TF._varint(blk, pos); vl, pos = TF._varint(blk, pos)
+            shared += sh > 0
+            pos += ns + vl
+    assert kinds == {0, 1} and shared >= 5
+    # the committed fixture is exactly what the committed script writes
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(gold), "..", "tools", "make_tf_ckpt_fixture.py"), str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert open(str(tmp_path / "tf_v1_fixture.ckpt"), "rb").read() == raw
