@@ -53,7 +53,12 @@ conv_igemm3_kernel(const ConvK p) {
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
   const int lrow = tid >> 3;
-  const int chunk = (tid & 7) ^ (lrow & 7);            // source chunk of this lane's LDS slot
+  const int chunk = (tid & 7) ^ (lrow & 7);            // source chunk of this lane's LDS slot (pixel tile)
+  // The FILTER tile has its own swizzle: its rows are read by the MFMA A operand in a PERMUTED order (see the epilogue:
+  // a lane must end up with 8 consecutive output channels), rows 8 (f >> 2) + (f & 3) + 4 (a & 1) + 32 (a >> 1) for
+  // fragment row f of block a, and the key ((row >> 3) & 3) << 1 | (row >> 1) & 1 makes exactly those reads
+  // bank-conflict free (the 16 lanes a ds_read_b128 services together hit 16 different 16-byte bank groups).
+  const int chunkw = (tid & 7) ^ ((((lrow >> 3) & 3) << 1) | ((lrow >> 1) & 1));
   int hb[PI], wb[PI], ro[PI];
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
@@ -84,6 +89,10 @@ conv_igemm3_kernel(const ConvK p) {
   // fragment read offsets (16-B slots): row*8 + ((kk*4 + fch) ^ (row & 7)); row & 7 == frow & 7
   const int fr0 = frow * 8 + (fch ^ (frow & 7));
   const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
+  // filter fragments: block a reads tile rows 32 (a >> 1) + 4 (a & 1) + [8 (frow >> 2) + (frow & 3)]  (slot = row * 8 + chunk ^ key)
+  const int fwrow = 8 * (frow >> 2) + (frow & 3), fwkey = ((frow >> 2) << 1) | ((frow >> 1) & 1);
+  const int fw0 = fwrow * 8 + (fch ^ fwkey);
+  const int fw1 = fwrow * 8 + ((4 + fch) ^ fwkey);
   // stride-2 data gradient, tile inside one parity class: only taps with kr = kr0 (mod 2), ks = ks0 (mod 2) meet
   // non-zero rows of the dilated input -- walk those only (steps of 2), a quarter of the K tiles
   int kr0 = 0, ks0 = 0, kstep = 1, nk = (p.Ktot + 63) >> 6;
@@ -125,10 +134,14 @@ conv_igemm3_kernel(const ConvK p) {
         glds16(xr, sp + i * NT, ok ? (ro[i] + ((hn >> 1) * p.W_in + (wn_ >> 1)) * ldx2 + kc * 2) : (int)kOOB); \
       }                                                                                                      \
     }                                                                                                        \
-    const int kb = SH ? ((kr * p.S + ks) * p.C_in + kc) * 2 : ((LT) * 64 + chunk * 8) * 2;                   \
+    /* the filter lane's own K position (its chunk differs from the pixel lane's): linear in K, except in the     \
+       tap-skipping walk, where C_in % 64 == 0 and a K tile lies inside one tap */                             \
+    const int kb = (SH && kstep == 2) ? ((kr * p.S + ks) * p.C_in + kc + (chunkw - chunk) * 8) * 2                \
+                                      : ((LT) * 64 + chunkw * 8) * 2;                                          \
+    const bool kvw = (SH && kstep == 2) ? kv : (kb < p.Ktot * 2);                                              \
     u32x4* sw = sp + BM * 8;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                           \
-      glds16(wr, sw + i * NT, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                                \
+      glds16(wr, sw + i * NT, (kvw && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                               \
     kc += 64;                                                                                                \
     while (kc >= p.C_in) { kc -= p.C_in; if ((ks += kstep) >= p.S) { ks = ks0; kr += kstep; } }              \
     st_issue = st_issue == NSTG - 1 ? 0 : st_issue + 1;                                                      \
@@ -172,10 +185,10 @@ conv_igemm3_kernel(const ConvK p) {
       const u32x4* cW = smem + st_prev * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int fr = kk ? fr1 : fr0;
+        const int fr = kk ? fr1 : fr0, fw = kk ? fw1 : fw0;
         bf16x8 wf[NI], pf[MI];
 #pragma unroll
-        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[a * 128 + fr]);
+        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[(a >> 1) * 256 + (a & 1) * 32 + fw]);
 #pragma unroll
         for (int b = 0; b < MI; ++b) pf[b] = __builtin_bit_cast(bf16x8, cP[b * 128 + fr]);
 #pragma unroll
@@ -198,9 +211,19 @@ conv_igemm3_kernel(const ConvK p) {
   }
 #undef MBX_ISSUE_TILE
   wait_vmcnt<0>();
-  // ---------------------------------------------------------------- epilogue
+  // ---------------------------------------------------------------- epilogue: straight from the accumulators
+  // acc[a][b][r] = output channel  wn TN + 32 (a >> 1) + 8 fch + 4 (a & 1) + r  of pixel  wm TM + 16 b + frow  (the filter rows
+  // were fed to the MFMA in that order): blocks 2A and 2A + 1 together give a lane EIGHT CONSECUTIVE channels of one pixel
+  // = one 16-byte bf16 store, and the four lanes of a pixel cover 64 contiguous bytes.  No LDS staging, no barrier, the
+  // ring is not needed any more: every global read of the epilogue (residual skip, accumulate source, ReLU mask) is an
+  // independent 16-byte load that can be in flight with all the others of the lane (round 2 staged the tile through
+  // LDS and walked it row-wise in 16-32 passes, each behind a barrier and each stalled on its own loads -- as long as
+  // the K loop on the K <= 448 layers).
+  static_assert(NI % 2 == 0, "wave tile: a multiple of 32 output channels");
+  constexpr int NA = NI / 2;
+  const int cl0 = wn * TN + fch * 8;                           // + 32 A: first of this lane's 8 channels inside the tile
   if constexpr (EV == 5) {
-    // float32 head outputs (tiny): straight from the accumulators; lane = pixel (lane & 15), 4 channels
+    // float32 head outputs (tiny launches): scalar stores
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
       const int m = m0 + wm * TM + b * 16 + frow;
@@ -209,125 +232,35 @@ conv_igemm3_kernel(const ConvK p) {
       float* yrow = reinterpret_cast<float*>(p.y) + img * p.y_img_stride + pix * p.ldy;
 #pragma unroll
       for (int a = 0; a < NI; ++a) {
-        const int c0 = n0 + wn * TN + a * 16 + fch * 4;
+        const int c0 = n0 + cl0 + 32 * (a >> 1) + 4 * (a & 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (c0 + r < p.C_out) yrow[c0 + r] = acc[a][b][r];
       }
     }
   } else {
-    // Stage the fp32 tile through the (now idle) LDS ring, then walk it ROW-wise: every global access of
-    // the epilogue (store, residual skip, accumulate, relu mask) is a 16-byte-per-lane access with the
-    // lanes of a row contiguous, instead of 8-byte accesses strided by the pixel pitch.
-    constexpr int LDT = BN + 4;                                // floats per tile row (+16 B: bank spread)
-    float* tile = reinterpret_cast<float*>(smem);
+    float s1[NA][8], s2[NA][8];
+    conv_epilogue_direct<EV, SH, NI, MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
+    if constexpr (EV == 1) {
+      // batch-norm statistics partials of this tile (of the STORED, bf16-rounded values), in a fixed order: the lane's
+      // MI pixels (above) -> the 16 lanes that share its channels (DPP row sums) -> the WMW waves along the pixel
+      // dimension through LDS (the ring is idle: every wave is past the last barrier of the K loop)
+      float* red = reinterpret_cast<float*>(smem);             // [WMW][BN][2]
 #pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b)
-        *reinterpret_cast<f32x4*>(tile + (wm * TM + b * 16 + frow) * LDT + wn * TN + a * 16 + fch * 4) = acc[a][b];
-    __syncthreads();
-    constexpr int TPR = BN / 8, RPP2 = NT / TPR, NPASS = BM / RPP2;
-    const int cg = tid % TPR, r0 = tid / TPR;
-    const int c0 = n0 + cg * 8;
-    const bool cok = c0 < p.C_out;                             // C_out % 8 == 0 for bf16 outputs
-    float sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-    if constexpr (EV == 3 || EV == 4) {
-      if (cok) {
+      for (int A = 0; A < NA; ++A)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (p.scale) sc[j] = p.scale[c0 + j];
-          if (p.shiftv) sh[j] = p.shiftv[c0 + j];
-        }
-      }
-    }
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP2 + r0;
-      const int m = m0 + row;
-      if (m < p.M && cok) {
-        int img, pix;
-        if (SH && p.parity) {
-          int oh_, ow_;
-          decode_pixel_parity(p, (unsigned)m, img, oh_, ow_);
-          pix = oh_ * p.W_out + ow_;
-        } else {
-          img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw);
-          pix = m - img * p.HW_out;
-        }
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cg * 8 + 4);
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-        unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + img * p.y_img_stride + pix * p.ldy + c0;
-        if constexpr (EV == 3) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
-        } else if constexpr (EV == 4) {
-          const u32x4 sk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-          const unsigned w[4] = {sk.x, sk.y, sk.z, sk.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[2 * j]);
-            v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[2 * j + 1]);
-          }
-        } else {
-          if (p.rscale != 0.f) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
+          const float x1 = row_sum16(s1[A][j]), x2 = row_sum16(s2[A][j]);
+          if (frow == 0) {
+            red[((wm * BN) + cl0 + 32 * A + j) * 2] = x1;
+            red[((wm * BN) + cl0 + 32 * A + j) * 2 + 1] = x2;
           }
         }
-        if constexpr (EV == 2) {
-          if (p.accumulate) {
-            const u32x4 old = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
-            const unsigned w[4] = {old.x, old.y, old.z, old.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
-          }
-          if (p.skip) {                      // relu backward of the tensor this gradient belongs to
-            const u32x4 mk = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-            const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
-              if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
-            }
-          }
-        }
-        if constexpr (EV == 3 || EV == 4) {
-          if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-        }
-        unsigned q8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
-        *reinterpret_cast<u32x4*>(yp) = u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)};
-        if constexpr (EV == 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[j] += f; s2[j] += f * f; }
-        }
-      }
-    }
-    if constexpr (EV == 1) {
-      // batch-norm statistics partials of this tile: per-thread sums over its rows, then over the RPP2
-      // row groups through LDS (the staged tile is dead after the barrier).
-      __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);           // [RPP2][BN][2]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[(r0 * BN + cg * 8 + j) * 2] = s1[j];
-        red[(r0 * BN + cg * 8 + j) * 2 + 1] = s2[j];
-      }
       __syncthreads();
       if (tid < BN && n0 + tid < p.C_out) {
         float x1 = 0.f, x2 = 0.f;
-        for (int w = 0; w < RPP2; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+#pragma unroll
+        for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
         float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
         o[0] = x1;
         o[1] = x2;
@@ -1133,8 +1066,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
   {
-    const size_t ring = NSTG * (size_t)(BM + BN) * 128, stage = (size_t)BM * (BN + 4) * 4;   // the epilogue stages fp32
-    const size_t lds = ring > stage ? ring : stage;
+    const size_t lds = NSTG * (size_t)(BM + BN) * 128;          // the ring; the epilogue works out of the accumulators
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
                    : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
     static bool attr_set3[6] = {false, false, false, false, false, false};
@@ -1247,6 +1179,14 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     k.acc_src = reinterpret_cast<const unsigned short*>(d->acc_src); k.acc_img_stride = (int)d->acc_img_stride; k.ld_acc = d->ld_acc;
   } else {
     k.acc_src = reinterpret_cast<const unsigned short*>(d->y); k.acc_img_stride = (int)d->y_img_stride; k.ld_acc = d->ldy;
+  }
+  {  // ranges of the epilogue's buffer descriptors: last pixel of the last image + the channels of the view
+    const long long last_pix = (long long)k.HW_out - 1, span = ((d->C_out + 7) / 8) * 8;
+    const long long yb = 2 * ((long long)(d->N - 1) * d->y_img_stride + last_pix * d->ldy + span);
+    const long long sb = d->skip ? 2 * ((long long)(d->N - 1) * d->skip_img_stride + last_pix * d->ld_skip + span) : 0;
+    const long long ab = 2 * ((long long)(d->N - 1) * k.acc_img_stride + last_pix * k.ld_acc + span);
+    if (!f32 && (yb >= (1LL << 31) || sb >= (1LL << 31) || ab >= (1LL << 31))) return MBX_ERR_UNSUPPORTED;
+    k.y_bytes = (unsigned)yb; k.skip_bytes = (unsigned)sb; k.acc_bytes = (unsigned)ab;
   }
   set_magic((unsigned)k.HW_out, k.mg_hw, k.sh_hw);
   set_magic((unsigned)k.W_out, k.mg_w, k.sh_w);

@@ -14,10 +14,11 @@ namespace {
 //    wave does both behind one barrier, so the ~0.5 us of DMA issue and the LDS reads + MFMAs of a K step add up; it
 //    gets its overlap from 2-3 small blocks per CU, which caps the tile at 128 x 64 / 128 x 128 (43 - 64 FLOP per byte
 //    pulled through the L2 -> LDS path, and that path, ~45 GB/s per CU, is what bounds these launches).
-//  * PERSISTENT: one block per CU walks tiles t = first, first + grid, ...; the loaders run two K steps ahead ACROSS
-//    tile boundaries, so the next tile's first filter / pixel tiles land while the compute waves write the current
-//    tile out.  The epilogue therefore cannot borrow the ring: it goes through its own LDS window, CR rows at a time
-//    (the loaders attend its barriers).
+//  * PERSISTENT: one block per CU walks tiles t = first, first + grid, ... (or pulls them from a counter); the loaders
+//    run NST - 1 K steps ahead ACROSS tile boundaries, so the next tile's first filter / pixel tiles land while the
+//    compute waves write the current tile out -- straight from the accumulators (conv_epilogue_direct: 16-byte stores, no
+//    LDS staging, no barriers; round 2 staged it through an LDS window in 16-32 row passes behind two barriers each,
+//    which the loaders had to attend).
 //  * Tiles are (64 MY pixels) x (64 NW channels): 192 x 128 and 256 x 128 move 77 / 85 FLOP per byte.
 // Stride-2 data gradients and the float32 head epilogue stay on conv_igemm3_kernel.
 template <int MY, int NW>
@@ -31,17 +32,14 @@ struct Ig5 {
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   static constexpr int STAGE = (BM + BN) * 8;                       // 16-byte slots per ring stage
-  static constexpr int LDT = BN + 4;                                // floats per staged row
-  // ring depth: the loaders run NST - 1 K steps ahead.  Four stages where they fit beside a 16-row epilogue window
-  // (128x64, 128x128): the K loop is paced by the landing of the operand tiles (0.5 us per 32 KB step measured with
-  // timestamps inside the kernel, whatever the compute waves do), i.e. by the bytes in flight against the latency.
-  static constexpr int NST = (4 * STAGE * 16 + 16 * LDT * 4 <= 160 * 1024 - 64) ? MBX_I5_NST4 : 3;
+  static constexpr int RED_BYTES = WM * BN * 2 * 4;                 // batch-norm statistics: [WM waves][BN channels][2] floats
+  // ring depth: the loaders run NST - 1 K steps ahead.  Four stages where they fit: the K loop is paced by the landing
+  // of the operand tiles (0.5 us per 32 KB step measured with timestamps inside the kernel, whatever the compute waves
+  // do), i.e. by the bytes in flight against the latency.
+  static constexpr int NST = (4 * STAGE * 16 + RED_BYTES + 64 <= 160 * 1024) ? MBX_I5_NST4 : 3;
   static constexpr int RING_BYTES = NST * STAGE * 16;
-  static constexpr int CR = (RING_BYTES + 64 * LDT * 4 <= 160 * 1024 - 64) ? 64 : (RING_BYTES + 32 * LDT * 4 <= 160 * 1024 - 64) ? 32 : 16;
-  static constexpr int EP_BYTES = CR * LDT * 4;
-  static constexpr int LDS_BYTES = RING_BYTES + EP_BYTES + 16;      // + four tile ids of the queued assignment
-  static constexpr int NCHUNK = BM / CR;                            // epilogue passes through the window
-  static_assert(TM % 16 == 0 && TN % 16 == 0 && WM * WN == 8, "wave grid");
+  static constexpr int LDS_BYTES = RING_BYTES + RED_BYTES + 16;     // + four tile ids of the queued assignment
+  static_assert(TM % 16 == 0 && TN % 32 == 0 && WM * WN == 8, "wave grid");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -52,22 +50,18 @@ conv_igemm5_kernel(const ConvK p) {
   constexpr bool PW = MODE == 1;
   constexpr int BM = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, MI = G::MI, NI = G::NI, STAGE = G::STAGE, NST = G::NST;
   constexpr int NL = MY + NW;                                       // LDS-DMA instructions per loader wave and K step
-  constexpr int LDT = G::LDT, CR = G::CR, NCHUNK = G::NCHUNK;
-  // row-wise walk of a window by the 512 compute threads: TPR threads per row, RP rows per pass
-  constexpr int TPR = BN / 8, RPP2 = 512 / TPR, RP = RPP2 < CR ? RPP2 : CR, NPASS = CR / RP;
-  static_assert(CR % RP == 0 && NPASS >= 1, "window rows per pass");
-  constexpr int NBAR = 2 * NCHUNK + (EV == 1 ? 2 : 0);              // barriers of one tile's epilogue
+  constexpr int NBAR = EV == 1 ? 1 : 0;                             // barriers of one tile's epilogue (statistics reduce)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  float* const ep = reinterpret_cast<float*>(smem + NST * STAGE);
+  float* const red = reinterpret_cast<float*>(smem + NST * STAGE);  // [WM][BN][2]
   // QUEUED tile assignment (p.work_counter): tile sequence of this workgroup = its first tile by position, then
   // gridDim.x + (values of the counter).  Lane 0 of compute wave 0 fetches the id of tile j+2 when tile j starts (a
   // returning atomic, in flight during the K loop -- the compute waves issue no other vector-memory instruction there)
-  // and publishes it through s_ids[(j + 2) & 3] in tile j's epilogue, barriers before anyone needs it: the loaders read
+  // and publishes it through s_ids[(j + 2) & 3] at the end of tile j's K loop, barriers before anyone needs it: the loaders read
   // the id of tile j+1 while they are still inside tile j (they run NST - 1 K steps ahead, hence the nk >= NST condition;
   // shorter K loops fall back to the static deal).  Same tiles, same arithmetic: results do not depend on the mode.
   // (an explicit LDS pointer: through a generic or volatile one hipcc emits FLAT accesses, which count on vmcnt too)
   typedef __attribute__((address_space(3))) int* lds_int_ptr;
-  const lds_int_ptr s_ids = (lds_int_ptr)(ep + CR * LDT);
+  const lds_int_ptr s_ids = (lds_int_ptr)(red + G::WM * BN * 2);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
@@ -83,6 +77,8 @@ conv_igemm5_kernel(const ConvK p) {
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
     const int r8 = lane >> 3;
     const int chunk = (lane & 7) ^ r8;                              // source chunk of this lane's slot (row & 7 == r8)
+    // filter rows (64 i + 8 lw + r8) carry the key of the permuted fragment reads (conv_igemm3_kernel): bits 3-4 and 1 of the row
+    const int chunkw = (lane & 7) ^ (((lw & 3) << 1) | ((r8 >> 1) & 1));
     const int ldx2 = p.ldx * 2;
     // issue cursor: (tile, K step) two steps ahead of the compute waves; row state of THAT tile
     int t_i = first, it_i = 0, st_issue = 0, j_i = 0;               // j_i: index of the issue tile in this workgroup's sequence
@@ -131,10 +127,10 @@ conv_igemm5_kernel(const ConvK p) {
 #define MBX5_ISSUE_B()                                                                                        \
   do {                                                                                                        \
     u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
-    const bool kv = kr < p.R;                                                                                 \
-    const int kb = (it_i * 64 + chunk * 8) * 2;                                                               \
+    const int kb = (it_i * 64 + chunkw * 8) * 2;                      /* the filter lane's own K position */    \
+    const bool kvw = kb < p.Ktot * 2;                                                                         \
     _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                            \
-      glds16(wr, sp + (MY + i) * 512, (kv && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                         \
+      glds16(wr, sp + (MY + i) * 512, (kvw && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                        \
     kc += 64;                                                                                                 \
     while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
@@ -178,7 +174,7 @@ conv_igemm5_kernel(const ConvK p) {
         raw_barrier();
       }
 #pragma unroll 1
-      for (int b = 0; b < NBAR; ++b) raw_barrier();                 // the compute waves' epilogue (own LDS window)
+      for (int b = 0; b < NBAR; ++b) raw_barrier();                 // the compute waves' statistics reduce
     }
 #undef MBX5_READBACK
 #undef MBX5_ISSUE_B
@@ -194,6 +190,9 @@ conv_igemm5_kernel(const ConvK p) {
   const int frow = lane & 15, fch = lane >> 4;
   const int fr0 = frow * 8 + (fch ^ (frow & 7));
   const int fr1 = frow * 8 + ((4 + fch) ^ (frow & 7));
+  const int fwrow = 8 * (frow >> 2) + (frow & 3), fwkey = ((frow >> 2) << 1) | ((frow >> 1) & 1);
+  const int fw0 = fwrow * 8 + (fch ^ fwkey);                        // filter fragments: permuted rows, their own key
+  const int fw1 = fwrow * 8 + ((4 + fch) ^ fwkey);
   int st_comp = 0;
   const bool fetcher = queued && tid == 0;
   auto fetch_tile = [&]() -> int {                                  // next id off the counter (>= ntiles: none left)
@@ -229,10 +228,10 @@ conv_igemm5_kernel(const ConvK p) {
       const u32x4* cW = smem + st_comp * STAGE + BM * 8 + (wn * TN) * 8;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int fr = kk ? fr1 : fr0;
+        const int fr = kk ? fr1 : fr0, fw = kk ? fw1 : fw0;
         bf16x8 wf[NI], pf[MI];
 #pragma unroll
-        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[a * 128 + fr]);
+        for (int a = 0; a < NI; ++a) wf[a] = __builtin_bit_cast(bf16x8, cW[(a >> 1) * 256 + (a & 1) * 32 + fw]);
 #pragma unroll
         for (int b = 0; b < MI; ++b) pf[b] = __builtin_bit_cast(bf16x8, cP[b * 128 + fr]);
 #pragma unroll
@@ -246,154 +245,37 @@ conv_igemm5_kernel(const ConvK p) {
       raw_barrier();
     }
     MBX5_STAMP(1);                                                  // K loop done
-    // ---------------------------------------------------------------- epilogue: CR rows at a time through `ep`
-    const int cg = tid % TPR, r0 = tid / TPR;                       // this thread's 8-channel group and row inside a pass
-    const int c0 = n0 + cg * 8;
-    const bool cok = c0 < p.C_out;                                  // C_out % 8 == 0 for bf16 outputs
-    float sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-    if constexpr (EV == 3 || EV == 4) {
-      if (cok) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (p.scale) sc[j] = p.scale[c0 + j];
-          if (p.shiftv) sh[j] = p.shiftv[c0 + j];
-        }
-      }
-    }
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    // The epilogue's global READS (residual skip / accumulate source / relu mask) are issued PFB passes ahead, the first
-    // batch before the first window is staged.  Loaded pass by pass each exposed a memory latency with one block per CU
-    // and nothing to overlap it (timestamps inside the kernel, 128x128 tile of block17's 1x1: epilogue 4.2 us with the
-    // residual read against 1.2 us for a plain store, the K loop 3.0 us).
-    constexpr int NQ = NCHUNK * NPASS;                              // passes of a tile, window after window
-    constexpr int PFW = (EV == 2 && MI * NI >= 12) ? 2 : 4;         // two reads per pass + 48-64 accumulators: stay under 128 VGPRs
-    constexpr int PFB = NQ < PFW ? NQ : PFW;
-    constexpr bool PRE = (EV == 2 || EV == 4);
-    int yoff[PFB];
-    u32x4 pre_a[PFB], pre_b[PFB];
-    auto prefetch = [&](int q0) {
-#pragma unroll
-      for (int i = 0; i < PFB; ++i) {
-        const int q = q0 + i;
-        const int m = m0 + (q / NPASS) * CR + (q % NPASS) * RP + r0;
-        yoff[i] = -1;
-        if (q < NQ && r0 < RP && m < p.M && cok) {
-          const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
-          yoff[i] = img * p.y_img_stride + pix * p.ldy + c0;
-          if constexpr (EV == 4) {
-            pre_a[i] = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-          } else if constexpr (EV == 2) {
-            if (p.accumulate) pre_a[i] = *reinterpret_cast<const u32x4*>(p.acc_src + img * p.acc_img_stride + pix * p.ld_acc + c0);
-            if (p.skip) pre_b[i] = *reinterpret_cast<const u32x4*>(p.skip + img * p.skip_img_stride + pix * p.ld_skip + c0);
-          }
-        }
-      }
-    };
-    if constexpr (PRE) prefetch(0);
-    if (fetcher) s_ids[(jt + 2) & 3] = next2;                       // visible behind the epilogue's barriers
-#pragma unroll
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-      // the accumulator blocks whose rows fall into this window (compile-time block index, run-time predicate)
-#pragma unroll
-      for (int b = 0; b < MI; ++b) {
-        const int row = wm * TM + b * 16 + frow - ch * CR;
-        if ((unsigned)(wm * TM + b * 16 - ch * CR) < (unsigned)CR) {
-#pragma unroll
-          for (int a = 0; a < NI; ++a)
-            *reinterpret_cast<f32x4*>(ep + row * LDT + wn * TN + a * 16 + fch * 4) = acc[a][b];
-        }
-      }
-      lds_barrier();
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int wrow = ps * RP + r0;                              // row inside the window
-        const int q = ch * NPASS + ps, qi = q % PFB;
-        if (q % PFB == 0 && (!PRE || q > 0)) prefetch(q);           // next batch (the first one is already in flight)
-        if (yoff[qi] >= 0) {
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8);
-          const f32x4 t1 = *reinterpret_cast<const f32x4*>(ep + wrow * LDT + cg * 8 + 4);
-          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-          unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + yoff[qi];
-          if constexpr (EV == 3) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
-          } else if constexpr (EV == 4) {
-            const unsigned w[4] = {pre_a[qi].x, pre_a[qi].y, pre_a[qi].z, pre_a[qi].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[2 * j]);
-              v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[2 * j + 1]);
-            }
-          } else {
-            if (p.rscale != 0.f) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
-            }
-          }
-          if constexpr (EV == 2) {
-            if (p.accumulate) {
-              const unsigned w[4] = {pre_a[qi].x, pre_a[qi].y, pre_a[qi].z, pre_a[qi].w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
-            }
-            if (p.skip) {                      // relu backward of the tensor this gradient belongs to
-              const unsigned w[4] = {pre_b[qi].x, pre_b[qi].y, pre_b[qi].z, pre_b[qi].w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
-                if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
-              }
-            }
-          }
-          if constexpr (EV == 3 || EV == 4) {
-            if (p.relu) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-          }
-          unsigned q8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
-          *reinterpret_cast<u32x4*>(yp) = u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)};
-          if constexpr (EV == 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[j] += f; s2[j] += f * f; }
-          }
-        }
-      }
-      lds_barrier();
-    }
+    // ---------------------------------------------------------------- epilogue: straight from the accumulators
+    if (fetcher) s_ids[(jt + 2) & 3] = next2;                       // visible behind the next tile's K-loop barriers
+    constexpr int NA = NI / 2;
+    const int cl0 = wn * TN + fch * 8;
+    float s1[NA][8], s2[NA][8];
+    // (128 registers per lane in a 16-wave block: the accumulate + mask epilogue keeps two pixel blocks of reads in flight)
+    conv_epilogue_direct<EV, false, NI, MI, ((EV == 2 && MI * NI >= 8) || MI * NI >= 16) ? (MI % 2 == 0 ? 2 : 1) : MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
     MBX5_STAMP(2);                                                  // rows written
     if constexpr (EV == 1) {
-      // batch-norm statistics partials of this tile: per-thread sums over its rows -> over the row groups of a wave
-      // (lanes TPR apart share a channel group; fixed order) -> over the 8 waves through the window
+      // batch-norm statistics partials of this tile: lane's pixels -> the 16 lanes sharing its channels (DPP row sums)
+      // -> the WM waves along the pixel dimension through `red` (its own LDS area: the ring is being refilled)
 #pragma unroll
-      for (int off = TPR; off < 64; off <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], off); s2[j] += __shfl_xor(s2[j], off); }
-      }
-      float* red = ep;                                              // [8 waves][BN][2] floats <= 16 rows of the window
-      if (lane < TPR) {
+      for (int A = 0; A < NA; ++A)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          red[(wave * BN + cg * 8 + j) * 2] = s1[j];
-          red[(wave * BN + cg * 8 + j) * 2 + 1] = s2[j];
+          const float x1 = row_sum16(s1[A][j]), x2 = row_sum16(s2[A][j]);
+          if (frow == 0) {
+            red[(wm * BN + cl0 + 32 * A + j) * 2] = x1;
+            red[(wm * BN + cl0 + 32 * A + j) * 2 + 1] = x2;
+          }
         }
-      }
-      lds_barrier();
+      lds_barrier();                                                // (the loaders attend: NBAR)
       if (tid < BN && n0 + tid < p.C_out) {
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
+        for (int w = 0; w < G::WM; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
         float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
         o[0] = x1;
         o[1] = x2;
       }
-      lds_barrier();
+      // (no second barrier: `red` is rewritten only after the next tile's K loop, nk >= 1 barriers away)
     }
 #undef MBX5_STAMP
   }

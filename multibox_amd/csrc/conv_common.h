@@ -19,6 +19,7 @@ struct ConvK {
   const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
   const unsigned short* w; int C_out, R, S, Ktot;
   unsigned x_bytes, w_bytes;
+  unsigned y_bytes, skip_bytes, acc_bytes;  // buffer-descriptor ranges of the epilogue's tensors (bf16 outputs; < 2 GB each)
   int mul, shift, pad_t, pad_l, W_out, HW_out, M;
   void* y; int y_img_stride, ldy;
   int epi, relu, accumulate;
@@ -150,5 +151,144 @@ __device__ __forceinline__ unsigned lds_readback_issue(const void* lds_slot) {
   return v;
 }
 __device__ __forceinline__ void lds_readback_wait(unsigned v) { asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(v) : "memory"); }
+
+// ------------------------------------------------------------------------------------------
+// The epilogue of the implicit-GEMM kernels, straight from the accumulators (conv_igemm3_kernel and conv_igemm5_kernel).
+// acc[a][b][r] holds output channel  32 (a >> 1) + 8 fch + 4 (a & 1) + r  (relative to the wave tile) of pixel
+// 16 b + frow: blocks 2A and 2A + 1 give a lane EIGHT CONSECUTIVE channels of one pixel = one 16-byte bf16 store;
+// the four lanes of a pixel cover 64 contiguous bytes.  mlane = the lane's pixel for b = 0, clane = its first channel for
+// A = 0.  EV: 0 store, 1 store + batch-norm statistics sums (s1 / s2: per-lane sums of the STORED, bf16-rounded values
+// over its MI pixels), 2 accumulate (+ ReLU mask), 3 affine (+ReLU), 4 residual (+ReLU).
+// BRANCH-FREE: every global access goes through a buffer descriptor with a range-checked 32-bit offset (out-of-tile
+// lanes read zeros and their stores are dropped), so that ALL the 16-byte reads of a chunk of BCH pixel blocks (residual
+// skip, accumulate source, mask) are issued back to back before the first one is consumed -- with a branch around each
+// group, as first written, every group exposed its own memory latency (the data-gradient launches with two reads per
+// group got 6-10 % SLOWER than the LDS-staged epilogue of round 2).  BCH bounds the registers the reads in flight take.
+template <int EV, bool SH, int NI, int MI, int BCH = MI>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
+                                                     float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
+  static_assert(NI % 2 == 0 && EV != 5 && MI % BCH == 0, "wave tile: a multiple of 32 output channels; float32 heads are handled by the caller");
+  constexpr int NA = NI / 2;
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+  const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.acc_src, p.acc_bytes);
+  float sc[NA][8], sh[NA][8];
+#pragma unroll
+  for (int A = 0; A < NA; ++A)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[A][j] = 1.f; sh[A][j] = 0.f; }
+  if constexpr (EV == 3 || EV == 4) {
+#pragma unroll
+    for (int A = 0; A < NA; ++A) {
+      const int c0 = clane + 32 * A;
+      if (c0 < p.C_out) {                                    // C_out % 8 == 0 for bf16 outputs
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (p.scale) sc[A][j] = p.scale[c0 + j];
+          if (p.shiftv) sh[A][j] = p.shiftv[c0 + j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int A = 0; A < NA; ++A)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[A][j] = 0.f; s2[A][j] = 0.f; }
+  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+#pragma unroll
+  for (int b0 = 0; b0 < MI; b0 += BCH) {
+    unsigned yo[BCH][NA], so[BCH][NA], ao[BCH][NA];
+    u32x4 la[BCH][NA], lb[BCH][NA];
+    // ---- phase 1: addresses of the chunk, every read issued
+#pragma unroll
+    for (int bb = 0; bb < BCH; ++bb) {
+      const int m = mlane + (b0 + bb) * 16;
+      int img, pix;
+      {
+        const unsigned mm = m < p.M ? (unsigned)m : 0u;
+        if (SH && p.parity) {
+          int oh_, ow_;
+          decode_pixel_parity(p, mm, img, oh_, ow_);
+          pix = oh_ * p.W_out + ow_;
+        } else {
+          img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+          pix = (int)mm - img * p.HW_out;
+        }
+      }
+#pragma unroll
+      for (int A = 0; A < NA; ++A) {
+        const int c0 = clane + 32 * A;
+        const bool ok = m < p.M && c0 < p.C_out;
+        yo[bb][A] = ok ? (unsigned)((img * p.y_img_stride + pix * p.ldy + c0) * 2) : kOOB;
+        if constexpr (EV == 4) {
+          so[bb][A] = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
+          la[bb][A] = buf_load16(kr_, so[bb][A]);
+        } else if constexpr (EV == 2) {
+          ao[bb][A] = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
+          so[bb][A] = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
+          if (do_acc) la[bb][A] = buf_load16(ar, ao[bb][A]);
+          if (do_mask) lb[bb][A] = buf_load16(kr_, so[bb][A]);
+        }
+      }
+    }
+    // ---- phase 2: arithmetic and stores
+#pragma unroll
+    for (int bb = 0; bb < BCH; ++bb) {
+      const int b = b0 + bb;
+#pragma unroll
+      for (int A = 0; A < NA; ++A) {
+        float v[8] = {acc[2 * A][b][0], acc[2 * A][b][1], acc[2 * A][b][2], acc[2 * A][b][3],
+                      acc[2 * A + 1][b][0], acc[2 * A + 1][b][1], acc[2 * A + 1][b][2], acc[2 * A + 1][b][3]};
+        if constexpr (EV == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[A][j] + sh[A][j];
+        } else if constexpr (EV == 4) {
+          const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[A][2 * j]);
+            v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[A][2 * j + 1]);
+          }
+        } else {
+          if (p.rscale != 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
+          }
+        }
+        if constexpr (EV == 2) {
+          if (do_acc) {
+            const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
+          }
+          if (do_mask) {                      // relu backward of the tensor this gradient belongs to
+            const unsigned w[4] = {lb[bb][A].x, lb[bb][A].y, lb[bb][A].z, lb[bb][A].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
+              if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
+            }
+          }
+        }
+        if constexpr (EV == 3 || EV == 4) {
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+        }
+        unsigned q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)},
+                                               yr, (int)yo[bb][A], 0, 0);
+        if constexpr (EV == 1) {
+          // (out-of-tile lanes hold exact zeros -- zero-filled pixel rows / filter rows -- and add nothing)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[A][j] += f; s2[A][j] += f * f; }
+        }
+      }
+    }
+  }
+}
 
 }  // namespace

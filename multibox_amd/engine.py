@@ -69,25 +69,18 @@ class ConvOp:
 
 class Net:
     def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
-                 bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0, bn_frozen_stats=False):
+                 bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0):
         """repeats: number of block35 / block17 / block8 repetitions (model.py:142,162,187); anything
-        but the reference's (10, 20, 9) is a reduced-depth network for tests.
-        bn_frozen_stats (TESTS ONLY, mode "train"): batch norm normalises with the MOVING statistics (call
-        load_frozen_stats() after setting them) while every layer stays trainable and gradients flow through the
-        normalisation as through a per-channel affine map -- no batch reduction anywhere, so a random-init 100-layer
-        network is no longer chaotic and the assembled backward pass can be held against the torch oracle
-        (oracle/torch_model.py, bn_training=False) with a tight, stated tolerance (tests/test_gpu_model.py)."""
+        but the reference's (10, 20, 9) is a reduced-depth network for tests."""
         assert mode in ("train", "infer")
         self.repeats = tuple(repeats)
         self.B, self.S, self.k, self.mode, self.fine_tune, self.dev = batch, input_size, k, mode, fine_tune, device
         self.bn_decay = bn_decay
-        self.bn_frozen_stats = bool(bn_frozen_stats) and mode == "train"
         self.tune_registry = []                    # (key, descriptor, fwd | dgrad | wgrad) of every tunable conv launch
         # MBX_DETERMINISTIC=1: bit-reproducible gradients for bisecting parity bugs -- three-launch batch-norm backward
         # (no atomics) and un-split weight-gradient tiles (one adder per element); slower, same mathematics
         self.deterministic = bool(int(os.environ.get("MBX_DETERMINISTIC", "0")))
         self.no_onepass = self.deterministic or bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
-        self.no_onepass = self.no_onepass or self.bn_frozen_stats
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
@@ -512,10 +505,6 @@ class Net:
                 def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
-                    if self.bn_frozen_stats:           # (tests) normalise with the loaded moving statistics
-                        _lib.check(l.mbx_bn_apply(op.y.data_ptr(), op.M, op.K, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                                                  int(op.relu), out.ptr, out.ld, s), "bn_apply (frozen statistics)")
-                        return
                     _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, self.bn_decay,
                                                     op.y.data_ptr(), op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
                                                     mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_apply_fused")
@@ -661,8 +650,6 @@ class Net:
                                                    self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce")
                     _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, K, M, dbeta.data_ptr(),
                                                      self.m12.data_ptr(), s), "bn_bwd_finalize")
-                    if self.bn_frozen_stats:           # (tests) statistics are constants: dy = rstd * mask(da), no mean terms
-                        self.m12.zero_()
                     _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                   op.dy.data_ptr(), s), "bn_bwd_apply")
@@ -724,11 +711,6 @@ class Net:
         _lib.check(_lib.lib().mbx_bn_fold(self.MM.data_ptr(), self.MV.data_ptr(), self.Bt.data_ptr(), BN_EPS, self.nBt,
                                           self.bn_scale.data_ptr(), self.bn_shift.data_ptr(),
                                           torch.cuda.current_stream().cuda_stream), "bn_fold")
-
-    def load_frozen_stats(self):
-        """bn_frozen_stats mode: normalise with the moving statistics as they stand now (mean = MM, rstd = 1/sqrt(MV + eps))."""
-        self.bn_mean.copy_(self.MM)
-        self.bn_rstd.copy_(torch.rsqrt(self.MV + BN_EPS))
 
     def set_input(self, images_f32):
         """images [B,S,S,3] float32 in [-1,1] (inputs.py:350-351) -> packed bf16 NHWC8."""

@@ -45,7 +45,16 @@ def _same(n, k, s):
 
 class Model:
     def __init__(self, params, k=5, bn_training=True, heads_bn_training=None, q=None, bn_decay=0.9997,
-                 repeats=(10, 20, 9)):
+                 repeats=(10, 20, 9), force=None):
+        """force: optional {scope: tensor [B,C,H,W]} of activations to TEACHER-FORCE: the output of every batch-norm
+        convolution named in it (after BN / ReLU) and of every residual block named by its ".../Conv2d_1x1" scope takes
+        the given VALUE while gradients still flow through this model's own graph (x + (forced - x).detach()).  With
+        the engine's stored activations forced in, both backward passes are linearised around the same point (same
+        ReLU masks, same layer inputs), which is what makes a full-depth gradient comparison well-posed: a bf16
+        rounding difference in the forward pass otherwise flips ReLU masks and decorrelates the gradients of a random-init
+        100-layer network (the bf16-emulating and the float32 oracle agree only to cosine ~0.5 there)."""
+        self.force = force
+        self.keep_acts, self.acts = False, {}          # debugging: keep every BN convolution's output (and its gradient)
         self.P, self.k, self.q = params, k, (q or (lambda t: t))
         self.repeats = repeats              # model.py:142,162,187 use (10, 20, 9); smaller = reduced-depth test net
         self.bn_training = bn_training
@@ -89,6 +98,11 @@ class Model:
             y = torch.relu(y)
         if bn:
             y = self.q(y)
+            if self.force is not None and scope in self.force:
+                y = y + (self.force[scope] - y).detach()
+            if self.keep_acts and y.requires_grad:
+                y.retain_grad()
+                self.acts[scope] = y
         entry["out_hw"] = [int(y.shape[2]), int(y.shape[3])]
         return _tag(y, [scope])
 
@@ -134,7 +148,10 @@ class Model:
         net = net + scale * up
         if relu:
             net = torch.relu(net)
-        return _tag(self.q(net), [s + "Conv2d_1x1"])
+        net = self.q(net)
+        if self.force is not None and (s + "Conv2d_1x1") in self.force:
+            net = net + (self.force[s + "Conv2d_1x1"] - net).detach()
+        return _tag(net, [s + "Conv2d_1x1"])
 
     # The backbone in four stages (each also callable on its own for stage-wise gradient tests).
     def stem(self, x):

@@ -59,6 +59,22 @@ def oracle_params(torch, net):
     return P
 
 
+def engine_activations(net):
+    """{scope: [B,C,H,W] float32 CPU tensor} of what the engine has stored after a forward pass: the output (after BN /
+    ReLU) of every batch-norm convolution and the output of every residual block (keyed by its ".../Conv2d_1x1" scope) --
+    the teacher-forcing points of oracle.torch_model.Model(force=...)."""
+    out = {}
+    for op in net.convs:
+        if op.kind in ("bn", "frozen"):
+            off = 0
+            for m in op.members:
+                out[m.scope] = op.out.slice(off, m.K).tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
+                off += m.K
+        elif op.kind == "residual":
+            out[op.members[0].scope] = op.out.tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
+    return out
+
+
 def _cos(a, b):
     a, b = a.double().reshape(-1), b.double().reshape(-1)
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
@@ -360,16 +376,27 @@ def test_overfits_one_batch(env):
     assert last[0] < first[0] / 8.0 and last[1] < first[1] / 4.0, (first, last)      # both terms of loss.py:100-101
 
 
-def test_full_depth_backward_frozen_statistics():
-    """ONE tight end-to-end check of the assembled full-depth (10 / 20 / 9) backward pass -- all 409
-    convolution launches, the out-of-place trunk gradients, the deferred grouped weight gradients reading every kept dy.
-    Batch-statistics BN makes a random-init 100-layer network chaotic (the two torch oracles agree with each other only to
-    cos 0.57 there), so this test uses the engine's test-only `bn_frozen_stats` mode: batch norm normalises with FIXED
-    statistics (calibrated once: the batch statistics of this very batch, so activations are O(1) at every depth) while
-    every layer stays trainable and gradients flow through the normalisation -- exactly what oracle/torch_model.py
-    computes with bn_training=False.  No batch reduction anywhere => well-posed.  MBX_DETERMINISTIC=1 (no atomics).
-    Stated tolerance, per variable whose gradient is not negligible (norm > 1e-3 of the median): cosine >= 0.999 and
-    relative L2 error <= 2e-2 against the bf16-emulating oracle on the same weights, batch and matching."""
+def test_full_depth_backward_teacher_forced():
+    """ONE tight end-to-end check of the assembled full-depth (10 / 20 / 9) backward pass in the REAL
+    training mode (batch-statistics BN) -- all 409 convolution launches, the BN backward of every layer, the out-of-place
+    trunk gradients, the deferred grouped weight gradients reading every kept dy -- at batch 8 under MBX_DETERMINISTIC=1.
+
+    Why teacher forcing.  A free-running comparison is ill-posed at this depth, and NOT because of batch statistics: with
+    FIXED statistics too, the bf16-emulating and the float32 torch oracle agree with each other only to cosine 0.52 on the
+    gradients (tools/teacher_forced_explore.py; forward outputs differ by 15 %): one bf16 rounding difference in the forward
+    pass flips ReLU masks downstream and the backward passes are linearised around different points.  So the oracle is run
+    TEACHER-FORCED (oracle/torch_model.py Model(force=...)): at every batch-norm convolution and every residual block it
+    continues from the ENGINE's stored activation, gradients flowing through its own graph.  Both backward passes then
+    use the same masks and the same layer inputs; what remains is the bf16 rounding of the engine's stored gradients.
+
+    Stated tolerance, per variable whose gradient is not negligible (norm > 1e-3 of the median), against the
+    teacher-forced bf16-emulating oracle on the same weights, batch and matching: cosine >= 0.9995 and relative L2 error
+    <= 3e-2; whole gradient cosine >= 0.9998, relative L2 <= 2e-2.  Two documented exceptions: the betas of Conv2d_2b_3x3
+    and Conv2d_4a_3x3, the layers in front of a 3x3/2 max pool -- their da is sparse (16 % non-zero, routed by the pool)
+    and d(beta) = sum(da * mask) cancels heavily, so a 1.4 % random error of da (measured, tools/stem_grad_probe.py: da
+    itself agrees to cosine 0.9999, and sum(engine da * mask) reproduces the engine's d(beta)) becomes 3-18 % of the
+    small sum: cosine >= 0.98, relative L2 <= 0.25 there.  Measured at batch 8: median cosine 0.99993, 5th percentile
+    0.99983, whole gradient 0.999887 / 1.5 %."""
     import os
     import torch
     import __graft_entry__ as g
@@ -382,13 +409,13 @@ def test_full_depth_backward_frozen_statistics():
     old = os.environ.get("MBX_DETERMINISTIC")
     os.environ["MBX_DETERMINISTIC"] = "1"
     try:
-        net = Net(batch=B, input_size=299, k=5, mode="train", seed=5, bn_frozen_stats=True)
+        net = Net(batch=B, input_size=299, k=5, mode="train", seed=5)
     finally:
         if old is None:
             os.environ.pop("MBX_DETERMINISTIC")
         else:
             os.environ["MBX_DETERMINISTIC"] = old
-    assert net.deterministic and net.bn_frozen_stats and net.repeats == (10, 20, 9)
+    assert net.deterministic and net.repeats == (10, 20, 9)
     gen = torch.Generator().manual_seed(11)
     net.Bt.copy_((torch.randn(net.nBt, generator=gen) * 0.1).cuda())
     images = torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1
@@ -399,17 +426,7 @@ def test_full_depth_backward_frozen_statistics():
     for b in range(B):
         xy = rng.uniform(0, .7, (n_gt[b], 2)); wh = rng.uniform(.05, .3, (n_gt[b], 2))
         gt[b, :n_gt[b], :2] = xy; gt[b, :n_gt[b], 2:] = xy + wh
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
-    # ---- calibration: this batch's statistics become the (fixed) moving statistics of both models
-    P0 = oracle_params(torch, net)
-    with torch.no_grad():
-        cal = Model(P0, k=5, bn_training=True, q=q_bf16, bn_decay=0.0)       # decay 0: new moving value = batch value
-        cal.build(images)
-    for scope, (mean, var) in cal.new_moving.items():
-        net.set_param(scope + "/BatchNorm/moving_mean", mean)
-        net.set_param(scope + "/BatchNorm/moving_variance", var)
-        P0[scope + "/BatchNorm/moving_mean"], P0[scope + "/BatchNorm/moving_variance"] = mean.clone(), var.clone()
-    net.load_frozen_stats()
+    P0 = oracle_params(torch, net)                  # before the forward pass updates the moving statistics
     # ---- engine: forward, matching + loss, backward
     net.set_input(images.cuda())
     net.forward()
@@ -421,22 +438,28 @@ def test_full_depth_backward_frozen_statistics():
     torch.cuda.synchronize()
     assert int(ml.status.max()) == 0
     match = ml.match.cpu().numpy()
-    # ---- oracle in the same mode, same matching
+    # ---- the oracle, continuing from the engine's activations at every layer boundary, same matching
     P = {k_: v.clone().requires_grad_(True) for k_, v in P0.items()}
-    m = Model(P, k=5, bn_training=False, q=q_bf16)
+    m = Model(P, k=5, bn_training=True, q=q_bf16, force=engine_activations(net))
     rl, rz = m.build(images)
     loc, conf = multibox_loss(rl, rz, torch.from_numpy(priors), torch.from_numpy(gt), match, 1000.0)
     (loc + conf).backward()
-    # forward first (a wrong forward would make the gradient comparison meaningless)
-    assert rel_l2(net.locs.cpu(), rl.detach()) < 2e-2 and rel_l2(net.logits.cpu(), rz.detach()) < 2e-2
+    # forward: with every layer fed the engine's input, the head outputs agree to a few bf16 ulps
+    assert rel_l2(net.locs.cpu(), rl.detach()) < 1e-2 and rel_l2(net.logits.cpu(), rz.detach()) < 1e-2
     names = [n for n in net.param_index if n.endswith(("/weights", "/biases", "/beta"))]
     gq = {n: P[n].grad for n in names}
     ge = {n: net.get_param(n, "grad").detach().float().cpu() for n in names}
     assert all(bool(torch.isfinite(ge[n]).all()) for n in names)
     med = np.median([float(gq[n].norm()) for n in names])
     big = [n for n in names if float(gq[n].norm()) > 1e-3 * med]
-    assert len(big) > 0.9 * len(names), (len(big), len(names))
-    worst_cos = min(((_cos(ge[n], gq[n]), n) for n in big))
-    worst_l2 = max(((rel_l2(ge[n], gq[n]), n) for n in big))
-    assert worst_cos[0] >= 0.999, worst_cos
-    assert worst_l2[0] <= 2e-2, worst_l2
+    assert len(big) > 0.95 * len(names), (len(big), len(names))
+    pool_fed = ("InceptionResnetV2/Conv2d_2b_3x3/BatchNorm/beta", "InceptionResnetV2/Conv2d_4a_3x3/BatchNorm/beta")
+    for n in big:
+        c, e = _cos(ge[n], gq[n]), rel_l2(ge[n], gq[n])
+        if n in pool_fed:
+            assert c >= 0.98 and e <= 0.25, (n, c, e)
+        else:
+            assert c >= 0.9995 and e <= 3e-2, (n, c, e)
+    whole_e = torch.cat([ge[n].reshape(-1) for n in names])
+    whole_q = torch.cat([gq[n].reshape(-1) for n in names])
+    assert _cos(whole_e, whole_q) >= 0.9998 and rel_l2(whole_e, whole_q) <= 2e-2, (_cos(whole_e, whole_q), rel_l2(whole_e, whole_q))
