@@ -240,7 +240,8 @@ conv_igemm3_kernel(const ConvK p) {
     }
   } else {
     float s1[NA][8], s2[NA][8];
-    conv_epilogue_direct<EV, SH, NI, MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
+    // (reads in flight per lane: all of the tile's, or two pixel blocks at a time where that would take > 64 registers)
+    conv_epilogue_direct<EV, SH, NI, MI, (EV == 2 && MI * NA >= 8 && MI % 2 == 0) ? 2 : MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
     if constexpr (EV == 1) {
       // batch-norm statistics partials of this tile (of the STORED, bf16-rounded values), in a fixed order: the lane's
       // MI pixels (above) -> the 16 lanes that share its channels (DPP row sums) -> the WMW waves along the pixel
@@ -781,9 +782,14 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
     for (int it = 0; it < nsteps; ++it) {
       const bool more = it + 2 < nsteps;
       st_pub = st_pub == NST - 1 ? 0 : st_pub + 1;        // slot of step it+1
+#ifndef MBX_NO_LANDING_PROBE
       if (more) { MBX_ISSUE_STEP5_Y(); wait_vmcnt<NY>(); } else wait_vmcnt<0>();   // step it+1 has retired (this wave's share)
       const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NSUB - 1) * 512 + lw * 64 + lane);
       if (more) MBX_ISSUE_STEP5_X();
+#else                                                 // (debug builds only: A/B of what the hand-off costs)
+      const unsigned probe = 0;
+      if (more) { MBX_ISSUE_STEP5(); wait_vmcnt<NSUB>(); } else wait_vmcnt<0>();
+#endif
       if (bias) {                                         // dy images of the step being multiplied (landed, read-only now)
         const u32x4* img_y = smem + st_bias * STAGE;
 #pragma unroll
@@ -795,7 +801,11 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
         }
         st_bias = st_bias == NST - 1 ? 0 : st_bias + 1;
       }
+#ifndef MBX_NO_LANDING_PROBE
       lds_readback_wait(probe);                           // read-back returned: publish step it+1
+#else
+      (void)probe;
+#endif
       raw_barrier();
     }
 #undef MBX_ISSUE_STEP5_X

@@ -166,11 +166,15 @@ conv_igemm5_kernel(const ConvK p) {
 #ifdef MBX_I5_STAMPS
         if (p.dbg & 2) { if (more) MBX5_ISSUE_B(); raw_barrier(); continue; }   // timing probe: do not wait for the landing (wrong results)
 #endif
+#ifndef MBX_NO_LANDING_PROBE
         // the NEXT step (steps s+1 .. s+NST-2 are outstanding, + the MY pieces just issued) has retired: this wave's share
         if (more) wait_vmcnt<(NST - 3) * NL + MY>(); else wait_vmcnt<0>();
         const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane);
         if (more) MBX5_ISSUE_B();
         lds_readback_wait(probe);                                   // read-back returned: publish
+#else                                                               // (debug builds only: A/B of what the hand-off costs)
+        if (more) { MBX5_ISSUE_B(); wait_vmcnt<(NST - 2) * NL>(); } else wait_vmcnt<0>();
+#endif
         raw_barrier();
       }
 #pragma unroll 1
@@ -215,6 +219,18 @@ conv_igemm5_kernel(const ConvK p) {
 #define MBX5_STAMP(i) do { } while (0)
 #endif
     MBX5_STAMP(0);                                                  // tile start
+    // The epilogue's READS (residual skip / accumulate source / ReLU mask) are issued HERE, before the K loop: the compute
+    // waves issue no other vector-memory instruction in the loop and never wait on vmcnt there, so the reads -- up to
+    // 64 KB per tile, the HBM-bound half of a short-K tile's life -- land while the tile is multiplied; the epilogue then
+    // is arithmetic + fire-and-forget 16-byte stores.  (As many pixel blocks as 16 registers hold: the whole tile for
+    // 128x64 / 128x128 / 256x64 residual tiles, half of it for 256x128; the rest is read in the epilogue.)
+    constexpr int NA = NI / 2;
+    // pixel blocks whose reads are issued ahead: 16 registers' worth (four 16-byte reads per lane)
+    constexpr int PRE_RAW = (EV == 4 || EV == 2) ? 4 / (NA * (EV == 2 ? 2 : 1)) : 0;
+    constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
+    const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
+    u32x4 pla[PREB > 0 ? PREB : 1][NA], plb[PREB > 0 ? PREB : 1][NA];
+    if constexpr (PREB > 0) conv_epilogue_issue_reads<EV, false, NA, PREB>(p, mlane, clane, 0, pla, plb);
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -247,11 +263,17 @@ conv_igemm5_kernel(const ConvK p) {
     MBX5_STAMP(1);                                                  // K loop done
     // ---------------------------------------------------------------- epilogue: straight from the accumulators
     if (fetcher) s_ids[(jt + 2) & 3] = next2;                       // visible behind the next tile's K-loop barriers
-    constexpr int NA = NI / 2;
-    const int cl0 = wn * TN + fch * 8;
-    float s1[NA][8], s2[NA][8];
-    // (128 registers per lane in a 16-wave block: the accumulate + mask epilogue keeps two pixel blocks of reads in flight)
-    conv_epilogue_direct<EV, false, NI, MI, ((EV == 2 && MI * NI >= 8) || MI * NI >= 16) ? (MI % 2 == 0 ? 2 : 1) : MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
+    float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];
+    conv_epilogue_channels<EV, NA>(p, clane, sc, sh, s1, s2);
+    if constexpr (PREB > 0) {
+      conv_epilogue_finish<EV, false, NI, MI, PREB>(p, acc, mlane, clane, 0, pla, plb, sh, sc, s1, s2);
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (PREB < MI) {
+      // the rest of the tile: reads issued here, one or two pixel blocks at a time (128 registers per lane in a 16-wave block)
+      constexpr int REM = MI - PREB, CH = (EV == 0 || EV == 1 || EV == 3) ? REM : (REM % 2 == 0 ? 2 : 1);
+      conv_epilogue_range<EV, false, NI, MI, PREB, MI, CH>(p, acc, mlane, clane, sh, sc, s1, s2);
+    }
     MBX5_STAMP(2);                                                  // rows written
     if constexpr (EV == 1) {
       // batch-norm statistics partials of this tile: lane's pixels -> the 16 lanes sharing its channels (DPP row sums)

@@ -164,19 +164,130 @@ __device__ __forceinline__ void lds_readback_wait(unsigned v) { asm volatile("s_
 // skip, accumulate source, mask) are issued back to back before the first one is consumed -- with a branch around each
 // group, as first written, every group exposed its own memory latency (the data-gradient launches with two reads per
 // group got 6-10 % SLOWER than the LDS-staged epilogue of round 2).  BCH bounds the registers the reads in flight take.
-template <int EV, bool SH, int NI, int MI, int BCH = MI>
-__device__ __forceinline__ void conv_epilogue_direct(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
+// One pixel block's (image, pixel) pair for lane pixel m (clamped when out of range)
+template <bool SH>
+__device__ __forceinline__ void epi_pixel(const ConvK& p, const int m, int& img, int& pix) {
+  const unsigned mm = m < p.M ? (unsigned)m : 0u;
+  if (SH && p.parity) {
+    int oh_, ow_;
+    decode_pixel_parity(p, mm, img, oh_, ow_);
+    pix = oh_ * p.W_out + ow_;
+  } else {
+    img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
+    pix = (int)mm - img * p.HW_out;
+  }
+}
+
+// Phase 1 for pixel blocks [b0, b0 + BCH): issue every 16-byte read of the epilogue (nothing waits here).
+template <int EV, bool SH, int NA, int BCH>
+__device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const int mlane, const int clane, const int b0,
+                                                          u32x4 (&la)[BCH][NA], u32x4 (&lb)[BCH][NA]) {
+  if constexpr (EV == 2 || EV == 4) {
+    const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.acc_src, p.acc_bytes);
+    const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+#pragma unroll
+    for (int bb = 0; bb < BCH; ++bb) {
+      const int m = mlane + (b0 + bb) * 16;
+      int img, pix;
+      epi_pixel<SH>(p, m, img, pix);
+#pragma unroll
+      for (int A = 0; A < NA; ++A) {
+        const int c0 = clane + 32 * A;
+        const bool ok = m < p.M && c0 < p.C_out;
+        const unsigned so = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
+        if constexpr (EV == 4) {
+          la[bb][A] = buf_load16(kr_, so);
+        } else {
+          const unsigned ao = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
+          if (do_acc) la[bb][A] = buf_load16(ar, ao);
+          if (do_mask) lb[bb][A] = buf_load16(kr_, so);
+        }
+      }
+    }
+  }
+}
+
+// Phase 2 for pixel blocks [b0, b0 + BCH): arithmetic and the 16-byte stores (fire and forget).
+template <int EV, bool SH, int NI, int MI, int BCH>
+__device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
+                                                     const int b0, const u32x4 (&la)[BCH][NI / 2], const u32x4 (&lb)[BCH][NI / 2],
+                                                     const float (&sh)[NI / 2][8], const float (&sc)[NI / 2][8],
                                                      float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
-  static_assert(NI % 2 == 0 && EV != 5 && MI % BCH == 0, "wave tile: a multiple of 32 output channels; float32 heads are handled by the caller");
   constexpr int NA = NI / 2;
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
-  const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.acc_src, p.acc_bytes);
-  float sc[NA][8], sh[NA][8];
+  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+#pragma unroll
+  for (int bb = 0; bb < BCH; ++bb) {
+    const int b = b0 + bb;
+    const int m = mlane + b * 16;
+    int img, pix;
+    epi_pixel<SH>(p, m, img, pix);
+#pragma unroll
+    for (int A = 0; A < NA; ++A) {
+      const int c0 = clane + 32 * A;
+      const unsigned yo = (m < p.M && c0 < p.C_out) ? (unsigned)((img * p.y_img_stride + pix * p.ldy + c0) * 2) : kOOB;
+      float v[8] = {acc[2 * A][b][0], acc[2 * A][b][1], acc[2 * A][b][2], acc[2 * A][b][3],
+                    acc[2 * A + 1][b][0], acc[2 * A + 1][b][1], acc[2 * A + 1][b][2], acc[2 * A + 1][b][3]};
+      if constexpr (EV == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[A][j] + sh[A][j];
+      } else if constexpr (EV == 4) {
+        const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[A][2 * j]);
+          v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[A][2 * j + 1]);
+        }
+      } else {
+        if (p.rscale != 0.f) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
+        }
+      }
+      if constexpr (EV == 2) {
+        if (do_acc) {
+          const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
+        }
+        if (do_mask) {                      // relu backward of the tensor this gradient belongs to
+          const unsigned w[4] = {lb[bb][A].x, lb[bb][A].y, lb[bb][A].z, lb[bb][A].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
+            if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
+          }
+        }
+      }
+      if constexpr (EV == 3 || EV == 4) {
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+      }
+      unsigned q8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)},
+                                             yr, (int)yo, 0, 0);
+      if constexpr (EV == 1) {
+        // (out-of-tile lanes hold exact zeros -- zero-filled pixel rows / filter rows -- and add nothing)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[A][j] += f; s2[A][j] += f * f; }
+      }
+    }
+  }
+}
+
+// per-channel scale / shift of the affine and residual epilogues, statistics sums cleared
+template <int EV, int NA>
+__device__ __forceinline__ void conv_epilogue_channels(const ConvK& p, const int clane, float (&sc)[NA][8], float (&sh)[NA][8],
+                                                       float (&s1)[NA][8], float (&s2)[NA][8]) {
 #pragma unroll
   for (int A = 0; A < NA; ++A)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[A][j] = 1.f; sh[A][j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { sc[A][j] = 1.f; sh[A][j] = 0.f; s1[A][j] = 0.f; s2[A][j] = 0.f; }
   if constexpr (EV == 3 || EV == 4) {
 #pragma unroll
     for (int A = 0; A < NA; ++A) {
@@ -190,105 +301,34 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvK& p, const f32x4
       }
     }
   }
+}
+
+// Pixel blocks [B0, B1) in chunks of BCH: reads of a chunk issued back to back, then its arithmetic and stores.  The
+// empty asm keeps the compiler from hoisting the NEXT chunk's reads above this chunk (BCH bounds the registers the
+// reads in flight take: hoisted all together they spilled).
+template <int EV, bool SH, int NI, int MI, int B0, int B1, int BCH>
+__device__ __forceinline__ void conv_epilogue_range(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
+                                                    const float (&sh)[NI / 2][8], const float (&sc)[NI / 2][8],
+                                                    float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
+  static_assert((B1 - B0) % BCH == 0 && B0 >= 0 && B1 <= MI, "chunks");
+  constexpr int NA = NI / 2;
 #pragma unroll
-  for (int A = 0; A < NA; ++A)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[A][j] = 0.f; s2[A][j] = 0.f; }
-  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
-#pragma unroll
-  for (int b0 = 0; b0 < MI; b0 += BCH) {
-    unsigned yo[BCH][NA], so[BCH][NA], ao[BCH][NA];
+  for (int b0 = B0; b0 < B1; b0 += BCH) {
     u32x4 la[BCH][NA], lb[BCH][NA];
-    // ---- phase 1: addresses of the chunk, every read issued
-#pragma unroll
-    for (int bb = 0; bb < BCH; ++bb) {
-      const int m = mlane + (b0 + bb) * 16;
-      int img, pix;
-      {
-        const unsigned mm = m < p.M ? (unsigned)m : 0u;
-        if (SH && p.parity) {
-          int oh_, ow_;
-          decode_pixel_parity(p, mm, img, oh_, ow_);
-          pix = oh_ * p.W_out + ow_;
-        } else {
-          img = (int)fast_div(mm, p.mg_hw, p.sh_hw);
-          pix = (int)mm - img * p.HW_out;
-        }
-      }
-#pragma unroll
-      for (int A = 0; A < NA; ++A) {
-        const int c0 = clane + 32 * A;
-        const bool ok = m < p.M && c0 < p.C_out;
-        yo[bb][A] = ok ? (unsigned)((img * p.y_img_stride + pix * p.ldy + c0) * 2) : kOOB;
-        if constexpr (EV == 4) {
-          so[bb][A] = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
-          la[bb][A] = buf_load16(kr_, so[bb][A]);
-        } else if constexpr (EV == 2) {
-          ao[bb][A] = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
-          so[bb][A] = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
-          if (do_acc) la[bb][A] = buf_load16(ar, ao[bb][A]);
-          if (do_mask) lb[bb][A] = buf_load16(kr_, so[bb][A]);
-        }
-      }
-    }
-    // ---- phase 2: arithmetic and stores
-#pragma unroll
-    for (int bb = 0; bb < BCH; ++bb) {
-      const int b = b0 + bb;
-#pragma unroll
-      for (int A = 0; A < NA; ++A) {
-        float v[8] = {acc[2 * A][b][0], acc[2 * A][b][1], acc[2 * A][b][2], acc[2 * A][b][3],
-                      acc[2 * A + 1][b][0], acc[2 * A + 1][b][1], acc[2 * A + 1][b][2], acc[2 * A + 1][b][3]};
-        if constexpr (EV == 3) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[A][j] + sh[A][j];
-        } else if constexpr (EV == 4) {
-          const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[A][2 * j]);
-            v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[A][2 * j + 1]);
-          }
-        } else {
-          if (p.rscale != 0.f) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
-          }
-        }
-        if constexpr (EV == 2) {
-          if (do_acc) {
-            const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(w[j] & 0xffffu); v[2 * j + 1] += bf2f(w[j] >> 16); }
-          }
-          if (do_mask) {                      // relu backward of the tensor this gradient belongs to
-            const unsigned w[4] = {lb[bb][A].x, lb[bb][A].y, lb[bb][A].z, lb[bb][A].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (!(bf2f(w[j] & 0xffffu) > 0.f)) v[2 * j] = 0.f;
-              if (!(bf2f(w[j] >> 16) > 0.f)) v[2 * j + 1] = 0.f;
-            }
-          }
-        }
-        if constexpr (EV == 3 || EV == 4) {
-          if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-        }
-        unsigned q8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)},
-                                               yr, (int)yo[bb][A], 0, 0);
-        if constexpr (EV == 1) {
-          // (out-of-tile lanes hold exact zeros -- zero-filled pixel rows / filter rows -- and add nothing)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[A][j] += f; s2[A][j] += f * f; }
-        }
-      }
-    }
+    conv_epilogue_issue_reads<EV, SH, NA, BCH>(p, mlane, clane, b0, la, lb);
+    conv_epilogue_finish<EV, SH, NI, MI, BCH>(p, acc, mlane, clane, b0, la, lb, sh, sc, s1, s2);
+    if (b0 + BCH < B1) asm volatile("" ::: "memory");
   }
+}
+
+template <int EV, bool SH, int NI, int MI, int BCH = MI>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
+                                                     float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
+  static_assert(NI % 2 == 0 && EV != 5 && MI % BCH == 0, "wave tile: a multiple of 32 output channels; float32 heads are handled by the caller");
+  constexpr int NA = NI / 2;
+  float sc[NA][8], sh[NA][8];
+  conv_epilogue_channels<EV, NA>(p, clane, sc, sh, s1, s2);
+  conv_epilogue_range<EV, SH, NI, MI, 0, MI, BCH>(p, acc, mlane, clane, sh, sc, s1, s2);
 }
 
 }  // namespace
