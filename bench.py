@@ -223,8 +223,8 @@ def committed_traffic():
             n = mb = 0.0
             for kern in ("conv_igemm3_kernel", "conv_igemm5_kernel"):
                 if kern in j:
-                    n += j[kern]["launches"]
-                    mb += j[kern]["launches"] * j[kern]["MB_per_launch"]
+                    n += j[kern]["calls"]
+                    mb += j[kern]["calls"] * j[kern]["MB_per_launch"]
             if n <= 0:
                 continue
             return mb / n * 1e6, os.path.relpath(pj, ROOT) + \

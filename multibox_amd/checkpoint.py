@@ -10,7 +10,33 @@ import re
 import torch
 
 
-def save(logdir, trainer, max_to_keep=3):
+def _prune(logdir, max_to_keep, keep_every_n_hours, now=None):
+    """tf.train.Saver's retention (train.py:282-286): the newest max_to_keep checkpoints stay; an older one that is about to
+    be deleted is KEPT FOR GOOD instead if it was written at least keep_checkpoint_every_n_hours after the previous
+    permanently kept one (Saver._next_checkpoint_time; the clock starts at the first save into this directory).  The
+    little state TF keeps in the Saver object lives in <logdir>/checkpoint_retention.json here, so that it survives restarts."""
+    import json
+    import time
+    state_path = os.path.join(logdir, "checkpoint_retention.json")
+    try:
+        st = json.load(open(state_path))
+    except (OSError, ValueError):
+        st = {"next_keep_time": (now if now is not None else time.time()) + 3600.0 * keep_every_n_hours, "kept": []}
+    kept = set(st["kept"])
+    olds = sorted((p for p in glob.glob(os.path.join(logdir, "model.ckpt-*.pt")) if os.path.basename(p) not in kept), key=_step_of)
+    for p in olds[:-max_to_keep] if max_to_keep > 0 else []:
+        t = os.path.getmtime(p)
+        if keep_every_n_hours > 0 and t > st["next_keep_time"]:
+            st["kept"].append(os.path.basename(p))
+            st["next_keep_time"] += 3600.0 * keep_every_n_hours
+        else:
+            os.remove(p)
+    tmp = state_path + ".tmp"
+    json.dump(st, open(tmp, "w"))
+    os.replace(tmp, state_path)
+
+
+def save(logdir, trainer, max_to_keep=3, keep_checkpoint_every_n_hours=10000.0):
     net = trainer.net
     os.makedirs(logdir, exist_ok=True)
     path = os.path.join(logdir, "model.ckpt-%d.pt" % trainer.global_step)
@@ -24,9 +50,7 @@ def save(logdir, trainer, max_to_keep=3):
     tmp = path + ".tmp"                             # a kill in mid-save must not leave a truncated newest checkpoint
     torch.save(state, tmp)
     os.replace(tmp, path)
-    olds = sorted(glob.glob(os.path.join(logdir, "model.ckpt-*.pt")), key=_step_of)
-    for p in olds[:-max_to_keep]:
-        os.remove(p)
+    _prune(logdir, max_to_keep, float(keep_checkpoint_every_n_hours))
     return path
 
 

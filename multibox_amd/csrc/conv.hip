@@ -170,7 +170,7 @@ conv_igemm3_kernel(const ConvK p) {
     if (more) MBX_ISSUE_TILE(it + NSTG - 1);
     st_comp = st_comp == NSTG - 1 ? 0 : st_comp + 1;    // now the slot of tile it+1; tile `it` is in st_prev
     const int st_prev = st_comp == 0 ? NSTG - 1 : st_comp - 1;
-#ifndef MBX_NO_LANDING_PROBE                      // (debug builds only: A/B of what the hand-off costs)
+#ifndef MBX_NO_PROBE_I3                      // (debug builds only: A/B of what the hand-off costs)
     unsigned probe;
     if constexpr (NSTG == 3) {
       // 3-deep: tile it+1 was issued a whole step ago: wait for it HERE (tile it+2 is in flight meanwhile) and start
@@ -198,7 +198,7 @@ conv_igemm3_kernel(const ConvK p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
       }
     }
-#ifndef MBX_NO_LANDING_PROBE
+#ifndef MBX_NO_PROBE_I3
     if constexpr (NSTG == 2) {
       wait_vmcnt<0>();                                  // tile it+1 (issued at the top of this step) has retired
       probe = lds_readback_issue(probe_base + st_comp * STAGE);
@@ -782,7 +782,7 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
     for (int it = 0; it < nsteps; ++it) {
       const bool more = it + 2 < nsteps;
       st_pub = st_pub == NST - 1 ? 0 : st_pub + 1;        // slot of step it+1
-#ifndef MBX_NO_LANDING_PROBE
+#ifndef MBX_NO_PROBE_WG
       if (more) { MBX_ISSUE_STEP5_Y(); wait_vmcnt<NY>(); } else wait_vmcnt<0>();   // step it+1 has retired (this wave's share)
       const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NSUB - 1) * 512 + lw * 64 + lane);
       if (more) MBX_ISSUE_STEP5_X();
@@ -801,7 +801,7 @@ __device__ __forceinline__ void wgrad5_body(const WgradK2& q, u32x4* smem, const
         }
         st_bias = st_bias == NST - 1 ? 0 : st_bias + 1;
       }
-#ifndef MBX_NO_LANDING_PROBE
+#ifndef MBX_NO_PROBE_WG
       lds_readback_wait(probe);                           // read-back returned: publish step it+1
 #else
       (void)probe;

@@ -166,7 +166,7 @@ conv_igemm5_kernel(const ConvK p) {
 #ifdef MBX_I5_STAMPS
         if (p.dbg & 2) { if (more) MBX5_ISSUE_B(); raw_barrier(); continue; }   // timing probe: do not wait for the landing (wrong results)
 #endif
-#ifndef MBX_NO_LANDING_PROBE
+#ifndef MBX_NO_PROBE_I5
         // the NEXT step (steps s+1 .. s+NST-2 are outstanding, + the MY pieces just issued) has retired: this wave's share
         if (more) wait_vmcnt<(NST - 3) * NL + MY>(); else wait_vmcnt<0>();
         const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane);

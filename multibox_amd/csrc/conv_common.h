@@ -132,6 +132,13 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// debug builds only (tools/ab_builds.sh): what the landing hand-off costs, per kernel family
+#ifdef MBX_NO_LANDING_PROBE
+#define MBX_NO_PROBE_I3 1
+#define MBX_NO_PROBE_I5 1
+#define MBX_NO_PROBE_WG 1
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -144,9 +151,12 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // same probe cost 1.5 ms per step in the loader waves of the deep rings.  Written as inline asm the compiler adds no
 // wait: the issue is free-standing and lds_readback_wait() waits on lgkmcnt only.  (The flat load also holds a vmcnt
 // slot until it returns; a counted vmcnt wait issued after it can only become more conservative by that one.)
+// lds_slot: the calling lane's 16-byte slot of the piece (piece base + lane); the lanes read CONSECUTIVE dwords of the
+// piece's first 256 bytes instead (base + 4 lane): with dwords at a 16-byte stride the 64 lanes met 8 banks four ways and
+// the read-back alone was 11 % of the convolution kernels' LDS cycles (SQ_LDS_BANK_CONFLICT, profiles/r03_conv_lds_counters.txt)
 __device__ __forceinline__ unsigned lds_readback_issue(const void* lds_slot) {
   unsigned v;
-  const unsigned long long a = reinterpret_cast<unsigned long long>(lds_slot);    // generic address: shared aperture | offset
+  const unsigned long long a = reinterpret_cast<unsigned long long>(lds_slot) - 12ull * (threadIdx.x & 63);   // generic address: shared aperture | offset
   asm volatile("flat_load_dword %0, %1" : "=v"(v) : "v"(a) : "memory");
   return v;
 }

@@ -161,3 +161,24 @@ def test_oracle_nms_known_answers():
     assert R.nms_greedy(b, 0.1).tolist() == [0, 3]
     assert R.nms_greedy(b, 1.0).tolist() == [0, 1, 2, 3, 4]
     assert R.nms_greedy(np.zeros((0, 4)), 0.5).tolist() == []
+
+
+def test_checkpoint_retention_like_tf_saver(tmp_path):
+    """tf.train.Saver(max_to_keep, keep_checkpoint_every_n_hours) (train.py:282-286): the newest max_to_keep files stay, and a
+    file about to be deleted is kept for good if it is at least N hours younger than the previous permanent one."""
+    import json
+    import time
+    from multibox_amd import checkpoint as CK
+    d = str(tmp_path)
+    t0 = time.time() - 10 * 3600
+    for i, hours in enumerate([0.0, 0.5, 1.0, 2.5, 3.0, 5.2, 5.3, 6.0]):          # "saved" at t0 + hours
+        p = os.path.join(d, "model.ckpt-%d.pt" % (100 * i))
+        open(p, "wb").write(b"x")
+        os.utime(p, (t0 + 3600 * hours, t0 + 3600 * hours))
+        CK._prune(d, max_to_keep=2, keep_every_n_hours=2.0, now=t0)
+    left = sorted(os.listdir(d))
+    # permanent: 300 (2.5 h > first deadline t0 + 2 h; the deadline moves to 4 h) and 500 (5.2 h > 4 h; -> 6 h);
+    # newest two: 600, 700; everything else was deleted when it fell out of the window
+    assert [f for f in left if f.endswith(".pt")] == ["model.ckpt-300.pt", "model.ckpt-500.pt", "model.ckpt-600.pt", "model.ckpt-700.pt"]
+    assert json.load(open(os.path.join(d, "checkpoint_retention.json")))["kept"] == ["model.ckpt-300.pt", "model.ckpt-500.pt"]
+    assert CK.latest_checkpoint(d).endswith("model.ckpt-700.pt")

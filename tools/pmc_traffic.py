@@ -1,4 +1,4 @@
-"""Build profiles/r01_hbm_traffic_pmc.json from two rocprofv3 --pmc passes of the same command:
+"""Build profiles/rNN_hbm_traffic_pmc.json from two rocprofv3 --pmc passes of the same command:
    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR_F -o f -- python bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline
    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d DIR_W -o w -- python bench.py ... (same)
 usage: python tools/pmc_traffic.py DIR_F/f_counter_collection.csv DIR_W/w_counter_collection.csv STEPS out.json
@@ -38,7 +38,8 @@ res["_per_step"] = {"fetch_GB": round(tf / 1e9 / steps, 2), "write_GB": round(tw
                     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); FETCH counts L2 misses incl. Infinity Cache hits"}
 import hashlib, os
 _conv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multibox_amd", "csrc", "conv.hip")
-res["conv_hip_sha"] = hashlib.sha256(open(_conv, "rb").read()).hexdigest()[:16]     # bench.py prints traffic only if this matches
+res["conv_hip_sha"] = hashlib.sha256(open(_conv, "rb").read()).hexdigest()[:16]     # bench.py prints traffic only if these match
+res["conv5_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv5.hip"), "rb").read()).hexdigest()[:16]
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res.items():
     print(k, v)

@@ -93,8 +93,11 @@ def main():
         w0, b0 = net.W.clone(), net.Bt.clone()
         snap = {k: getattr(tr, k).clone() for k in ("Wms", "Btms", "Wema", "Btema") if getattr(tr, k, None) is not None}
         mm0, mv0, gs0 = net.MM.clone(), net.MV.clone(), tr.global_step
-        for _ in range(steps):
+        for i in range(steps):
             tr.step()
+            if (i + 1) % 200 == 0:                       # (a silent GPU job is taken to be hung after 7 minutes)
+                torch.cuda.synchronize()
+                print("quiet run: step %d" % (i + 1), file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         reference = (net.W.clone(), net.Bt.clone())
         net.W.copy_(w0); net.Bt.copy_(b0); net.MM.copy_(mm0); net.MV.copy_(mv0); tr.global_step = gs0
@@ -112,6 +115,8 @@ def main():
             if not (bool(torch.isfinite(net.W).all()) and bool(torch.isfinite(net.Bt).all())):
                 first_bad = step
                 break
+            if step % 100 == 0:
+                print("noisy run: step %d, %d noise launches" % (step, launched[0]), file=sys.stderr, flush=True)
     stop.set()
     th.join()
     torch.cuda.synchronize()

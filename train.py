@@ -168,12 +168,12 @@ def main():
             log.flush()
             step0, t_log = tr.global_step, now
         if rank == 0 and time.time() - t_save > cfg.SAVE_INTERVAL_SECS:
-            CK.save(args.logdir, tr, cfg.MAX_TO_KEEP)
+            CK.save(args.logdir, tr, cfg.MAX_TO_KEEP, cfg.get("KEEP_CHECKPOINT_EVERY_N_HOURS", 10000.0))
             t_save = time.time()
     if real is not None:
         real.close()                                              # stop the input worker processes
     if rank == 0:
-        print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP))
+        print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP, cfg.get("KEEP_CHECKPOINT_EVERY_N_HOURS", 10000.0)))
     if world > 1:
         torch.distributed.destroy_process_group()
 
