@@ -140,7 +140,9 @@ def test_conv_epilogues(T):
 
 
 @pytest.mark.parametrize("g", [("e1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("e7", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
-                               ("e3", 2, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1))], ids=["1x1", "1x7", "3x3"])
+                               ("e3", 2, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1)),
+                               # more tiles than CUs (308 of 128x64, 2.4 per workgroup of 128x128 ...): the queue really hands tiles out
+                               ("e4", 16, 35, 35, 64, 320, 1, 1, 1, (0, 0, 0, 0))], ids=["1x1", "1x7", "3x3", "1x1_many_tiles"])
 def test_igemm5_epilogues_bit_identical(T, g):
     """Every epilogue of the persistent igemm5 launch (statistics, frozen-BN affine, residual, accumulate + ReLU mask,
     plain scaled store) against the igemm3 launch of the same descriptor: same arithmetic in the same order."""
@@ -190,6 +192,20 @@ def test_igemm5_epilogues_bit_identical(T, g):
             if kind == "stats":      # partial rows differ with the tile height; their totals are sums of the same bf16 values
                 a, b = st0.double().sum(0), st1.double().sum(0)
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-3), "%s stats cfg %d" % (name, cfg)
+            # QUEUED tile assignment (mbx_conv_desc.work_counter, a zeroed device int32): the same tiles pulled from a counter
+            # instead of dealt statically -- identical output AND identical statistics partials; the launch leaves the
+            # counter advanced by the tiles it handed out plus one failed fetch per workgroup lane that ran dry
+            ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+            y2 = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+            st2 = torch.zeros((rows1, Co, 2), device="cuda")
+            d2 = variants(y2, st2)[kind]
+            d2.tile_config = cfg
+            d2.work_counter = ctr.data_ptr()
+            assert l.mbx_conv(C.byref(d2), stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y1.tensor(), y2.tensor()), "%s %s cfg %d queued" % (name, kind, cfg)
+            if kind == "stats":
+                assert torch.equal(st1, st2), "%s stats cfg %d queued" % (name, cfg)
 
 
 def test_conv_f32_head_output(T):
