@@ -244,11 +244,17 @@ class Trainer:
         net.zero_grads()
 
     def _capture(self):
-        """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture."""
+        """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture.  The warm-up pass is not a training
+        step: the BN moving statistics it touched are put back (the captured step that follows would otherwise apply this
+        batch's moving-average update twice -- at the first step and after every in-process re-capture)."""
+        net = self.net
+        mm, mv = net.MM.clone(), net.MV.clone()
         self._front()
         for fns, _, _ in self._segments:
             for f in fns:
                 f()
+        net.MM.copy_(mm)
+        net.MV.copy_(mv)
         torch.cuda.synchronize()
         graphs = []
         # thread_local: RCCL's watchdog thread may query events while we capture (data-parallel runs)
