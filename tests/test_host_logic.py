@@ -182,3 +182,30 @@ def test_checkpoint_retention_like_tf_saver(tmp_path):
     assert [f for f in left if f.endswith(".pt")] == ["model.ckpt-300.pt", "model.ckpt-500.pt", "model.ckpt-600.pt", "model.ckpt-700.pt"]
     assert json.load(open(os.path.join(d, "checkpoint_retention.json")))["kept"] == ["model.ckpt-300.pt", "model.ckpt-500.pt"]
     assert CK.latest_checkpoint(d).endswith("model.ckpt-700.pt")
+
+
+def test_record_text_is_byte_identical_to_json_dump_of_the_dicts():
+    """detect.py:438-460 writes json.dump(list of {"image_id", "bbox", "score"}); multibox_amd/records.py produces the same
+    TEXT without building the dicts (in worker processes) -- byte for byte, including non-finite numbers, -0.0, tiny and
+    huge values, string ids that need escaping, empty patches and empty batches."""
+    import json
+    from multibox_amd import detect as D, records as REC
+    rng = np.random.RandomState(0)
+    B, K = 16, 40
+    boxes = rng.rand(B, K, 4) * 300
+    boxes[3, 5, 2] = 1e-7; boxes[4, 0, 0] = 1e22; boxes[5, 1, 1] = float("nan"); boxes[6, 0, 0] = float("inf"); boxes[7, 0, 0] = -0.0
+    scores = rng.rand(B, K).astype(np.float32)
+    scores[2, 3] = np.float32("nan"); scores[1, 0] = np.float32(1e-30)
+    count = np.array([40, 25, 0] + [7] * 13, np.int32)
+    ids = list(range(B - 1)) + ['abc"x\\']
+    want = json.dumps(D.results_to_json_records(boxes, scores, count, ids))
+    recs = REC.results_to_json_text(boxes, scores, count, ids)
+    assert len(recs) == int(count.sum()) and REC.records_to_json(recs) == want
+    n, chunk = REC.batch_chunk(boxes, scores, count, ids)
+    assert n == int(count.sum()) and REC.records_to_json([chunk]) == want
+    # chunks of several batches, empty ones in between, and no records at all
+    n2, chunk2 = REC.batch_chunk(boxes[:2], scores[:2], count[:2], ids[:2])
+    assert REC.records_to_json([chunk2, "", chunk]) == json.dumps(
+        D.results_to_json_records(boxes[:2], scores[:2], count[:2], ids[:2]) + D.results_to_json_records(boxes, scores, count, ids))
+    assert REC.records_to_json([]) == json.dumps([]) == "[]"
+    assert REC.records_to_json([""]) == "[]"
