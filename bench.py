@@ -164,7 +164,7 @@ def timed_eager_pass(run, entry_points=None):
     return out, pair_ms, plain_ms
 
 
-KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm5_kernel")), ("wgrad", ("conv_wgrad",)),
+KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel")), ("wgrad", ("conv_wgrad",)),
                   ("bn_fwd", ("bn_finalize_kernel", "bn_apply_kernel", "bn_apply_fused_kernel")), ("bn_bwd", ("bn_bwd_",)))
 
 
@@ -210,29 +210,29 @@ def _file_sha(path):
 
 
 def committed_traffic():
-    """HBM bytes per launch of the dominant kernel class (conv_igemm3_kernel + conv_igemm5_kernel launches, weighted by
-    their launch counts) from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- only if that profile was
-    taken on THESE kernel sources (the file stamps the sha256 of csrc/conv.hip and csrc/conv5.hip); a stale profile prints null."""
+    """HBM bytes per launch of the dominant kernel class (conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel launches,
+    weighted by their launch counts) from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- only if that profile was
+    taken on THESE kernel sources (the file stamps the sha256 of csrc/conv.hip, conv5.hip and conv7.hip); a stale profile prints null."""
     import glob
-    shas = {k: _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", f)) for k, f in (("conv_hip_sha", "conv.hip"), ("conv5_hip_sha", "conv5.hip"))}
+    shas = {k: _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", f)) for k, f in (("conv_hip_sha", "conv.hip"), ("conv5_hip_sha", "conv5.hip"), ("conv7_hip_sha", "conv7.hip"))}
     for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
         try:
             j = json.load(open(pj))
             if any(j.get(k) != v for k, v in shas.items()):
                 continue
             n = mb = 0.0
-            for kern in ("conv_igemm3_kernel", "conv_igemm5_kernel"):
+            for kern in ("conv_igemm3_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel"):
                 if kern in j:
                     n += j[kern]["calls"]
                     mb += j[kern]["calls"] * j[kern]["MB_per_launch"]
             if n <= 0:
                 continue
             return mb / n * 1e6, os.path.relpath(pj, ROOT) + \
-                " (launch-weighted mean over conv_igemm3_kernel and conv_igemm5_kernel; FETCH_SIZE x2 gfx950 correction + " \
+                " (launch-weighted mean over conv_igemm3_kernel, conv_igemm5_kernel and conv_igemm7_kernel; FETCH_SIZE x2 gfx950 correction + " \
                 "WRITE_SIZE, separate --pmc passes; source shas match)"
         except Exception:
             continue
-    return None, "no committed PMC profile matches the current csrc/conv.hip + conv5.hip (%s)" % shas
+    return None, "no committed PMC profile matches the current csrc/conv.hip + conv5.hip + conv7.hip (%s)" % shas
 
 
 def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominant="igemm", traced=None):
@@ -257,7 +257,7 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
-    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel (implicit-GEMM convolution: forward + data-gradient launches)",
+    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel (implicit-GEMM convolution: forward + data-gradient launches)",
             "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
@@ -339,7 +339,7 @@ def detect_leg(args, world, rank, pg):
             classes, pair_ms, _ = timed_eager_pass(one, ["mbx_conv"])
             d = classes["igemm"]
             ach = d["work"] / (d["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                                "traffic": None, "launches_per_batch": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2)}
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -495,7 +495,8 @@ def main():
                "final_losses": {"location": round(losses[0], 3), "confidence": round(losses[1], 3), "regularization": round(losses[2], 4)},
                "matching_ok": status_ok, "grid_barrier_timeouts": barrier_timeouts, "rccl": rccl,
                # the kernel mix of THIS run (data-parallel runs cap the BN-backward grid; both use the same conv kernels)
-               "kernels": {"igemm5_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 32),
+               "kernels": {"igemm5_launches": sum(1 for _, d_, _ in net.tune_registry if 32 < d_.tile_config < 64),
+                           "igemm7_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 64),
                            "bn_backward": "three-launch" if net.no_onepass else "one-launch (grid barrier, max %s workgroups)" % (net.bn_max_wg or "all"),
                            "skipped_steps_events": tr.events},
                "algorithmic_tflop_per_step": round(per_image_gflop * 1e-3 * B * world, 3)}

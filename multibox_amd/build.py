@@ -22,6 +22,7 @@ SOURCES = {
     "postproc.hip": ["-ffp-contract=off"],
     "conv.hip": ["-munsafe-fp-atomics"],
     "conv5.hip": [],
+    "conv7.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
     "augment.hip": ["-ffp-contract=off"],
 }

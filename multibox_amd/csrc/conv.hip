@@ -19,6 +19,8 @@
 
 // conv5.hip: persistent igemm5 launches (mbx_conv_desc.tile_config = kI5Flag + index + 1)
 int mbx_launch_igemm5(void* convk, int index, hipStream_t s);
+// conv7.hip: the panel-resident pointwise launch (mbx_conv_desc.tile_config = kI7Cfg)
+int mbx_launch_igemm7(void* convk, hipStream_t s);
 extern const int mbx_i5_tiles[][2];
 extern const int mbx_i5_num_tiles;
 
@@ -1050,6 +1052,7 @@ int pick_cfg(long M, int C_out) {
 
 constexpr int kNumCfgs = 14;
 constexpr int kI5Flag = 32;      // mbx_conv_desc.tile_config = 32 + t: igemm5 tile t (conv5.hip), persistent launch
+constexpr int kI7Cfg = 65;       // mbx_conv_desc.tile_config = 65: igemm7 (conv7.hip), persistent pointwise launch with the filter panel in LDS
 int choose_cfg(long M, int C_out, int desc_cfg) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
@@ -1145,6 +1148,7 @@ int check_desc(const mbx_conv_desc* d) {
 extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   if (!d) return MBX_ERR_INVALID_ARG;
   const long M = (long)d->N * d->H_out * d->W_out;
+  if (d->tile_config == kI7Cfg) return (int)((M + 127) / 128);
   if (d->tile_config > kI5Flag) {
     const int i = d->tile_config - kI5Flag - 1;
     if (i >= mbx_i5_num_tiles) return MBX_ERR_INVALID_ARG;
@@ -1228,6 +1232,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
     k.skip_taps = k.parity = 1;
   }
   hipStream_t s = mbx_s(stream);
+  if (d->tile_config == kI7Cfg) return mbx_launch_igemm7(&k, s);
   if (d->tile_config > kI5Flag) return mbx_launch_igemm5(&k, d->tile_config - kI5Flag - 1, s);
   switch (choose_cfg(k.M, k.C_out, d->tile_config)) {
     case 0: return launch_igemm<128, 128, 2, 2>(k, s);

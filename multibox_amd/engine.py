@@ -87,7 +87,7 @@ class Net:
         self.bn_max_wg = int(os.environ.get("MBX_BN_MAX_WG", "0")) or (bn_max_workgroups or 0)
         # work counters of the persistent igemm5 launches (mbx_conv_desc.work_counter): one per launch, cleared together
         # at the start of every pass (forward() / backward())
-        self.i5_counters = torch.zeros(2048, dtype=torch.int32, device=device)
+        self.i5_counters = torch.zeros(8192, dtype=torch.int32, device=device)
         self._i5_used = 0
         self.convs, self.fwd, self.bwd = [], [], []
         self.grad_alias = {}       # id(activation buffer) -> gradient buffer
@@ -477,9 +477,10 @@ class Net:
             # igemm5 launch therefore gets a work counter (tiles after a workgroup's first are pulled from it, like the
             # items of the grouped weight gradient) -- the same kernels with and without torch.distributed.
             if d.tile_config > ops.I5_FLAG and os.environ.get("MBX_I5_STATIC") != "1":
-                assert self._i5_used < self.i5_counters.numel()
+                n = ops.I7_COUNTERS if d.tile_config == ops.I7_TILE_CONFIG else 1        # igemm7: one counter per column tile
+                assert self._i5_used + n <= self.i5_counters.numel()
                 d.work_counter = self.i5_counters.data_ptr() + 4 * self._i5_used
-                self._i5_used += 1
+                self._i5_used += n
             if os.environ.get("MBX_NO_2STAGE") == "1":                     # bisecting aid: 3-deep-ring twins of the 2-deep tiles
                 d.tile_config = {9: 7, 10: 2, 11: 5, 12: 2, 13: 8, 14: 1}.get(d.tile_config, d.tile_config)
         return d

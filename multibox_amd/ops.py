@@ -135,6 +135,8 @@ def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
 N_TILE_CONFIGS = 14
 I5_FLAG = 32                                   # tile_config 32 + t: persistent igemm5 launch (csrc/conv5.hip), tile t
 I5_TILE_CONFIGS = (33, 34, 35, 36, 37)         # 128x64, 128x128, 192x128, 256x128, 256x64
+I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
+I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
 _TUNED = {}          # repr(shape key) -> tile_config: one measurement per distinct conv in a process
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")
 

@@ -208,6 +208,58 @@ def test_igemm5_epilogues_bit_identical(T, g):
                 assert torch.equal(st1, st2), "%s stats cfg %d queued" % (name, cfg)
 
 
+@pytest.mark.parametrize("g", [("p1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("p2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
+                               ("p3", 16, 17, 17, 320, 1088, 1, 1, 1, (0, 0, 0, 0)), ("p4", 5, 35, 35, 96, 320, 1, 1, 1, (0, 0, 0, 0)),
+                               ("p5", 64, 8, 8, 384, 2080, 1, 1, 1, (0, 0, 0, 0))], ids=["k384", "k128", "k320_many_tiles", "k96", "k384_n2080"])
+def test_igemm7_panel_resident_bit_identical(T, g):
+    """The persistent pointwise launch with the filter panel resident in LDS (tile_config 65, csrc/conv7.hip) against the
+    igemm3 launch of the same descriptor, every epilogue it supports (affine, residual, accumulate + ReLU mask, scaled
+    store), statically dealt and with work counters: same arithmetic in the same order -> bit-identical."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=31)
+    gen = torch.Generator().manual_seed(32)
+    xb = ops.View.alloc(N, H, W, Ci + 8).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    sc, sh = (torch.rand(Co, generator=gen) + 0.5).cuda(), torch.randn(Co, generator=gen).cuda()
+    skip = ops.View.alloc(N, H, W, Co + 8).slice(8, Co)
+    skip.tensor().copy_(torch.randn(N, H, W, Co, generator=gen).to(torch.bfloat16))
+    old = ops.View.alloc(N, H, W, Co)
+    old.tensor().copy_(torch.randn(N, H, W, Co, generator=gen).to(torch.bfloat16))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def variants(y):
+        return {
+            "affine": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, epilogue=ops.EPI_AFFINE, relu=1, scale=sc, shift=sh),
+            "residual": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17),
+            "acc_mask": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, accumulate=1, skip=skip, acc_src=old, rscale=0.2),
+            "acc_only": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, accumulate=1, acc_src=old),
+            "scaled": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, rscale=0.3),
+        }
+    y0, y1 = ops.View.alloc(N, H, W, Co, zero=True), ops.View.alloc(N, H, W, Co, zero=True)
+    for kind in ("affine", "residual", "acc_mask", "acc_only", "scaled"):
+        d0 = variants(y0)[kind]
+        assert l.mbx_conv(C.byref(d0), stream) == 0
+        for queued in (False, True):
+            d1 = variants(y1)[kind]
+            d1.tile_config = ops.I7_TILE_CONFIG
+            ctr = torch.zeros(ops.I7_COUNTERS, dtype=torch.int32, device="cuda")
+            if queued:
+                d1.work_counter = ctr.data_ptr()
+            y1.tensor().zero_()
+            assert l.mbx_conv(C.byref(d1), stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y0.tensor(), y1.tensor()), "%s %s queued=%s" % (name, kind, queued)
+    # what it does not apply to is refused, not computed wrongly: statistics epilogue, K > 384, 3x3
+    d = ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y1, stats=torch.zeros((ops.conv_stats_rows(variants(y1)["scaled"]) + 8, Co, 2), device="cuda"))
+    d.tile_config = ops.I7_TILE_CONFIG
+    assert l.mbx_conv(C.byref(d), stream) == -2                      # MBX_ERR_UNSUPPORTED
+
+
 def test_conv_f32_head_output(T):
     """model.py:213-219: 1x1, no BN/bias/act, C_out = 5k = 25 (locations 4k + confidences k), fp32 out."""
     torch = T

@@ -40,6 +40,7 @@ import hashlib, os
 _conv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multibox_amd", "csrc", "conv.hip")
 res["conv_hip_sha"] = hashlib.sha256(open(_conv, "rb").read()).hexdigest()[:16]     # bench.py prints traffic only if these match
 res["conv5_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv5.hip"), "rb").read()).hexdigest()[:16]
+res["conv7_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv7.hip"), "rb").read()).hexdigest()[:16]
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res.items():
     print(k, v)

@@ -14,7 +14,7 @@ names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "pack_input" in n]
 step = rows[starts[-1]:]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-ig = [r for r in step if "conv_igemm3" in r["Kernel_Name"] or "conv_igemm5" in r["Kernel_Name"]]      # igemm5: the persistent launches
+ig = [r for r in step if any(k in r["Kernel_Name"] for k in ("conv_igemm3", "conv_igemm5", "conv_igemm7"))]      # igemm5: the persistent launches
 wg = [r for r in step if "conv_wgrad2" in r["Kernel_Name"]]
 net = Net(batch=B, device="cpu")
 convs = [op for op in net.fwd if isinstance(op, ConvOp)]
@@ -25,7 +25,7 @@ dg = ig[n_f:]
 dgi = iter(dg)
 rec = {}
 for op, r in zip(convs, fwd):
-    rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": ("i5:" if "igemm5" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1), "fwd_grid": r["Grid_Size_X"]}
+    rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": ("i5:" if "igemm5" in r["Kernel_Name"] else "i7:" if "igemm7" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1), "fwd_grid": r["Grid_Size_X"]}
 if len(wg) == len(bw):          # per-layer weight-gradient launches (round 1); the grouped launches have no per-layer time
     for op, r in zip(bw, wg):
         rec[id(op)]["wg"] = dur(r)
@@ -34,7 +34,7 @@ for op in bw:
     if op.need_dx:
         d = next(dgi)
         rec[id(op)]["dg"] = dur(d)
-        rec[id(op)]["dg_k"] = ("i5:" if "igemm5" in d["Kernel_Name"] else "") + re.search(r"<([^>]*)>", d["Kernel_Name"]).group(1)
+        rec[id(op)]["dg_k"] = ("i5:" if "igemm5" in d["Kernel_Name"] else "i7:" if "igemm7" in d["Kernel_Name"] else "") + re.search(r"<([^>]*)>", d["Kernel_Name"]).group(1)
 print("%-58s %7s %5s %5s %3s | %7s %7s %7s | TF/s fwd dg wg | %s" % ("layer", "M", "Cin", "K", "RS", "fwd us", "dg us", "wg us", "cfg"))
 agg = {}
 tot = [0, 0, 0]
