@@ -506,6 +506,11 @@ class Net:
                 def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    # (timing probe of tools/whatif_probe.py: finalize only, `a` keeps the previous step's values)
+                    if getattr(self, "_probe_skip_apply", False) and ("/block" in op.name or "/Block8" in op.name):
+                        _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, self.bn_decay,
+                                                     mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "fin")
+                        return
                     _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, self.bn_decay,
                                                     op.y.data_ptr(), op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
                                                     mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_apply_fused")
@@ -682,7 +687,7 @@ class Net:
 
             def run(op=op, pre=pre, ddesc=ddesc):
                 s = st()
-                if pre is not None:
+                if pre is not None and not (op.kind == "bn" and getattr(self, "_probe_skip_bn_bwd", False)):
                     pre(s)
                 if ddesc is not None:
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)

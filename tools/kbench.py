@@ -78,7 +78,9 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
         bias = torch.zeros(Co, device="cuda")
         d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=bias, skip=skip, rscale=0.1)
         act = ops.View.alloc(B, H, W, Ci); act.buf.normal_()         # data gradient: accumulate + relu mask
-        d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1, accumulate=1, skip=act)
+        # KB_NOMASK=1: the same launch without the mask read (what a packed mask could save at most)
+        d_d = ops.make_desc(dy, wT, Ci, R, S, st, R - 1 - pt, S - 1 - pl, dx, transposed=1, accumulate=1,
+                            skip=None if os.environ.get("KB_NOMASK") else act)
     d_f.tile_config = kb_cfg; d_d.tile_config = kb_cfg
     import ctypes as _C
     from multibox_amd import _lib as _L
