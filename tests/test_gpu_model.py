@@ -463,3 +463,49 @@ def test_full_depth_backward_teacher_forced():
     whole_e = torch.cat([ge[n].reshape(-1) for n in names])
     whole_q = torch.cat([gq[n].reshape(-1) for n in names])
     assert _cos(whole_e, whole_q) >= 0.9998 and rel_l2(whole_e, whole_q) <= 2e-2, (_cos(whole_e, whole_q), rel_l2(whole_e, whole_q))
+
+
+def test_detect_forward_same_bits_with_shipped_tile_table_and_library_rule():
+    """The whole detect forward (BASELINE config 4: 256 patches, k = 7, folded BN) gives the SAME BITS with the shipped
+    tile table -- which sends launches to the persistent igemm5 kernel (queued tiles) and to the panel-resident igemm7
+    kernel -- as with the library's own rule (MBX_AUTOTUNE=0: igemm3 tiles only): `results never depend on tile_config`
+    (include/mbx.h) on the real layer shapes, not only on the test geometries of test_gpu_conv.py."""
+    import os
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd.engine import Net
+    from multibox_amd import ops
+    B = 256
+    gen = torch.Generator().manual_seed(11)
+    images = (torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1).cuda()
+
+    def run(autotune):
+        old = os.environ.get("MBX_AUTOTUNE")
+        os.environ["MBX_AUTOTUNE"] = "1" if autotune else "0"
+        try:
+            net = Net(batch=B, input_size=299, k=7, mode="infer", seed=5)
+        finally:
+            if old is None:
+                os.environ.pop("MBX_AUTOTUNE", None)
+            else:
+                os.environ["MBX_AUTOTUNE"] = old
+        g2 = torch.Generator().manual_seed(7)                      # moving statistics / betas away from their initial values
+        net.MM.copy_((torch.randn(net.nBt, generator=g2) * 0.05).cuda())
+        net.MV.copy_((torch.rand(net.nBt, generator=g2) * 0.5 + 0.75).cuda())
+        net.Bt.copy_((torch.randn(net.nBt, generator=g2) * 0.1).cuda())
+        net.fold_bn()
+        net.set_input(images)
+        locs, logits = net.forward()
+        torch.cuda.synchronize()
+        kinds = [d.tile_config for _, d, _ in net.tune_registry]
+        return locs.clone(), logits.clone(), net.features.tensor().clone(), kinds
+
+    l_t, c_t, f_t, kinds_t = run(True)
+    l_r, c_r, f_r, kinds_r = run(False)
+    assert sum(1 for k in kinds_t if ops.I5_FLAG < k < ops.I7_TILE_CONFIG) > 50 and ops.I7_TILE_CONFIG in kinds_t, \
+        "the shipped table no longer exercises the persistent kernels here"
+    assert all(k <= ops.N_TILE_CONFIGS for k in kinds_r)
+    assert bool(torch.isfinite(f_t.float()).all()) and float(f_t.float().abs().max()) > 0
+    assert torch.equal(f_t, f_r), "backbone features differ between tile tables"
+    assert torch.equal(l_t, l_r) and torch.equal(c_t, c_r), "head outputs differ between tile tables"
