@@ -32,9 +32,9 @@ def _build(torch, seed, pg=None, use_graph=True):
     return net, Trainer(net, pri, max_num_bboxes=13, use_graph=use_graph, process_group=pg)
 
 
-def _batch(torch, rank):
+def _batch(torch, rank, B=4):
     from multibox_amd.synth import synthetic_batch
-    images, gt, n = synthetic_batch(4, 299, 13, seed=40 + rank)
+    images, gt, n = synthetic_batch(B, 299, 13, seed=40 + rank)
     return torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda()
 
 
@@ -101,7 +101,7 @@ def test_two_rank_step_equals_summed_gradient_step(tmp_path):
     assert not torch.equal(r0["W"], w0.cpu())
 
 
-def _worker_shipped(rank, world, port, out_dir):
+def _worker_shipped(rank, world, port, out_dir, B=4):
     """The SHIPPED data-parallel configuration: one-launch batch-norm backward with a capped grid, measured tile table,
     hipGraph segments, bucketed async all-reduce.  Two ranks share this box's one GPU, so each caps its grid-barrier
     kernels at 96 workgroups (two concurrent 192-workgroup grids cannot both be resident on 256 CUs; on the 8-GPU
@@ -120,33 +120,42 @@ def _worker_shipped(rank, world, port, out_dir):
     from multibox_amd import priors as PR
     from multibox_amd.synth import DEFAULT_ASPECT_RATIOS
     pri = np.array(PR.generate_priors(DEFAULT_ASPECT_RATIOS[5]), np.float32)
-    net = Net(batch=4, input_size=299, k=5, mode="train", seed=13 + rank, bn_max_workgroups=96)   # different seeds:
+    net = Net(batch=B, input_size=299, k=5, mode="train", seed=13 + rank, bn_max_workgroups=96)   # different seeds:
     tr = Trainer(net, pri, max_num_bboxes=13, use_graph=True, process_group=dist.group.WORLD)      # broadcast fixes it
     tr.broadcast_parameters(src=0)
     n_onepass = sum(1 for op in net.convs if getattr(op, "bn_ws_off", -1) >= 0)
-    tr.set_batch(*_batch(torch, rank))
-    for _ in range(3):
-        tr.step()
-    torch.cuda.synchronize()
-    healthy = True
-    try:
-        tr.check_health()
-    except RuntimeError:
-        healthy = False
+    n_persistent = sum(1 for _, d, _ in net.tune_registry if d.tile_config > 32)
+    tr.set_batch(*_batch(torch, rank, B))
+    healthy, fallback = True, False
+    for _ in range(2):                       # steps, health check (may fall back, both ranks together), more steps
+        for _ in range(3 if B == 4 else 2):  # (B = 64: 240 MB of gradients cross gloo's host path every step)
+            tr.step()
+        torch.cuda.synchronize()
+        try:
+            fallback = tr.check_health()["fallback"] or fallback
+        except RuntimeError:
+            healthy = False
     torch.save({"W": net.W.cpu(), "Bt": net.Bt.cpu(), "Wg": net.Wg.cpu(), "loss": tr.losses(), "healthy": healthy,
-                "timeouts": net.barrier_timeouts(), "onepass_layers": n_onepass}, os.path.join(out_dir, "s_rank%d.pt" % rank))
+                "fallback": fallback, "timeouts": net.barrier_timeouts(), "onepass_layers": n_onepass,
+                "persistent_launches": n_persistent, "events": tr.events}, os.path.join(out_dir, "s_rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shipped_configuration(tmp_path):
+@pytest.mark.parametrize("B", [4, 64])
+def test_two_rank_shipped_configuration(tmp_path, B):
+    """B = 64 is BASELINE config 3's per-GPU batch: the shipped tile table sends ~175 launches per step to the persistent
+    igemm5 kernel (queued tiles), and the two ranks' persistent kernels and capped grid-barrier kernels contend for the
+    ONE GPU of this box -- far heavier sharing than RCCL's kernels cause on a rank's own GPU.  A grid-barrier time-out
+    under that load is allowed if (and only if) the trainer handled it: the step skipped on both ranks, the fall-back taken
+    together, training continued, parameters still identical."""
     import torch
     import torch.multiprocessing as mp
     import __graft_entry__ as g
     g.build()
     ctx = mp.get_context("spawn")
-    port = 30700 + (os.getpid() % 1000)
-    ps = [ctx.Process(target=_worker_shipped, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    port = 30700 + (os.getpid() % 1000) + B
+    ps = [ctx.Process(target=_worker_shipped, args=(r, 2, port, str(tmp_path), B)) for r in range(2)]
     for p in ps:
         p.start()
     for p in ps:
@@ -154,8 +163,14 @@ def test_two_rank_shipped_configuration(tmp_path):
         assert p.exitcode == 0
     r0, r1 = torch.load(tmp_path / "s_rank0.pt"), torch.load(tmp_path / "s_rank1.pt")
     assert r0["onepass_layers"] > 100                                   # the one-launch BN backward really ran
-    assert r0["healthy"] and r1["healthy"] and r0["timeouts"] == 0 and r1["timeouts"] == 0
-    # three steps on: all-reduced gradients and weights identical on both ranks, bit for bit
+    assert r0["healthy"] and r1["healthy"]
+    if B == 4:
+        assert r0["timeouts"] == 0 and r1["timeouts"] == 0 and not r0["fallback"]
+    else:
+        assert r0["persistent_launches"] > 100                          # queued igemm5 launches under contention
+        assert r0["fallback"] == r1["fallback"] and (r0["fallback"] or r0["timeouts"] + r1["timeouts"] == 0), (r0["events"], r1["events"])
+        print("B=64 two ranks on one GPU: timeouts", r0["timeouts"], r1["timeouts"], "fallback", r0["fallback"])
+    # four / six steps on: all-reduced gradients and weights identical on both ranks, bit for bit
     assert torch.equal(r0["Wg"], r1["Wg"]) and torch.equal(r0["W"], r1["W"]) and torch.equal(r0["Bt"], r1["Bt"])
     assert bool(torch.isfinite(r0["W"]).all()) and all(np.isfinite(x) for x in r0["loss"])
     assert r0["loss"][:2] != r1["loss"][:2]
