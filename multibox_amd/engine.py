@@ -89,6 +89,8 @@ class Net:
         # at the start of every pass (forward() / backward())
         self.i5_counters = torch.zeros(8192, dtype=torch.int32, device=device)
         self._i5_used = 0
+        # timing probes of tools/whatif_probe.py (wrong results while set: work is REMOVED to bound what a restructuring could save)
+        self._probe_skip_apply = self._probe_skip_bn_bwd = False
         self.convs, self.fwd, self.bwd = [], [], []
         self.grad_alias = {}       # id(activation buffer) -> gradient buffer
         self.written = set()       # gradient regions already written in the backward pass (build time)
@@ -507,7 +509,7 @@ class Net:
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     # (timing probe of tools/whatif_probe.py: finalize only, `a` keeps the previous step's values)
-                    if getattr(self, "_probe_skip_apply", False) and ("/block" in op.name or "/Block8" in op.name):
+                    if self._probe_skip_apply and ("/block" in op.name or "/Block8" in op.name):
                         _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, self.bn_decay,
                                                      mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "fin")
                         return
@@ -687,7 +689,7 @@ class Net:
 
             def run(op=op, pre=pre, ddesc=ddesc):
                 s = st()
-                if pre is not None and not (op.kind == "bn" and getattr(self, "_probe_skip_bn_bwd", False)):
+                if pre is not None and not (op.kind == "bn" and self._probe_skip_bn_bwd):
                     pre(s)
                 if ddesc is not None:
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
