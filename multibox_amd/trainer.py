@@ -12,6 +12,7 @@ every step.
 from __future__ import annotations
 
 import math
+import os
 import re
 
 import torch
@@ -79,9 +80,15 @@ class Trainer:
         self._stop_flag = torch.zeros((), **f32)       # request_stop(): copied into the step control block every step
         # backward segments = gradient buckets: data-parallel runs use more of them, so that the bucket that can only
         # start after the LAST backward launch (nothing left to overlap it with) is small
+        tail = 0
         if n_segments is None:
             n_segments = 6 if self.reducer.enabled else 4
-        self._segments = self._make_segments(n_segments)
+            # ... and the LAST bucket is cut short on top of that: the 2 M parameters at the bottom of the network (stem,
+            # Mixed_5b, block35: 6.7 MB of the 240) get a bucket of their own, so that the all-reduce nothing overlaps
+            # moves 7 MB instead of 38 (the bucket before it -- the rest of block17 and Mixed_6a -- starts with a
+            # quarter of the backward pass still to run)
+            tail = int(os.environ.get("MBX_DP_TAIL_PARAMS", "2000000")) if self.reducer.enabled else 0      # (0: A/B knob)
+        self._segments = self._make_segments(n_segments, tail_params=tail)
 
     def refresh_frozen_reg(self):
         """Regulariser of the frozen backbone under --fine_tune: a constant that train.py:246 still adds to the total
@@ -201,10 +208,11 @@ class Trainer:
         return out
 
     # ------------------------------------------------------------------ segments / buckets
-    def _make_segments(self, n):
+    def _make_segments(self, n, tail_params=0):
         """Split the backward launch list into n runs of roughly equal parameter count; each run's
         gradients are one contiguous bucket of Wg (backward order = reverse parameter order).  Every run ends with
-        ONE grouped weight-gradient launch for its layers (the weight gradients are deferred: ops.WgradGroup)."""
+        ONE grouped weight-gradient launch for its layers (the weight gradients are deferred: ops.WgradGroup).
+        tail_params > 0: the last run is split once more where at most that many parameters remain (n + 1 runs)."""
         net = self.net
         tagged = list(zip(net.bwd_launches, net.bwd_ops, net.bwd_jobs))
         from .engine import PoolOp
@@ -221,6 +229,10 @@ class Trainer:
                 if hi - lo >= target and len(segs) < n - 1:
                     segs.append((cur, lo, hi, jobs))
                     cur, jobs, hi = [], [], lo
+                elif tail_params > 0 and len(segs) == n - 1 and hi > lo and 0 < lo - self.w_lo <= tail_params:
+                    segs.append((cur, lo, hi, jobs))
+                    cur, jobs, hi = [], [], lo
+                    tail_params = 0
         if cur:
             segs.append((cur, self.w_lo, hi, jobs))
         out = []

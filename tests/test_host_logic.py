@@ -92,13 +92,17 @@ def test_backward_segments_cover_gradient_buffer():
         net = Net(batch=1, input_size=299, k=5, mode="train", fine_tune=fine_tune, device="cpu")
         tr = Trainer.__new__(Trainer)
         tr.net, tr.w_lo = net, (net.head_w_start if fine_tune else 0)
-        segs = tr._make_segments(4)
-        assert sum(len(s[0]) for s in segs) == len(net.bwd_launches)
-        hi = net.nW
-        for fns, lo, h in segs:
-            assert h == hi and lo < h
-            hi = lo
-        assert hi == tr.w_lo
+        for n, tail in ((4, 0), (6, 2_000_000)):
+            segs = tr._make_segments(n, tail_params=tail)
+            assert len(segs) <= n + (1 if tail else 0) and (fine_tune or len(segs) == n + (1 if tail else 0))
+            assert sum(len(s[0]) for s in segs) == len(net.bwd_launches)
+            hi = net.nW
+            for fns, lo, h in segs:
+                assert h == hi and lo < h
+                hi = lo
+            assert hi == tr.w_lo
+            if tail and not fine_tune:      # the data-parallel form: the bucket no backward launch overlaps is the small one
+                assert segs[-1][2] - segs[-1][1] <= tail and all(s_[2] - s_[1] > tail for s_ in segs[:-1])
 
 
 def test_generate_aspect_ratios_matches_reference_golden():
