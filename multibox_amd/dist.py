@@ -8,11 +8,10 @@ batch sum, so the reduction is SUM with no rescaling.  Batch-norm statistics sta
 
 Buckets are contiguous slices of the flat fp32 gradient buffer, one per backward segment
 (heads -> block8 -> block17 -> ...): each is handed to RCCL as soon as its segment's hipGraph has
-been enqueued, so the collective overlaps the rest of backward.  On the 8-GPU xGMI mesh a
-bucket of 40 MB moves 2*(7/8)*40 MB per GPU; six buckets of 40 MB keep each message large enough
-to be link-bound rather than latency-bound, and the parameters at the bottom of the network (stem,
-Mixed_5b, block35: 6.7 MB) form a seventh, small bucket -- the only one nothing overlaps
-(Trainer._make_segments, tail_params)."""
+been enqueued, so the collective overlaps the rest of backward.  Four buckets of 60 MB (on the
+8-GPU xGMI mesh one moves 2*(7/8)*60 MB per GPU: link-bound, not latency-bound), and the parameters
+at the bottom of the network (stem, Mixed_5b, block35: 6.7 MB) form a fifth, small bucket -- the only
+one nothing overlaps (Trainer._make_segments, tail_params)."""
 from __future__ import annotations
 
 import os

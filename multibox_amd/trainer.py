@@ -78,16 +78,17 @@ class Trainer:
         self.events = []                               # things a log should show (BN-backward fall-back, ...)
         self._timeouts_seen = 0
         self._stop_flag = torch.zeros((), **f32)       # request_stop(): copied into the step control block every step
-        # backward segments = gradient buckets: data-parallel runs use more of them, so that the bucket that can only
-        # start after the LAST backward launch (nothing left to overlap it with) is small
+        # backward segments = gradient buckets (each also ends in one grouped weight-gradient launch and is one hipGraph).
+        # Four of 60 MB; data-parallel runs cut the LAST one once more: the 2 M parameters at the bottom of the network
+        # (stem, Mixed_5b, block35: 6.7 MB of the 240) get a bucket of their own, so that the all-reduce nothing overlaps
+        # moves 7 MB instead of 59 (the bucket before it -- the lower half of block17 and Mixed_6a -- is handed over with a
+        # quarter of the backward pass still to run).  More, smaller buckets measured slower (each segment costs ~0.04 ms:
+        # 6 + 1 segments 17.85 ms, 4 + 1 17.65, one rank with MBX_FORCE_DIST=1) and hide nothing more: at 2 ranks on one
+        # xGMI link a 60 MB bucket takes ~0.9 ms and the next one is ~2 ms of backward away.
         tail = 0
         if n_segments is None:
-            n_segments = 6 if self.reducer.enabled else 4
-            # ... and the LAST bucket is cut short on top of that: the 2 M parameters at the bottom of the network (stem,
-            # Mixed_5b, block35: 6.7 MB of the 240) get a bucket of their own, so that the all-reduce nothing overlaps
-            # moves 7 MB instead of 38 (the bucket before it -- the rest of block17 and Mixed_6a -- starts with a
-            # quarter of the backward pass still to run)
-            tail = int(os.environ.get("MBX_DP_TAIL_PARAMS", "2000000")) if self.reducer.enabled else 0      # (0: A/B knob)
+            n_segments = int(os.environ.get("MBX_DP_SEGMENTS", "4")) if self.reducer.enabled else 4
+            tail = int(os.environ.get("MBX_DP_TAIL_PARAMS", "2000000")) if self.reducer.enabled else 0      # (A/B knobs)
         self._segments = self._make_segments(n_segments, tail_params=tail)
 
     def refresh_frozen_reg(self):
