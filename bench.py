@@ -504,7 +504,15 @@ def main():
     traced = None
     if not args.no_roofline:                # three more real steps on EVERY rank (the all-reduce needs them all); rank 0 traces its kernels
         if rank == 0:
-            traced = traced_kernel_times(tr.step)
+            done = [0]
+
+            def counted_step():
+                tr.step()
+                done[0] += 1
+            traced = traced_kernel_times(counted_step)
+            while done[0] < 3:          # the tracer gave up part-way: the other ranks still wait in three rounds of all-reduces
+                counted_step()
+            torch.cuda.synchronize()
         else:
             for _ in range(3):
                 tr.step()
