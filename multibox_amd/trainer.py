@@ -292,25 +292,40 @@ class Trainer:
         """One optimisation step on the batch set by set_batch().  Returns nothing; read
         self.loss.loss2 / self.total_loss() when needed (no host sync here)."""
         net, red = self.net, self.reducer
+        reduce = self._reduce_bucket
         if self.use_graph:
             if self.graphs is None:
                 self._capture()
             self.graphs[0].replay()
-            for g, (_, lo, hi) in zip(self.graphs[1:], self._segments):
+            for i, (g, (_, lo, hi)) in enumerate(zip(self.graphs[1:], self._segments)):
                 g.replay()
-                red.reduce_async(net.Wg, lo, hi)
+                reduce(i, lo, hi)
         else:
             self._front()
-            for fns, lo, hi in self._segments:
+            for i, (fns, lo, hi) in enumerate(self._segments):
                 for f in fns:
                     f()
-                red.reduce_async(net.Wg, lo, hi)
-        if red.enabled:
-            net.step_ctl[1:2].copy_(self._stop_flag)   # (Btg was zeroed inside the step: control word [1] = this rank's request)
-        red.reduce_async(net.Btg, self.bt_lo, net.nBt + 8)          # beta gradients + the step control block
+                reduce(i, lo, hi)
         red.wait()
         self._optimizer()
         self.global_step += 1
+
+    def _reduce_bucket(self, i, lo, hi):
+        """Start the all-reduce of bucket i = Wg[lo:hi].  The LAST bucket (lowest addresses: the bottom of the network)
+        takes the beta gradients and the step control block, which lie right below Wg in net.G, along in the same
+        collective -- unless frozen filter gradients lie between (--fine_tune: w_lo > 0), then they go separately."""
+        net, red = self.net, self.reducer
+        if not red.enabled:
+            return
+        if i < len(self._segments) - 1:
+            red.reduce_async(net.Wg, lo, hi)
+            return
+        net.step_ctl[1:2].copy_(self._stop_flag)       # (G was zeroed inside the step: control word [1] = this rank's request)
+        if lo == 0:
+            red.reduce_async(net.G, self.bt_lo, net.G_off + hi)
+        else:
+            red.reduce_async(net.Wg, lo, hi)
+            red.reduce_async(net.Btg, self.bt_lo, net.nBt + 8)
 
     def run_eager_once(self):
         """forward + loss + backward launched eagerly (profiling aid; no optimizer, no all-reduce)."""

@@ -20,17 +20,22 @@ def _worker(rank, world, port, fine_tune, q):
     net = Net(batch=1, input_size=299, k=5, mode="train", fine_tune=fine_tune, device="cpu")
     tr = Trainer.__new__(Trainer)
     tr.net, tr.w_lo, tr.bt_lo = net, (net.head_w_start if fine_tune else 0), (net.head_bt_start if fine_tune else 0)
-    segs = tr._make_segments(4)
+    # the product's own bucket path (Trainer.step): four buckets + the small tail bucket of data-parallel runs, the last
+    # collective taking the beta gradients and the step control block along where they are contiguous with it
+    tr._segments = segs = tr._make_segments(4, tail_params=2_000_000)
     gen = torch.Generator().manual_seed(rank)
     net.Wg.copy_(torch.randn(net.nW, generator=gen))
     net.Btg.copy_(torch.randn(net.nBt + 8, generator=gen))     # beta gradients + the step control block (engine.py)
+    tr._stop_flag = net.Btg[net.nBt + 1].clone()               # (step() copies the rank's stop request into control word 1)
     mine_w, mine_b = net.Wg.clone(), net.Btg.clone()
-    red = BucketReducer(dist.group.WORLD)
+    red = tr.reducer = BucketReducer(dist.group.WORLD)
     assert red.enabled
-    for _, lo, hi in segs:
-        red.reduce_async(net.Wg, lo, hi)
-    red.reduce_async(net.Btg, tr.bt_lo, net.nBt + 8)
+    n_coll = 0
+    for i, (_, lo, hi) in enumerate(segs):
+        tr._reduce_bucket(i, lo, hi)
+    n_coll = len(red.works)
     red.wait()
+    assert n_coll == len(segs) + (1 if fine_tune else 0), (n_coll, len(segs))     # full training: no separate collective for Btg
     other = torch.Generator().manual_seed(1 - rank)
     ow = torch.randn(net.nW, generator=other)
     ob = torch.randn(net.nBt + 8, generator=other)
