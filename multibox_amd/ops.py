@@ -169,7 +169,11 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     key = repr(key)
     if key in _TUNED:
         desc.tile_config = _TUNED[key]
-        return desc.tile_config
+        # one launch to make sure the table's choice still APPLIES to this shape (a table written by an older library whose
+        # kernels covered other shapes must not turn into MBX_ERR_UNSUPPORTED in the middle of a training step)
+        if _lib.lib().mbx_conv(C.byref(desc), _stream()) == 0:
+            return desc.tile_config
+        del _TUNED[key]
     if candidates is None:
         candidates = (0, 2, 4, 5, 6, 9, 10, 12, 13, 14)      # the tiles that won somewhere on the B=64 layer shapes
         if os.environ.get("MBX_AUTOTUNE_SET") == "all":

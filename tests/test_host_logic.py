@@ -213,3 +213,40 @@ def test_record_text_is_byte_identical_to_json_dump_of_the_dicts():
         D.results_to_json_records(boxes[:2], scores[:2], count[:2], ids[:2]) + D.results_to_json_records(boxes, scores, count, ids))
     assert REC.records_to_json([]) == json.dumps([]) == "[]"
     assert REC.records_to_json([""]) == "[]"
+
+
+def test_shipped_tile_table_is_well_formed():
+    """multibox_amd/tune_cache.json (the measured tile choice per layer shape, tools/tune_by_trace.py): every key parses,
+    every value is a configuration the library knows for that kind of launch, and the persistent kernels are named only
+    for shapes they cover (igemm7: pointwise, unit stride, 64 < K <= 384, no statistics, at most 32 column tiles; igemm5: no
+    stride-2 data gradient, no float32 head epilogue)."""
+    import ast
+    import json
+    import os
+    from multibox_amd import ops
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multibox_amd", "tune_cache.json")
+    table = json.load(open(path))
+    assert len(table) > 300
+    n7 = n5 = 0
+    for key, cfg in table.items():
+        i3 = key.endswith("#i3")
+        k = ast.literal_eval(key[:-3] if i3 else key)
+        what = k[0]
+        assert what in ("fwd", "dgrad", "wgrad") and isinstance(cfg, int), key
+        if what == "wgrad":
+            assert 0 <= cfg <= 10 and not i3, key
+            continue
+        (_, N, H, W, Cin, K, R, S, stride, pt, pl, c_out, c_in, epilogue, stats, accumulate, skip, relu) = k
+        if i3:
+            assert 0 <= cfg <= ops.N_TILE_CONFIGS, key
+            continue
+        assert 0 <= cfg <= ops.N_TILE_CONFIGS or cfg in ops.I5_TILE_CONFIGS or cfg == ops.I7_TILE_CONFIG, key
+        if cfg > ops.I5_FLAG:
+            assert epilogue != ops.EPI_STORE_F32 and not (what == "dgrad" and stride == 2), key
+        if cfg in ops.I5_TILE_CONFIGS:
+            n5 += 1
+        if cfg == ops.I7_TILE_CONFIG:
+            n7 += 1
+            assert R == S == 1 and stride == 1 and pt == pl == 0 and not stats and 64 < c_in <= 384, key
+            assert (c_out + 127) // 128 <= ops.I7_COUNTERS, key
+    assert n5 > 50 and n7 >= 1
