@@ -16,6 +16,13 @@
 // pixel tile (blockIdx / tiles_n) first and every further one of ITS column tile from work_counter[g] (one int per column
 // tile, zero at launch; NULL: dealt statically inside the group) -- three tiles ahead, so that the loaders, which run a whole
 // tile ahead when K = 128, always find the next id published.
+//
+// Result (round 3, DESIGN.md sections 4 and 7).  Bit-identical on every test; chosen by the trace-based tuner for the
+// detect leg's block17 "up" forward (256 patches: 2436 vs 2553 us per batch) and for six shapes of the 512 x 512
+// configuration, for NO shape at BATCH_SIZE 64.  Halving the bytes did not halve the step: beside a 96 KB panel the ring
+// holds 2 x 16 KB of pixel tiles in flight against the ~1.1 us an LDS-DMA takes to land (igemm5 keeps 3 x 32 KB), and the
+// launches this was written for spend their time in the residual / accumulate traffic of the epilogue (2.9 - 4.3 TB/s),
+// which no operand layout changes.
 #include "conv_common.h"
 
 namespace {
