@@ -93,10 +93,15 @@ def main():
         extractor = PatchExtractor(B, S) if on_device else None
         # rank-sharded INPUT: this rank decodes only the records that feed its own batches
         in_stats = {}
-        batches = ((b["batch_index"], b) for b in detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch,
-                                                                device_patches=on_device, rank=rank, world=world, stats=in_stats))
+        # produced by a background thread a few batches ahead (record parsing, patch planning and batch assembly are host
+        # work that would otherwise sit between two forward passes): INPUT_PREFETCH_BATCHES, 0 = in this thread
+        from multibox_amd.inputs import prefetched
+        stream = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch, device_patches=on_device,
+                                rank=rank, world=world, stats=in_stats)
+        depth = int(cfg.get("INPUT_PREFETCH_BATCHES", 3))
+        batches = ((b["batch_index"], b) for b in (prefetched(stream, depth) if depth > 0 else stream))
     else:
-        in_stats = None
+        in_stats, extractor = None, None
         batches = D.shard_batches(synthetic_batches(), rank, world)
     # Software pipeline: batch i+1 (input upload, patch extraction, forward, decode / filter / top-K, D2H of its results
     # into pinned buffers) is ENQUEUED before the host turns batch i's results into records, so the Python loop of
@@ -104,8 +109,34 @@ def main():
     host_out = [(torch.empty((B, max_keep, 4), dtype=torch.float64, pin_memory=True),
                  torch.empty((B, max_keep), dtype=torch.float32, pin_memory=True),
                  torch.empty((B,), dtype=torch.int32, pin_memory=True)) for _ in range(2)]
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]      # start, forward, post-process, copied
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(2)]      # start, device work done, copied
     pending = None
+
+    # The device work of one batch -- pack the input, 205 forward launches, sigmoid, decode / clip / filter / top-K -- is
+    # captured ONCE into a hipGraph over static buffers (its ~210 eager launches cost 2.6 ms of host time per batch of 64,
+    # more than half of the 4.7 ms the GPU needs): per batch the host fills the input picture buffer and the patch
+    # metadata, replays the graph and queues the copies of the results.  DETECT_HIP_GRAPH: false = launch eagerly.
+    import ctypes
+    x_static = extractor.out if extractor is not None else torch.empty((B, S, S, 3), dtype=torch.float32, device="cuda")
+    meta_bytes = B * ctypes.sizeof(_lib.PatchMeta)
+    meta_static = torch.zeros(meta_bytes, dtype=torch.uint8, device="cuda")
+    meta_host = [torch.empty(meta_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    out_static = {}
+
+    def device_step():
+        net.set_input(x_static)
+        locs, logits = net.forward()
+        _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "sigmoid")
+        out_static["r"] = pp(locs, conf, meta_static)
+    graph = None
+    if bool(cfg.get("DETECT_HIP_GRAPH", True)):
+        x_static.zero_()
+        device_step()                                   # warm-up (lazy module loads) on an all-zero batch
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            device_step()
 
     # The record text (float repr of ~17 000 numbers per batch: ~10 ms of pure host work) is produced by worker
     # PROCESSES (NUM_RECORD_WORKERS, default 3; spawned: no fork after the GPU is initialised; numpy + json only), so this
@@ -120,31 +151,35 @@ def main():
 
     def finish(p):
         slot, bi_, ids_ = p
-        ev[slot][3].synchronize()
+        ev[slot][2].synchronize()
         hb, hs, hc = host_out[slot]
         if pool is not None:
             results.append((bi_, pool.submit(REC.batch_chunk, hb.numpy().copy(), hs.numpy().copy(), hc.numpy().copy(), ids_)))
         else:
             results.append((bi_, REC.batch_chunk(hb.numpy(), hs.numpy(), hc.numpy(), ids_)))
-        print("Step: %d, Time/image (ms): %.1f, Post-process/image (ms): %.3f" % (
-            len(results), ev[slot][0].elapsed_time(ev[slot][1]) / B, ev[slot][1].elapsed_time(ev[slot][2]) / B))
+        print("Step: %d, Time/image (ms): %.2f" % (len(results), ev[slot][0].elapsed_time(ev[slot][1]) / B))   # detect.py:446
 
     t_all = time.time()
     for bi, batch in batches:
-        meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
-                                 batch["max_to_keep"], batch["image_hw"])
         slot = step % 2
+        meta = D.make_patch_meta(batch["offsets"], batch["dims"], batch["is_flipped"], batch["restrictions"],
+                                 batch["max_to_keep"], batch["image_hw"], device="cpu")
+        meta_host[slot].copy_(meta)                     # slot's previous upload finished before its results were read (finish)
         ev[slot][0].record()
-        net.set_input(extractor(batch["sources"], batch["patches"]) if "sources" in batch else torch.from_numpy(batch["images"]).cuda())
-        locs, logits = net.forward()
-        _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "sigmoid")
+        if "sources" in batch:
+            extractor(batch["sources"], batch["patches"])                       # -> x_static (its own output buffer)
+        else:
+            x_static.copy_(torch.from_numpy(batch["images"]), non_blocking=False)
+        meta_static.copy_(meta_host[slot], non_blocking=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            device_step()
         ev[slot][1].record()
-        boxes, scores, _, count = pp(locs, conf, meta)
-        ev[slot][2].record()
+        boxes, scores, _, count = out_static["r"]
         for h, d in zip(host_out[slot], (boxes, scores, count)):
             h.copy_(d, non_blocking=True)
-        ev[slot][3].record()
+        ev[slot][2].record()
         ids = [int(i) if str(i).lstrip("-").isdigit() else i for i in batch["image_ids"]]     # detect.py:410 int(image_id)
         if pending is not None:
             finish(pending)

@@ -245,6 +245,33 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patche
 
 
 # ------------------------------------------------------------------ other resize methods (legacy TF kernels)
+def prefetched(iterable, depth=3):
+    """The items of `iterable`, produced by a background thread up to `depth` items ahead of the consumer (the reference's
+    input queues do the same for the detect graph, detect.py:283-292: tf.train.batch with its own runner thread).  Order is
+    kept; an exception of the producer is re-raised in the consumer at the point where it happened."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(int(depth), 1))
+    end = object()
+
+    def run():
+        try:
+            for item in iterable:
+                q.put((item, None))
+        except BaseException as e:       # noqa: BLE001 -- handed over, re-raised by the consumer
+            q.put((None, e))
+            return
+        q.put((end, None))
+    threading.Thread(target=run, name="mbx-input-prefetch", daemon=True).start()
+    while True:
+        item, err = q.get()
+        if err is not None:
+            raise err
+        if item is end:
+            return
+        yield item
+
+
 def resize_nearest_tf(img, out_h, out_w):
     """tf.image.resize_nearest_neighbor(align_corners=False), TF 0.11: src = min(floor(dst * in/out), in-1)."""
     img = np.asarray(img, np.float32)

@@ -59,12 +59,20 @@ def main():
     for on_device in ("true", "false"):
         cfg = os.path.join(tmp, "e2e_det_%s.yaml" % on_device)
         open(cfg, "w").write(CFG % on_device)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "detect.py"), "--priors", pri, "--checkpoint_path", logdir,
+        prof = ["-m", "cProfile", "-s", "tottime"] if os.environ.get("MBX_E2E_PROFILE") else []      # where the host time goes
+        r = subprocess.run([sys.executable] + prof + [os.path.join(ROOT, "detect.py"), "--priors", pri, "--checkpoint_path", logdir,
                             "--config", cfg, "--save_dir", os.path.join(tmp, "e2e_det_out"), "--tfrecords", rec],
                            capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
         if r.returncode != 0:
             print(r.stdout[-1500:], r.stderr[-1500:])
             raise SystemExit(1)
+        if prof:
+            lines = r.stdout.splitlines()
+            i = next((k for k, l in enumerate(lines) if "tottime" in l and "ncalls" in l), len(lines))
+            print("\n".join(lines[i:i + 28]))
+            if on_device == "true":
+                print("input on the GPU:", [l for l in lines if "patches/s" in l][-1], flush=True)
+                break
         print("input on the %s:" % ("GPU" if on_device == "true" else "host"),
               [l for l in r.stdout.splitlines() if "patches/s" in l][-1], flush=True)
 
