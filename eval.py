@@ -60,19 +60,32 @@ def main():
     if on_device:
         from multibox_amd.augment import BatchAugmenter
         aug = BatchAugmenter(B, S, slot_bytes=1024 * 1024 * 3)
+    # the device work of a batch (pack, forward, sigmoid, decode / top-100) as ONE hipGraph over static buffers, as in detect.py
+    x_static = torch.zeros((B, S, S, 3), dtype=torch.float32, device="cuda")
+    out_static = {}
+
+    def device_step():
+        net.set_input(x_static)
+        locs, logits = net.forward()
+        _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "sigmoid")
+        out_static["r"] = pp(locs, conf, meta)
+    device_step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        device_step()
     for images, gt, n_gt, areas, ids in eval_batches(args.tfrecords, cfg, B, cfg.MAX_NUM_BBOXES, device_images=on_device):
         t = time.time()
         if on_device:
             aug.begin()
             for u8 in images:
                 aug.add(u8, 0, False, [])
-            net.set_input(aug.run())
+            x_static.copy_(aug.run())
         else:
-            net.set_input(torch.from_numpy(images).cuda())
-        locs, logits = net.forward()
-        _lib.check(_lib.lib().mbx_decode_conf(None, logits.data_ptr(), None, B, net.P, 0.0, None, conf.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "sigmoid")
-        boxes, scores, _, count = pp(locs, conf, meta)
+            x_static.copy_(torch.from_numpy(images))
+        graph.replay()
+        boxes, scores, _, count = out_static["r"]
         torch.cuda.synchronize()
         dt = time.time() - t
         boxes, scores, count = boxes.cpu().numpy() * S, scores.cpu().numpy(), count.cpu().numpy()     # eval.py:158-160
