@@ -273,8 +273,9 @@ def test_deep_ring_bit_identical_under_memory_saturation(torch_cuda):
     the persistent igemm5 launch or in the grouped weight gradient, which all multiply out of rings that OTHER waves fill --
     would change a gradient bit and, through RMSProp, a parameter.  (All rings also carry the landing read-back now,
     csrc/conv_common.h lds_readback_issue: this test is the proof under load, the read-back the guarantee by construction.)"""
-    # 600 steps here (2 minutes); the 2000-step run of the same command is recorded in profiles/r03_saturation_stress.json
-    steps = os.environ.get("MBX_STRESS_STEPS", "600")
+    # 300 steps here (1 minute; MBX_STRESS_STEPS for more); the 2000-step run of the same command on the final build is
+    # recorded in profiles/r03_saturation_stress.json (693 582 noise launches, bit-identical)
+    steps = os.environ.get("MBX_STRESS_STEPS", "300")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "side_stream_stress.py"), steps, "compare", "saturate"],
                        capture_output=True, text=True, timeout=1500, env=dict(os.environ, MBX_DETERMINISTIC="1"))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
