@@ -9,7 +9,7 @@ configuration on every launch it applies to, replayed, and each launch's duratio
 (torch.profiler: the timestamps rocprofv3 reports).  A challenger replaces the current choice of a layer shape only if
 it is faster by --threshold; the new table is then verified on the step's wall time before it is written.
 
-usage: python tools/tune_by_trace.py [--batch 64] [--input-size 299] [--k 5] [--max-num-bboxes 13] [--infer] [--out FILE]
+usage: python tools/tune_by_trace.py [--batch 64] [--input-size 299] [--k 5] [--max-num-bboxes 13] [--infer | --fine-tune] [--out FILE]
 """
 import argparse
 import ctypes as C
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--max-num-bboxes", type=int, default=13)
     ap.add_argument("--infer", action="store_true", help="the detect path: inference-mode forward only (BATCH_SIZE patches)")
+    ap.add_argument("--fine-tune", action="store_true", help="train.py --fine_tune: frozen backbone, the heads train")
     ap.add_argument("--steps", type=int, default=4, help="traced replays per candidate")
     ap.add_argument("--threshold", type=float, default=0.015)
     ap.add_argument("--out", default=None)
@@ -64,7 +65,7 @@ def main():
         def step():
             graph["g"].replay()
     else:
-        net = Net(batch=args.batch, input_size=args.input_size, k=args.k, mode="train", seed=2)
+        net = Net(batch=args.batch, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2)
         pri = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[args.k], args.input_size).astype(np.float32)
         tr = Trainer(net, pri, max_num_bboxes=args.max_num_bboxes, location_loss_alpha=1000.0, use_graph=True)
         images, gt, n = synthetic_batch(args.batch, args.input_size, args.max_num_bboxes, seed=0)
