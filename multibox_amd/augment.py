@@ -165,21 +165,23 @@ class PatchExtractor:
         hp = self.h_pix.numpy()
         for u8, off in zip(sources, offsets):
             hp[off:off + u8.size] = np.ascontiguousarray(u8).reshape(-1)
-        real = []
-        for i, p in enumerate(patches):
-            if p is None:
-                continue
-            si, (y, x, h, w), fs = p
-            H, W = sources[si].shape[:2]
-            if not (0 <= y and 0 <= x and h > 0 and w > 0 and y + h <= H and x + w <= W):
-                raise ValueError("patch window %r outside its %dx%d image" % ((y, x, h, w), H, W))
-            it = self.items[len(real)]
-            it["src_offset"], it["img_h"], it["img_w"] = offsets[si], H, W
-            it["win_y"], it["win_x"], it["win_h"], it["win_w"], it["flip_source"] = y, x, h, w, int(bool(fs))
-            real.append(i)
-        n = len(real)
-        if real != list(range(n)):
+        n = next((i for i, p in enumerate(patches) if p is None), len(patches))      # padding entries come last
+        if any(p is not None for p in patches[n:]):
             raise ValueError("padding entries must come last")
+        if n:                                                   # whole columns at a time (256 patches per batch in detect.py)
+            si = np.fromiter((p[0] for p in patches[:n]), np.int64, n)
+            win = np.array([p[1] for p in patches[:n]], np.int64).reshape(n, 4)
+            y, x, h, w = win[:, 0], win[:, 1], win[:, 2], win[:, 3]
+            H = np.array([u8.shape[0] for u8 in sources], np.int64)[si]
+            W = np.array([u8.shape[1] for u8 in sources], np.int64)[si]
+            bad = ~((0 <= y) & (0 <= x) & (h > 0) & (w > 0) & (y + h <= H) & (x + w <= W))
+            if bad.any():
+                b = int(np.argmax(bad))
+                raise ValueError("patch window %r outside its %dx%d image" % (tuple(int(v) for v in win[b]), H[b], W[b]))
+            it = self.items[:n]
+            it["src_offset"], it["img_h"], it["img_w"] = np.array(offsets, np.uint64)[si], H, W
+            it["win_y"], it["win_x"], it["win_h"], it["win_w"] = y, x, h, w
+            it["flip_source"] = np.fromiter((int(bool(p[2])) for p in patches[:n]), np.int32, n)
         if n < self.B:
             self.out[n:].zero_()
         if n:

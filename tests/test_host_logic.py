@@ -250,3 +250,24 @@ def test_shipped_tile_table_is_well_formed():
             assert R == S == 1 and stride == 1 and pt == pl == 0 and not stats and 64 < c_in <= 384, key
             assert (c_out + 127) // 128 <= ops.I7_COUNTERS, key
     assert n5 > 50 and n7 >= 1
+
+
+def test_patch_meta_packing_matches_the_c_struct():
+    """detect.make_patch_meta (whole numpy columns) produces byte for byte the array of mbx_patch_meta structs that the
+    ctypes declaration of include/mbx.h lays out."""
+    import ctypes
+    from multibox_amd import detect as D, _lib
+    B = 7
+    rng = np.random.RandomState(0)
+    off, dm, hw = rng.randint(0, 500, (B, 2)), rng.randint(1, 500, (B, 2)), rng.randint(1, 900, (B, 2))
+    fl, k, rs = rng.randint(0, 2, (B, 1)), rng.randint(1, 200, (B, 1)), rng.rand(B, 4).astype(np.float32)
+    got = D.make_patch_meta(off, dm, fl, rs, k, hw, device="cpu").numpy()
+    arr = (_lib.PatchMeta * B)()
+    for b in range(B):
+        m = arr[b]
+        m.offset_y, m.offset_x, m.patch_h, m.patch_w = int(off[b][0]), int(off[b][1]), int(dm[b][0]), int(dm[b][1])
+        m.image_h, m.image_w, m.is_flipped, m.max_to_keep = int(hw[b][0]), int(hw[b][1]), int(fl[b][0]), int(k[b][0])
+        for i in range(4):
+            m.restrictions[i] = float(rs[b][i])
+    want = np.frombuffer(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)), dtype=np.uint8)
+    assert got.shape == want.shape and bool((got == want).all())
