@@ -175,6 +175,10 @@ typedef struct {
      the counter advanced: clear it before the next launch that uses it (one fill per step covers a whole table of
      them).  Results are identical either way.                                                                     */
   int32_t* work_counter;
+  /* Persistent launches only (tile_config > 32): 0 = one workgroup per CU; n > 0 = at most n workgroups, which leaves
+     CUs to a kernel running beside this one on another stream (the capped grouped weight gradient of the previous
+     backward segment, mbx_conv_wgrad_grouped_capped; RCCL).  Results do not depend on it.                          */
+  int32_t max_workgroups;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
@@ -228,6 +232,12 @@ int mbx_wgrad_plan(const mbx_wgrad_job* jobs /*HOST*/, int n_jobs, int flags, vo
                    mbx_wgrad_plan_info* info /*HOST, out*/);
 int mbx_conv_wgrad_grouped(void* device_image /*queue heads are written*/, const mbx_wgrad_plan_info* info /*HOST*/,
                            mbx_stream_t stream);
+/* The same launch with at most max_workgroups persistent workgroups (<= 0: one per CU).  The weight gradient is off the
+ * critical path of the backward pass (only the optimiser reads dW): launched on a second stream with a capped grid it
+ * runs BESIDE the next segment's data-gradient / batch-norm chain on the CUs that chain leaves idle; any number of
+ * workgroups drains the queues (placement is for speed only), results are those of the uncapped launch.            */
+int mbx_conv_wgrad_grouped_capped(void* device_image, const mbx_wgrad_plan_info* info /*HOST*/, int max_workgroups,
+                                  mbx_stream_t stream);
 
 /* Scalars on the dgrad/wgrad path: mbx_conv multiplies the accumulator by `rscale` when
  * epilogue == MBX_EPI_STORE and rscale != 0 (the residual branch scale of model.py:21 on the

@@ -49,6 +49,7 @@ _SIGS = {
     "mbx_wgrad_plan_bytes": (SZ, [P, I, I]),
     "mbx_wgrad_plan": (I, [P, I, I, P, SZ, P]),
     "mbx_conv_wgrad_grouped": (I, [P, P, P]),
+    "mbx_conv_wgrad_grouped_capped": (I, [P, P, I, P]),
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),

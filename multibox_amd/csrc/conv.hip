@@ -1207,6 +1207,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   k.pw = (d->R == 1 && d->S == 1 && d->pad_t == 0 && d->pad_l == 0 && d->stride == 1) ? 1 : 0;
   k.skip_taps = 0; k.parity = 0;
   k.work_counter = d->work_counter;
+  k.max_wg = d->max_workgroups;
 #ifdef MBX_I5_STAMPS
   {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
@@ -1550,6 +1551,11 @@ extern "C" int mbx_wgrad_plan(const mbx_wgrad_job* jobs, int n_jobs, int flags, 
 }
 
 extern "C" int mbx_conv_wgrad_grouped(void* device_image, const mbx_wgrad_plan_info* info, mbx_stream_t stream) {
+  return mbx_conv_wgrad_grouped_capped(device_image, info, 0, stream);
+}
+
+extern "C" int mbx_conv_wgrad_grouped_capped(void* device_image, const mbx_wgrad_plan_info* info, int max_workgroups,
+                                             mbx_stream_t stream) {
   if (!device_image || !info || info->n_items <= 0 || info->n_layers <= 0) return MBX_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(device_image) & 15) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
@@ -1563,7 +1569,8 @@ extern "C" int mbx_conv_wgrad_grouped(void* device_image, const mbx_wgrad_plan_i
   char* base = reinterpret_cast<char*>(device_image);
   hipStream_t s = mbx_s(stream);
   // (queue heads: zero in the plan image, and reset by the kernel's last block at the end of every launch)
-  const int blocks = info->n_items < plan_cus() ? info->n_items : plan_cus();      // one persistent block per CU
+  int blocks = info->n_items < plan_cus() ? info->n_items : plan_cus();            // one persistent block per CU
+  if (max_workgroups > 0 && blocks > max_workgroups) blocks = max_workgroups;     // (the queues are drained by any number)
   hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3(blocks), dim3(64 * (8 + kWgLoaders)), kLds, s,
                      reinterpret_cast<const WgradLayer*>(base + info->layers_off),
                      reinterpret_cast<const WgradItem*>(base + info->items_off),

@@ -57,7 +57,7 @@ conv_igemm5_kernel(const ConvK p) {
   // gridDim.x + (values of the counter).  Lane 0 of compute wave 0 fetches the id of tile j+2 when tile j starts (a
   // returning atomic, in flight during the K loop -- the compute waves issue no other vector-memory instruction there)
   // and publishes it through s_ids[(j + 2) & 3] at the end of tile j's K loop, barriers before anyone needs it: the loaders read
-  // the id of tile j+1 while they are still inside tile j (they run NST - 1 K steps ahead, hence the nk >= NST condition;
+  // the id of tile j+1 while they are still inside tile j (they run NST - 1 K steps ahead, hence the nk > NST condition;
   // shorter K loops fall back to the static deal).  Same tiles, same arithmetic: results do not depend on the mode.
   // (an explicit LDS pointer: through a generic or volatile one hipcc emits FLAT accesses, which count on vmcnt too)
   typedef __attribute__((address_space(3))) int* lds_int_ptr;
@@ -68,7 +68,10 @@ conv_igemm5_kernel(const ConvK p) {
   const int ntiles = p.tiles_m * p.tiles_n;
   const int first = xcd_remap(blockIdx.x, gridDim.x);               // tiles first, first + grid, ...
   const int nk = (p.Ktot + 63) >> 6;
-  const bool queued = p.work_counter != nullptr && nk >= NST;       // (uniform)
+  // nk > NST: the loaders read s_ids[j + 1] when they have issued the last K step of tile j, i.e. in iteration nk - NST of
+  // tile j's K loop; the compute waves publish that id after the last barrier of tile j - 1 -- with nk == NST the read
+  // would sit in iteration 0, behind that same barrier and in front of any other (a race: ADVICE round 3).
+  const bool queued = p.work_counter != nullptr && nk > NST;        // (uniform)
 
   if (wave >= 8) {
     // -------------------------------------------------------------------------------------------- loader waves
@@ -315,7 +318,8 @@ int launch5(ConvK& k, hipStream_t s) {
     int dev = 0, n = 0;
     ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
   }
-  const int grid = ntiles < ncu ? ntiles : ncu;                     // one persistent block per CU
+  int grid = ntiles < ncu ? ntiles : ncu;                           // one persistent block per CU
+  if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;             // ... or fewer: CUs left to a kernel on another stream
   const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
   static bool attr[5][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \

@@ -219,6 +219,7 @@ int mbx_launch_igemm7(void* convk, hipStream_t s) {
   }
   const long ntiles = (long)k.tiles_m * k.tiles_n;
   int grid = ntiles < ncu ? (int)ntiles : ncu;                      // one persistent workgroup per CU, dealt round-robin to the column tiles
+  if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;             // (mbx_conv_desc.max_workgroups)
   if (grid < k.tiles_n) grid = k.tiles_n;
   if (k.tiles_n > 32) return MBX_ERR_UNSUPPORTED;                   // (one work counter per column tile, 32 per launch)
   const int lds = nk * k7PanelTile * 16 + k7NST * k7Stage * 16 + 32;

@@ -69,7 +69,7 @@ class ConvOp:
 
 class Net:
     def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
-                 bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0):
+                 bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0, wgrad_overlap_cus=None):
         """repeats: number of block35 / block17 / block8 repetitions (model.py:142,162,187); anything
         but the reference's (10, 20, 9) is a reduced-depth network for tests."""
         assert mode in ("train", "infer")
@@ -85,6 +85,17 @@ class Net:
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
         self.bn_max_wg = int(os.environ.get("MBX_BN_MAX_WG", "0")) or (bn_max_workgroups or 0)
+        # overlapped weight gradients (ops.WG_OVERLAP_DEFAULT, Trainer._capture): while a capped grouped weight-gradient launch
+        # holds `wgrad_overlap_cus` CUs on a second stream, the persistent launches of the backward chain take at most
+        # `chain_cap` workgroups -- self.cu_cap, set by the Trainer around the segments it overlaps (0: no cap).  The layers
+        # whose one-launch BN backward does not fit `chain_cap` workgroups use the three-launch form.
+        self.wgrad_overlap_cus = ops.wgrad_overlap_cus() if wgrad_overlap_cus is None else int(wgrad_overlap_cus)
+        self.n_cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == "cuda" else 256
+        self.chain_cap = 0
+        if self.wgrad_overlap_cus > 0 and mode == "train":
+            self.wgrad_overlap_cus = min(self.wgrad_overlap_cus, self.n_cus // 2)
+            self.chain_cap = min(self.bn_max_wg or self.n_cus, self.n_cus - self.wgrad_overlap_cus)
+        self.cu_cap = 0
         # work counters of the persistent igemm5 launches (mbx_conv_desc.work_counter): one per launch, cleared together
         # at the start of every pass (forward() / backward())
         self.i5_counters = torch.zeros(8192, dtype=torch.int32, device=device)
@@ -452,7 +463,7 @@ class Net:
         ws_floats = 0
         for op in self.convs:
             op.bn_ws_off = -1
-            if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, op.K, self.bn_max_wg):
+            if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, op.K, self.chain_cap or self.bn_max_wg):
                 op.bn_ws_off = ws_floats
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
@@ -656,7 +667,7 @@ class Net:
                     _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, int(op.relu), op.y.data_ptr(), M, K, mean.data_ptr(),
                                                     rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
                                                     op.dy.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
-                                                    self.bn_max_wg, self.step_ctl.data_ptr(), s),
+                                                    self.cu_cap or self.bn_max_wg, self.step_ctl.data_ptr(), s),
                                "bn_bwd_onepass")
 
                 def pre(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, K=K, M=M):
@@ -700,6 +711,7 @@ class Net:
                 if pre is not None and not (op.kind == "bn" and self._probe_skip_bn_bwd):
                     pre(s)
                 if ddesc is not None:
+                    ddesc.max_workgroups = self.cu_cap          # (persistent launches; baked into a captured graph)
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
             L.append(run)
             self.bwd_ops.append(op)

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("tile_config", C.c_int32),
         ("acc_src", C.c_void_p), ("acc_img_stride", C.c_int64), ("ld_acc", C.c_int32),
         ("work_counter", C.c_void_p),
+        ("max_workgroups", C.c_int32),
     ]
 
 
@@ -130,6 +131,17 @@ def conv_stats_rows(desc: ConvDesc):
 def conv_wgrad(desc: ConvDesc, dy: View, dw, db=None):
     _lib.check(_lib.lib().mbx_conv_wgrad(C.byref(desc), dy.ptr, dy.img_stride, dy.ld, dw.data_ptr(), _p(db), _stream()),
                "mbx_conv_wgrad")
+
+
+# Overlapped weight gradients (Trainer): the grouped weight-gradient launch of backward segment i runs on a second stream
+# with this many persistent workgroups (one CU each) BESIDE the data-gradient / batch-norm chain of segments i+1, ..., whose
+# persistent launches (igemm5 / igemm7 / one-launch BN backward) are capped at the remaining CUs.  0 = off (the grouped
+# launch runs at the end of its own segment, on every CU).  MBX_WG_OVERLAP overrides.
+WG_OVERLAP_DEFAULT = 0
+
+
+def wgrad_overlap_cus():
+    return max(0, int(os.environ.get("MBX_WG_OVERLAP", WG_OVERLAP_DEFAULT)))
 
 
 N_TILE_CONFIGS = 14
@@ -251,9 +263,11 @@ class WgradGroup:
         self.image = torch.from_numpy(self.host_image).to(device)
         self.flops = float(self.info.flops)
 
-    def launch(self):
-        _lib.check(_lib.lib().mbx_conv_wgrad_grouped(self.image.data_ptr(), C.byref(self.info), _stream()),
-                   "mbx_conv_wgrad_grouped")
+    def launch(self, max_workgroups=0):
+        """max_workgroups > 0: a capped grid, for a launch that runs beside the next segment's backward chain on another
+        stream (Trainer: overlapped weight gradients)."""
+        _lib.check(_lib.lib().mbx_conv_wgrad_grouped_capped(self.image.data_ptr(), C.byref(self.info), int(max_workgroups),
+                                                            _stream()), "mbx_conv_wgrad_grouped")
 
     def tally(self):
         """(work items processed, launches completed) since the image was uploaded -- host sync."""

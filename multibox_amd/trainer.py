@@ -86,10 +86,19 @@ class Trainer:
         # 6 + 1 segments 17.85 ms, 4 + 1 17.65, one rank with MBX_FORCE_DIST=1) and hide nothing more: at 2 ranks on one
         # xGMI link a 60 MB bucket takes ~0.9 ms and the next one is ~2 ms of backward away.
         tail = 0
+        # OVERLAPPED weight gradients (net.wgrad_overlap_cus > 0, captured steps): the grouped launch of segment i runs on a
+        # second stream with a capped grid beside the chain of the segments behind it (_capture).  Without a process group
+        # the segments are only weight-gradient groups: more of them, cut by weight-gradient work instead of parameters, so
+        # that the first group starts early and the last one -- the only one nothing overlaps -- is small.
+        self.overlap_cus = net.wgrad_overlap_cus if (use_graph and torch.device(net.dev).type == "cuda") else 0
+        by_work = False
         if n_segments is None:
             n_segments = int(os.environ.get("MBX_DP_SEGMENTS", "4")) if self.reducer.enabled else 4
             tail = int(os.environ.get("MBX_DP_TAIL_PARAMS", "2000000")) if self.reducer.enabled else 0      # (A/B knobs)
-        self._segments = self._make_segments(n_segments, tail_params=tail)
+            if self.overlap_cus and not self.reducer.enabled:
+                n_segments, by_work = int(os.environ.get("MBX_WG_GROUPS", "8")), True
+        self._side = None
+        self._segments = self._make_segments(n_segments, tail_params=tail, by_work=by_work)
 
     def refresh_frozen_reg(self):
         """Regulariser of the frozen backbone under --fine_tune: a constant that train.py:246 still adds to the total
@@ -209,25 +218,36 @@ class Trainer:
         return out
 
     # ------------------------------------------------------------------ segments / buckets
-    def _make_segments(self, n, tail_params=0):
+    def _make_segments(self, n, tail_params=0, by_work=False):
         """Split the backward launch list into n runs of roughly equal parameter count; each run's
-        gradients are one contiguous bucket of Wg (backward order = reverse parameter order).  Every run ends with
-        ONE grouped weight-gradient launch for its layers (the weight gradients are deferred: ops.WgradGroup).
-        tail_params > 0: the last run is split once more where at most that many parameters remain (n + 1 runs)."""
+        gradients are one contiguous bucket of Wg (backward order = reverse parameter order).  Every run has
+        ONE grouped weight-gradient launch for its layers (the weight gradients are deferred: ops.WgradGroup;
+        self._seg_groups[i], None where a run has no trainable layer).
+        tail_params > 0: the last run is split once more where at most that many parameters remain (n + 1 runs).
+        by_work: cut by the layers' weight-gradient work (M x C_out x R S C_in) instead of by parameters.
+        Returns [(chain launches, lo, hi)]."""
         net = self.net
         tagged = list(zip(net.bwd_launches, net.bwd_ops, net.bwd_jobs))
         from .engine import PoolOp
         total = net.nW - self.w_lo
         target = max(total // max(n, 1), 1)
+
+        def work(job):
+            d = job.desc
+            return float(d.N) * d.H_out * d.W_out * d.C_out * d.R * d.S * d.C_in
+        wtarget = max(sum(work(j) for j in net.bwd_jobs if j is not None) / max(n, 1), 1.0)
+        wacc = 0.0
         segs, cur, jobs, hi = [], [], [], net.nW
         lo = hi
         for fn, op, job in tagged:
             cur.append(fn)
             if job is not None:
                 jobs.append(job)
+                wacc += work(job)
             if not isinstance(op, PoolOp):
                 lo = min(lo, op.w_off)
-                if hi - lo >= target and len(segs) < n - 1:
+                full = (wacc >= wtarget * (len(segs) + 1)) if by_work else (hi - lo >= target)
+                if full and hi > lo and len(segs) < n - 1:
                     segs.append((cur, lo, hi, jobs))
                     cur, jobs, hi = [], [], lo
                 elif tail_params > 0 and len(segs) == n - 1 and hi > lo and 0 < lo - self.w_lo <= tail_params:
@@ -236,17 +256,24 @@ class Trainer:
                     tail_params = 0
         if cur:
             segs.append((cur, self.w_lo, hi, jobs))
-        out = []
         on_gpu = torch.device(net.dev).type == "cuda"
         groups = net.make_wgrad_groups([j for _, _, _, j in segs]) if on_gpu else []
         self.wgrad_groups = groups
-        gi = 0
-        for fns, lo, hi, jobs in segs:
+        self._seg_groups, gi = [], 0
+        for _, _, _, jobs in segs:
             if jobs and on_gpu:
-                fns = fns + [groups[gi].launch]
+                self._seg_groups.append(groups[gi])
                 gi += 1
-            out.append((fns, lo, hi))
-        return out
+            else:
+                self._seg_groups.append(None)
+        return [(fns, lo, hi) for fns, lo, hi, _ in segs]
+
+    def _run_segment(self, i):
+        """Segment i in stream order: its backward chain, then its grouped weight gradient on every CU."""
+        for f in self._segments[i][0]:
+            f()
+        if self._seg_groups[i] is not None:
+            self._seg_groups[i].launch()
 
     # ---------------------------------------------------------------------------- step
     def _front(self):
@@ -263,24 +290,84 @@ class Trainer:
         net = self.net
         mm, mv = net.MM.clone(), net.MV.clone()
         self._front()
-        for fns, _, _ in self._segments:
-            for f in fns:
-                f()
+        for i in range(len(self._segments)):
+            self._run_segment(i)
         net.MM.copy_(mm)
         net.MV.copy_(mv)
         torch.cuda.synchronize()
         graphs = []
-        # thread_local: RCCL's watchdog thread may query events while we capture (data-parallel runs)
+        nseg, K = len(self._segments), self.overlap_cus
+        mode = dict(capture_error_mode="thread_local")     # RCCL's watchdog thread may query events while we capture
+        if K and self._side is None:
+            self._side = torch.cuda.Stream()
+
+        def chain(i, capped):
+            net.cu_cap = net.chain_cap if capped else 0      # persistent chain launches leave K CUs to the weight gradient
+            try:
+                for f in self._segments[i][0]:
+                    f()
+            finally:
+                net.cu_cap = 0
+
+        def beside(fn):
+            # fork: `fn` on the side stream, ordered behind everything enqueued so far on the capturing stream (and behind
+            # the side stream's earlier work); the caller joins with main.wait_stream(self._side)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                fn()
+            forked[0] = True
+
+        def join():
+            if forked[0]:
+                torch.cuda.current_stream().wait_stream(self._side)
+                forked[0] = False
+        forked = [False]
+        if K and not self.reducer.enabled:
+            # ONE graph.  The weight-gradient groups form their own pipeline on the side stream: group i starts when the
+            # chain of segment i is done (and group i-1 is), K persistent workgroups each; the chain never waits for it.
+            # The last group has nothing left to run beside: joined first, every CU.
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **mode):
+                self._front()
+                for i in range(nseg):
+                    chain(i, capped=i > 0)
+                    grp = self._seg_groups[i]
+                    if grp is None:
+                        continue
+                    if i == nseg - 1:
+                        join()
+                        grp.launch()
+                    else:
+                        beside(lambda grp=grp: grp.launch(K))
+                join()
+            self.graphs = [g]
+            return
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, **mode):
             self._front()
         graphs.append(g)
-        for fns, _, _ in self._segments:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                for f in fns:
-                    f()
-            graphs.append(g)
+        if K:
+            # data-parallel form: graph i = chain of segment i BESIDE the weight gradients of segment i-1 (joined at its end,
+            # so that bucket i-1 can be handed to RCCL between two graphs); one more graph for the last group
+            for i in range(nseg + 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    prev = self._seg_groups[i - 1] if i > 0 else None
+                    if i == nseg:
+                        if prev is not None:
+                            prev.launch()
+                    else:
+                        if prev is not None:
+                            beside(lambda prev=prev: prev.launch(K))
+                        chain(i, capped=prev is not None)
+                        join()
+                graphs.append(g)
+        else:
+            for i in range(nseg):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    self._run_segment(i)
+                graphs.append(g)
         self.graphs = graphs
 
     def set_batch(self, images, gt_bboxes, num_gt_bboxes):
@@ -297,14 +384,20 @@ class Trainer:
             if self.graphs is None:
                 self._capture()
             self.graphs[0].replay()
-            for i, (g, (_, lo, hi)) in enumerate(zip(self.graphs[1:], self._segments)):
-                g.replay()
-                reduce(i, lo, hi)
+            if self.overlap_cus and red.enabled:
+                # graph i + 1 = chain i beside the weight gradients of segment i - 1: bucket i - 1 is complete behind it
+                for i, g in enumerate(self.graphs[1:]):
+                    g.replay()
+                    if i > 0:
+                        reduce(i - 1, *self._segments[i - 1][1:])
+            else:
+                for i, (g, (_, lo, hi)) in enumerate(zip(self.graphs[1:], self._segments)):
+                    g.replay()
+                    reduce(i, lo, hi)
         else:
             self._front()
-            for i, (fns, lo, hi) in enumerate(self._segments):
-                for f in fns:
-                    f()
+            for i, (_, lo, hi) in enumerate(self._segments):
+                self._run_segment(i)
                 reduce(i, lo, hi)
         red.wait()
         self._optimizer()
@@ -330,9 +423,8 @@ class Trainer:
     def run_eager_once(self):
         """forward + loss + backward launched eagerly (profiling aid; no optimizer, no all-reduce)."""
         self._front()
-        for fns, _, _ in self._segments:
-            for f in fns:
-                f()
+        for i in range(len(self._segments)):
+            self._run_segment(i)
 
     def _optimizer(self):
         net, l = self.net, _lib.lib()

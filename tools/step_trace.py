@@ -1,0 +1,58 @@
+"""Every kernel of one replayed training step, in launch order: start (us from the step's first kernel), duration, gap to
+the previous kernel, short name + template arguments.  ROCm tracer through torch.profiler (the timestamps of a rocprofv3
+kernel trace).  usage: python tools/step_trace.py [out.tsv] [--fine-tune]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import __graft_entry__ as g
+g.build()
+from multibox_amd.engine import Net
+from multibox_amd.trainer import Trainer, decay_steps
+from multibox_amd import priors as PR
+from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+from torch.profiler import profile, ProfilerActivity
+out = next((a for a in sys.argv[1:] if not a.startswith("--")), "gpurun_out/step_trace.tsv")
+B = int(os.environ.get("KB_B", "64"))
+priors = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[5], 299).astype(np.float32)
+net = Net(batch=B, input_size=299, k=5, mode="train", seed=2, fine_tune="--fine-tune" in sys.argv)
+tr = Trainer(net, priors, max_num_bboxes=13, location_loss_alpha=1000.0, decay_steps_=decay_steps(56945, B, 4), use_graph=True)
+images, gt, n = synthetic_batch(B, 299, 13, seed=0)
+tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+for _ in range(5):
+    tr.step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+ev = []
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CUDA:
+        t0 = e.time_range.start
+        ev.append((t0, t0 + float(getattr(e, "device_time", None) or e.cuda_time), e.name))
+ev.sort()
+starts = [i for i, e in enumerate(ev) if "pack_input_kernel" in e[2]]
+step = ev[starts[-1]:]
+T0 = step[0][0]
+
+
+def short(nm):
+    nm = nm.replace("void ", "").replace("(anonymous namespace)::", "")
+    head = nm.split("(")[0]
+    return head[:90]
+
+
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+with open(out, "w") as f:
+    prev = T0
+    for s, e, nm in step:
+        f.write("%.2f\t%.2f\t%.2f\t%s\n" % (s - T0, e - s, s - prev, short(nm)))
+        prev = e
+cls = {}
+for s, e, nm in step:
+    c = cls.setdefault(short(nm).split("<")[0], [0.0, 0])
+    c[0] += e - s
+    c[1] += 1
+print("step wall %.3f ms, kernel time %.3f ms, %d kernels" % ((max(e for _, e, _ in step) - T0) / 1e3, sum(e - s for s, e, _ in step) / 1e3, len(step)))
+for k, (t, c) in sorted(cls.items(), key=lambda kv: -kv[1][0]):
+    print("  %-44s x%-4d %9.1f us  avg %6.2f" % (k[:44], c, t, t / c))
