@@ -142,7 +142,13 @@ def test_conv_epilogues(T):
 @pytest.mark.parametrize("g", [("e1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("e7", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
                                ("e3", 2, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1)),
                                # more tiles than CUs (308 of 128x64, 2.4 per workgroup of 128x128 ...): the queue really hands tiles out
-                               ("e4", 16, 35, 35, 64, 320, 1, 1, 1, (0, 0, 0, 0))], ids=["1x1", "1x7", "3x3", "1x1_many_tiles"])
+                               ("e4", 16, 35, 35, 64, 320, 1, 1, 1, (0, 0, 0, 0)),
+                               # K loops exactly as long as the ring is deep (nk == NST: 3 for the 192x128 / 256x128 tiles, 4 for
+                               # the others) with several tiles per workgroup -- the shapes of the detect leg at BATCH_SIZE 256 on
+                               # which the queued hand-off of round 3 raced (the loaders read the next tile id one barrier early);
+                               # such launches now deal their tiles statically even when a counter is given
+                               ("e5", 16, 35, 35, 192, 208, 1, 1, 1, (0, 0, 0, 0)), ("e6", 16, 35, 35, 256, 64, 1, 1, 1, (0, 0, 0, 0))],
+                         ids=["1x1", "1x7", "3x3", "1x1_many_tiles", "nk3", "nk4"])
 def test_igemm5_epilogues_bit_identical(T, g):
     """Every epilogue of the persistent igemm5 launch (statistics, frozen-BN affine, residual, accumulate + ReLU mask,
     plain scaled store) against the igemm3 launch of the same descriptor: same arithmetic in the same order."""
@@ -206,6 +212,18 @@ def test_igemm5_epilogues_bit_identical(T, g):
             assert torch.equal(y1.tensor(), y2.tensor()), "%s %s cfg %d queued" % (name, kind, cfg)
             if kind == "stats":
                 assert torch.equal(st1, st2), "%s stats cfg %d queued" % (name, cfg)
+            # ... and with a CAPPED grid (mbx_conv_desc.max_workgroups: CUs left to a kernel on another stream), so that
+            # every workgroup walks many tiles, queued and statically dealt
+            for ctr_on in (True, False):
+                ctr.zero_()
+                y2.tensor().zero_(); st2.zero_()
+                d2.max_workgroups = 24
+                d2.work_counter = ctr.data_ptr() if ctr_on else None
+                assert l.mbx_conv(C.byref(d2), stream) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(y1.tensor(), y2.tensor()), "%s %s cfg %d capped queued=%s" % (name, kind, cfg, ctr_on)
+                if kind == "stats":
+                    assert torch.equal(st1, st2), "%s stats cfg %d capped queued=%s" % (name, cfg, ctr_on)
 
 
 @pytest.mark.parametrize("g", [("p1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("p2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
@@ -487,3 +505,14 @@ def test_wgrad_grouped_matches_reference_and_single_layer_api(T, deterministic):
         for (name, dw, db, _, _), (dw0, db0) in zip(checks, first):
             assert torch.equal(dw, dw0), "deterministic plan not bit-reproducible: " + name
             assert db is None or torch.equal(db, db0)
+        # a CAPPED grid (mbx_conv_wgrad_grouped_capped: 24 persistent workgroups drain the same queues) gives the same bits
+        for _, dw, db, _, _ in checks:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        grp.launch(max_workgroups=24)
+        torch.cuda.synchronize()
+        for (name, dw, db, _, _), (dw0, db0) in zip(checks, first):
+            assert torch.equal(dw, dw0), "capped launch differs: " + name
+            assert db is None or torch.equal(db, db0)
+        assert grp.completed_ok()
