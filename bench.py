@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--detect-batch", type=int, default=256)
     ap.add_argument("--detect-steps", type=int, default=10)
     ap.add_argument("--log-losses", action="store_true", help="print the loss after every step to stderr (adds host syncs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configurations (fine-tune, 512x512)")
+    ap.add_argument("--config-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -372,6 +374,57 @@ def detect_leg(args, world, rank, pg):
     return out
 
 
+def config_leg(args, fine_tune, input_size, k, max_num_bboxes, label):
+    """One more single-GPU BASELINE configuration beside the headline, same build, same timing rules (inputs resident,
+    barrier-free single rank, --config-steps timed steps after 3 warm-up steps): `--fine_tune` at BATCH_SIZE 64 (BASELINE
+    config 1's semantics at the headline's batch: the like-for-like partner of cpu_baseline) or the 512x512 / k=7 /
+    MAX_NUM_BBOXES=100 geometry of config 5.  roofline = the implicit-GEMM launches of three traced replayed steps."""
+    import numpy as np
+    import torch
+    from multibox_amd.engine import Net
+    from multibox_amd.trainer import Trainer, decay_steps
+    from multibox_amd import priors as PR
+    from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
+    B = args.batch
+    priors = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], input_size).astype(np.float32)
+    net = Net(batch=B, input_size=input_size, k=k, mode="train", fine_tune=fine_tune, seed=2)
+    tr = Trainer(net, priors, max_num_bboxes=max_num_bboxes, location_loss_alpha=1000.0, decay_steps_=decay_steps(56945, B, 4),
+                 use_graph=not args.no_graph)
+    images, gt, n = synthetic_batch(B, input_size, max_num_bboxes, seed=0)
+    tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.config_steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.config_steps
+    losses = tr.losses()
+    gflop = net.flops_per_image(train=True) * 1e-9
+    out = {"workload": label, "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": args.config_steps,
+           "batch": B, "predictions": net.P, "algorithmic_tflop_per_step": round(gflop * B * 1e-3, 3),
+           "model_tflops": round(gflop * B * 1e-3 / dt, 1), "matching_ok": int(tr.match_status().max()) == 0,
+           "grid_barrier_timeouts": net.barrier_timeouts(), "total_loss_finite": bool(np.isfinite(losses[3]))}
+    if not args.no_roofline:
+        try:
+            traced = traced_kernel_times(tr.step)
+            classes, pair_ms, plain_ms = timed_eager_pass(tr.run_eager_once, ["mbx_conv"])
+            d = classes["igemm"]
+            ms = traced["igemm"][0] if traced else d["ms"]
+            ach = d["work"] / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "implicit-GEMM convolution launches (forward + data gradient)",
+                               "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches_per_step": d["calls"],
+                               "ms_per_step": round(ms, 3), "timing": "tracer" if traced else "hip events",
+                               "whole_step_frac": round(out["model_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None}
+        except Exception as e:
+            out["roofline"] = {"error": repr(e)}
+    del tr, net
+    torch.cuda.empty_cache()
+    return out
+
+
 def input_leg():
     """Row F1/F3 beside the headline: the GPU half of the training input (mbx_augment_batch: resize by the drawn method,
     colour ops, flip, scaling) on one batch of 64 synthetic 480x640 uint8 pictures ALREADY in HBM, every method and
@@ -459,23 +512,48 @@ def main():
         if args.log_losses and rank == 0:
             print("warmup step %d losses (loc, conf, reg, total) %s" % (tr.global_step, tr.losses()), file=sys.stderr)
     sync()
+    if pg is not None:
+        tr.exposed_events = []                 # step() brackets reducer.wait() with an event pair: the all-reduce time nothing hides
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.step()
         if args.log_losses and rank == 0:
             print("step %d losses (loc, conf, reg, total) %s" % (tr.global_step, tr.losses()), file=sys.stderr)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank alone (before the closing barrier)
     sync()
     dt = time.perf_counter() - t0
+    dp_diag = None
     if pg is not None:
+        exposed = [a.elapsed_time(b) for a, b in tr.exposed_events]
+        tr.exposed_events = None
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        # per-rank figures -> max / min over ranks (two small collectives, outside the timed region)
+        mine = torch.tensor([dt_own / args.steps * 1e3, sum(exposed) / max(len(exposed), 1), max(exposed or [0.0])],
+                            dtype=torch.float64, device="cuda")
+        hi, lo = mine.clone(), mine.clone()
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        dp_diag = {"rank_step_ms_max": round(float(hi[0]), 3), "rank_step_ms_min": round(float(lo[0]), 3),
+                   "allreduce_exposed_ms": round(float(hi[1]), 3), "allreduce_exposed_ms_min_rank": round(float(lo[1]), 3),
+                   "allreduce_exposed_ms_worst_step": round(float(hi[2]), 3),
+                   "buckets_bytes": [4 * (h - l) for _, l, h in tr._segments],
+                   "last_bucket_carries": "beta gradients + step control block (%d bytes)" % (4 * (net.nBt + 8)),
+                   "weight_gradient_overlap_cus": tr.overlap_cus}
     losses = tr.losses()
     # health over ALL ranks: matching status and grid-barrier timeouts of the last step (summed)
     health = torch.tensor([int(tr.match_status().max() != 0), net.barrier_timeouts()], dtype=torch.int32, device="cuda")
     if pg is not None:
         torch.distributed.all_reduce(health)
     status_ok, barrier_timeouts = int(health[0]) == 0, int(health[1])
+    # the trainer's own verdict (a collective: every rank): skipped steps, fall-back of the BN backward taken or not
+    try:
+        verdict = tr.check_health()
+        verdict["error"] = None
+    except RuntimeError as e:
+        verdict = {"stop": False, "fallback": False, "error": str(e)}
     out = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -494,6 +572,8 @@ def main():
                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
                "final_losses": {"location": round(losses[0], 3), "confidence": round(losses[1], 3), "regularization": round(losses[2], 4)},
                "matching_ok": status_ok, "grid_barrier_timeouts": barrier_timeouts, "rccl": rccl,
+               "health": {"fallback_taken_at_end": bool(verdict["fallback"]) or bool(net.no_onepass and not net.deterministic),
+                          "skipped_steps": int(tr.skipped_steps), "error": verdict["error"], "events": list(tr.events)},
                # the kernel mix of THIS run (data-parallel runs cap the BN-backward grid; both use the same conv kernels)
                "kernels": {"igemm5_launches": sum(1 for _, d_, _ in net.tune_registry if 32 < d_.tile_config < 64),
                            "igemm7_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 64),
@@ -501,6 +581,10 @@ def main():
                            "skipped_steps_events": tr.events},
                "algorithmic_tflop_per_step": round(per_image_gflop * 1e-3 * B * world, 3)}
         out["model_tflops"] = round(out["algorithmic_tflop_per_step"] / (dt / args.steps), 2)
+        if dp_diag is not None:
+            out["data_parallel"] = dp_diag
+        from multibox_amd import ops as _ops
+        out["tune_cache"] = dict(_ops.TUNE_STATS)      # table entries accepted as they are / shapes measured on THIS box / refused
     traced = None
     if not args.no_roofline:                # three more real steps on EVERY rank (the all-reduce needs them all); rank 0 traces its kernels
         if rank == 0:
@@ -531,9 +615,9 @@ def main():
             cpu_base = cpu_baseline(net, priors, args.cpu_seconds)
         except Exception as e:
             cpu_base = {"error": repr(e)}
+    del tr, net                     # free the training buffers before the other networks are built
+    torch.cuda.empty_cache()
     if not args.no_detect:
-        del tr, net                 # free the training buffers before the detect network is built
-        torch.cuda.empty_cache()
         try:
             dleg = detect_leg(args, world, rank, pg)
         except Exception as e:
@@ -546,9 +630,27 @@ def main():
                 out["input_augment"] = {"error": repr(e)}
         if pg is not None:
             torch.distributed.barrier()
+    if rank == 0 and world == 1 and not args.no_configs and not args.fine_tune and (args.input_size, args.k) == (299, 5):
+        cfgs = {}
+        for key, ft, S_, k_, G_, label in (
+                ("fine_tune", True, 299, 5, 13, "train.py --fine_tune (frozen backbone, heads train: BASELINE config 1's semantics), "
+                                                "299x299, k=5, BATCH_SIZE=%d" % args.batch),
+                ("s512_k7_g100", False, 512, 7, 100, "full train step at BASELINE config 5's geometry on one GPU: 512x512, k=7, "
+                                                     "MAX_NUM_BBOXES=100, BATCH_SIZE=%d" % args.batch)):
+            try:
+                cfgs[key] = config_leg(args, ft, S_, k_, G_, label)
+            except Exception as e:
+                cfgs[key] = {"error": repr(e)}
+        out["configs"] = cfgs
+        from multibox_amd import ops as _ops
+        out["tune_cache"] = dict(_ops.TUNE_STATS)
     if rank == 0:
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+            if isinstance(out.get("configs", {}).get("fine_tune"), dict) and "value" in out["configs"]["fine_tune"]:
+                # the like-for-like GPU figure sits beside it; the ratio is not a quality measure (roofline.frac is)
+                cpu_base["same_semantics_on_gpu"] = "configs.fine_tune: %s images/sec at BATCH_SIZE %d" % (
+                    out["configs"]["fine_tune"]["value"], args.batch)
         print(json.dumps(out), flush=True)
     if pg is not None:
         torch.distributed.destroy_process_group()

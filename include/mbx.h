@@ -188,6 +188,10 @@ typedef struct {
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
+/* Every check of mbx_conv for this descriptor -- arguments, ranges, whether desc->tile_config applies to the shape and
+ * epilogue -- WITHOUT a launch: what mbx_conv would return short of a launch error.  For callers that keep a table of
+ * measured tile choices and must not find out in the middle of a step that an entry no longer applies.               */
+int mbx_conv_supported(const mbx_conv_desc* desc /*HOST*/);
 
 /* Weight gradient (TF autodiff of slim.conv2d, train.py:263):
  * dw[k][r][s][c] += sum_{n,oh,ow} dy[n,oh,ow,k] * x[n, oh*stride-pad_t+r, ow*stride-pad_l+s, c]
@@ -250,6 +254,9 @@ int mbx_conv_wgrad_scaled(const mbx_conv_desc* desc, const void* dy, int64_t dy_
  * (scale=False), beta, epsilon 0.001, batch statistics over N*H*W when training, moving
  * averages updated as moving -= (1-decay)*(moving - batch) (biased variance).
  * Forward training = mbx_conv(stats_partial) -> mbx_bn_finalize -> mbx_bn_apply.          */
+/* decay < 0 ("store mode", also mbx_bn_apply_fused): moving_mean / moving_var are OVERWRITTEN with the batch mean and the
+ * biased batch variance instead of being updated -- for callers that apply the moving-average update later, gated by
+ * the step control word (mbx_bn_moving_update below), so that a step the optimiser skips leaves them untouched.      */
 int mbx_bn_finalize(const float* stats_partial /*[rows,C,2]*/, int rows, int C, int64_t count,
                     float eps, float decay, float* mean /*[C]*/, float* rstd /*[C]*/,
                     float* moving_mean /*[C] or NULL*/, float* moving_var /*[C] or NULL*/,
@@ -264,6 +271,14 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
                        const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
                        float* mean, float* rstd, float* moving_mean, float* moving_var,
                        mbx_stream_t stream);
+/* moving -= (1-decay)*(moving - batch) for n channels (every batch-norm layer of a step in one launch; batch_mean /
+ * batch_var as written by the store mode above: the same float32 expressions, bit-identical to the in-place update).
+ * skip_ctl (DEVICE, two float32, may be NULL): the step control block of mbx_rmsprop_ema_step -- if either word is
+ * non-zero the launch changes nothing except *skipped_steps += 1 (DEVICE uint64, may be NULL): a poisoned step or a
+ * step after a stop request is skipped EVERYWHERE, moving statistics included (train.py:94-99 updates them as part of
+ * the train op, which the reference's py_func error aborts as a whole, loss.py:82).                                  */
+int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* batch_mean, const float* batch_var,
+                         int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps, mbx_stream_t stream);
 /* Frozen BN folded into the conv epilogue (detect.py:313-326, train.py:124-131):
  * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
 int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,

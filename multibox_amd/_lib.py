@@ -44,6 +44,7 @@ _SIGS = {
     "mbx_extract_patches": (I, [P, P, I, I, P, P]),
     "mbx_conv_stats_rows": (I, [P]),
     "mbx_conv": (I, [P, P]),
+    "mbx_conv_supported": (I, [P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
     "mbx_conv_wgrad_scaled": (I, [P, P, C.c_int64, I, F, P, P, P]),
     "mbx_wgrad_plan_bytes": (SZ, [P, I, I]),
@@ -52,6 +53,7 @@ _SIGS = {
     "mbx_conv_wgrad_grouped_capped": (I, [P, P, I, P]),
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
+    "mbx_bn_moving_update": (I, [P, P, P, P, C.c_int64, F, P, P, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),

@@ -14,13 +14,20 @@ def _prune(logdir, max_to_keep, keep_every_n_hours, now=None):
     """tf.train.Saver's retention (train.py:282-286): the newest max_to_keep checkpoints stay; an older one that is about to
     be deleted is KEPT FOR GOOD instead if it was written at least keep_checkpoint_every_n_hours after the previous
     permanently kept one (Saver._next_checkpoint_time; the clock starts at the first save into this directory).  The
-    little state TF keeps in the Saver object lives in <logdir>/checkpoint_retention.json here, so that it survives restarts."""
+    little state TF keeps in the Saver object lives in <logdir>/checkpoint_retention.json here, so that it survives restarts
+    (TF's own clock restarts with every process: a run resumed often keeps a checkpoint later than tf.train.Saver would).
+    A state file that does not hold what is expected (hand-edited, an older format, `null`) is re-initialised."""
     import json
     import time
     state_path = os.path.join(logdir, "checkpoint_retention.json")
+    st = None
     try:
-        st = json.load(open(state_path))
+        with open(state_path) as f:
+            st = json.load(f)
     except (OSError, ValueError):
+        pass
+    if not (isinstance(st, dict) and isinstance(st.get("kept"), list) and isinstance(st.get("next_keep_time"), (int, float))
+            and all(isinstance(k, str) for k in st["kept"])):
         st = {"next_keep_time": (now if now is not None else time.time()) + 3600.0 * keep_every_n_hours, "kept": []}
     kept = set(st["kept"])
     olds = sorted((p for p in glob.glob(os.path.join(logdir, "model.ckpt-*.pt")) if os.path.basename(p) not in kept), key=_step_of)
@@ -32,7 +39,8 @@ def _prune(logdir, max_to_keep, keep_every_n_hours, now=None):
         else:
             os.remove(p)
     tmp = state_path + ".tmp"
-    json.dump(st, open(tmp, "w"))
+    with open(tmp, "w") as f:
+        json.dump(st, f)
     os.replace(tmp, state_path)
 
 
@@ -50,7 +58,11 @@ def save(logdir, trainer, max_to_keep=3, keep_checkpoint_every_n_hours=10000.0):
     tmp = path + ".tmp"                             # a kill in mid-save must not leave a truncated newest checkpoint
     torch.save(state, tmp)
     os.replace(tmp, path)
-    _prune(logdir, max_to_keep, float(keep_checkpoint_every_n_hours))
+    try:                                            # a retention problem must never lose the checkpoint just written
+        _prune(logdir, max_to_keep, float(keep_checkpoint_every_n_hours))
+    except Exception as e:                          # noqa: BLE001
+        import sys
+        print("[multibox_amd] checkpoint retention skipped: %r" % (e,), file=sys.stderr)
     return path
 
 

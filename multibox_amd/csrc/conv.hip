@@ -1110,6 +1110,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
       hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2, NSTG>), dim3(k.tiles_m * k.tiles_n),      \
                          dim3(64 * WNW * WMW), lds, s, k);                                                    \
     } while (0)
+    if (k.dry) return (k.shift && ev != 0 && ev != 2) ? MBX_ERR_UNSUPPORTED : MBX_OK;
     if (k.shift) {                               // stride-2 data gradient: its own instantiations (store / accumulate)
       if (ev == 0) MBX_LAUNCH_SH(0, 0);
       else if (ev == 2) MBX_LAUNCH_SH(2, 1);
@@ -1158,7 +1159,11 @@ extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   return (int)((M + c.BM - 1) / c.BM);
 }
 
-extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
+static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry);
+extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) { return conv_impl(d, stream, 0); }
+extern "C" int mbx_conv_supported(const mbx_conv_desc* d) { return conv_impl(d, nullptr, 1); }
+
+static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   int st = check_desc(d);
   if (st != MBX_OK) return st;
   if (!d->w || !d->y) return MBX_ERR_INVALID_ARG;
@@ -1208,6 +1213,7 @@ extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) {
   k.skip_taps = 0; k.parity = 0;
   k.work_counter = d->work_counter;
   k.max_wg = d->max_workgroups;
+  k.dry = dry;
 #ifdef MBX_I5_STAMPS
   {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;

@@ -321,6 +321,7 @@ int launch5(ConvK& k, hipStream_t s) {
   int grid = ntiles < ncu ? ntiles : ncu;                           // one persistent block per CU
   if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;             // ... or fewer: CUs left to a kernel on another stream
   const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+  if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
   static bool attr[5][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \
   do {                                                                                                        \

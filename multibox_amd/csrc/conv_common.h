@@ -37,6 +37,7 @@ struct ConvK {
   int parity;                          // pixels walked parity-class-major (0: raster order, MBX_NO_TAP_SKIP=1)
   int* work_counter;                   // igemm5: tiles after a workgroup's first come from this counter (NULL: static)
   int max_wg;                          // persistent launches: grid cap (0: one workgroup per CU); host side only
+  int dry;                             // host side only: mbx_conv_supported() -- every check, no launch
 #ifdef MBX_I5_STAMPS
   unsigned long long* stamps;          // debug build: wall_clock64() per tile phase of the first 8 tiles of 64 blocks
   int dbg;                             // debug build: MBX_I5_DBG timing probes (bit 0: compute waves idle, bit 1: loaders do not wait)

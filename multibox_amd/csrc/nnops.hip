@@ -61,8 +61,13 @@ bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_c
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (mmean) mmean[c] -= (1.0f - decay) * (mmean[c] - (float)m);        // assign_moving_average
-    if (mvar) mvar[c] -= (1.0f - decay) * (mvar[c] - (float)var);
+    if (decay < 0.f) {                                                     // store mode: the update is applied later,
+      if (mmean) mmean[c] = (float)m;                                      // gated by the step control word
+      if (mvar) mvar[c] = (float)var;                                      // (mbx_bn_moving_update)
+    } else {
+      if (mmean) mmean[c] -= (1.0f - decay) * (mmean[c] - (float)m);      // assign_moving_average
+      if (mvar) mvar[c] -= (1.0f - decay) * (mvar[c] - (float)var);
+    }
   }
 }
 
@@ -286,8 +291,13 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
       s_mean[ch] = fm; s_rstd[ch] = fr; s_beta[ch] = beta[c0 + ch];
       if (blockIdx.y == 0) {
         mean[c0 + ch] = fm; rstd[c0 + ch] = fr;
-        if (mmean) mmean[c0 + ch] -= (1.0f - decay) * (mmean[c0 + ch] - fm);
-        if (mvar) mvar[c0 + ch] -= (1.0f - decay) * (mvar[c0 + ch] - (float)var);
+        if (decay < 0.f) {                                                 // store mode (bn_finalize_kernel)
+          if (mmean) mmean[c0 + ch] = fm;
+          if (mvar) mvar[c0 + ch] = (float)var;
+        } else {
+          if (mmean) mmean[c0 + ch] -= (1.0f - decay) * (mmean[c0 + ch] - fm);
+          if (mvar) mvar[c0 + ch] -= (1.0f - decay) * (mvar[c0 + ch] - (float)var);
+        }
       }
     }
     __syncthreads();
@@ -911,6 +921,22 @@ ema_update_kernel(float* __restrict__ ema, const float* __restrict__ v, long lon
   }
 }
 
+// moving statistics of every batch-norm layer of a step in one launch, gated like the optimiser (a skipped step leaves
+// them untouched); lane 0 counts the skipped steps
+__global__ void __launch_bounds__(kT)
+bn_moving_update_kernel(float* __restrict__ mm, float* __restrict__ mv, const float* __restrict__ bmean,
+                        const float* __restrict__ bvar, long long n, float decay, const float* __restrict__ skip_ctl,
+                        unsigned long long* __restrict__ skipped) {
+  if (skip_ctl && (skip_ctl[0] != 0.f || skip_ctl[1] != 0.f)) {
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1ull;  // (one writer: launches are stream-ordered)
+    return;
+  }
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    mm[i] -= (1.0f - decay) * (mm[i] - bmean[i]);                          // bn_finalize_kernel's expressions
+    mv[i] -= (1.0f - decay) * (mv[i] - bvar[i]);
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 typedef const unsigned short* cus;
 typedef unsigned short* us;
@@ -1180,6 +1206,17 @@ extern "C" int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* 
   MBX_ENTER();
   hipLaunchKernelGGL(rmsprop_ema_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), w, g, ms, momentum != 0.f ? mom : nullptr,
                      ema, (us)w_bf16, (long long)n, lr, decay, momentum, eps, wd, ema_decay, trainable, reg_loss, skip_ctl);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* batch_mean, const float* batch_var,
+                                    int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps,
+                                    mbx_stream_t stream) {
+  if (!moving_mean || !moving_var || !batch_mean || !batch_var || n <= 0 || decay < 0.f) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_moving_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), moving_mean, moving_var,
+                     batch_mean, batch_var, (long long)n, decay, skip_ctl, reinterpret_cast<unsigned long long*>(skipped_steps));
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

@@ -96,6 +96,11 @@ class Net:
             self.wgrad_overlap_cus = min(self.wgrad_overlap_cus, self.n_cus // 2)
             self.chain_cap = min(self.bn_max_wg or self.n_cus, self.n_cus - self.wgrad_overlap_cus)
         self.cu_cap = 0
+        # defer_moving (the Trainer sets it): the forward pass leaves the moving statistics alone -- bn_finalize stores the batch
+        # variance beside the batch mean -- and apply_moving_update() applies `moving -= (1-decay)(moving - batch)` for every
+        # layer in ONE launch behind the backward pass, gated by the step control word like the optimiser: a step that is
+        # skipped (barrier timeout, stop request) is skipped everywhere.  Same float32 expressions: bit-identical values.
+        self.defer_moving = False
         # work counters of the persistent igemm5 launches (mbx_conv_desc.work_counter): one per launch, cleared together
         # at the start of every pass (forward() / backward())
         self.i5_counters = torch.zeros(8192, dtype=torch.int32, device=device)
@@ -383,6 +388,7 @@ class Net:
         self.MM = torch.zeros(self.nBt, **f32)
         self.MV = torch.ones(self.nBt, **f32)
         self.bn_mean = torch.zeros(self.nBt, **f32)
+        self.bn_var = torch.zeros(self.nBt, **f32)      # biased batch variance (deferred moving-average update)
         self.bn_rstd = torch.ones(self.nBt, **f32)
         self.bn_scale = torch.ones(self.nBt, **f32)     # folded (frozen) BN
         self.bn_shift = torch.zeros(self.nBt, **f32)
@@ -524,17 +530,22 @@ class Net:
                 beta = self._sl(self.Bt, op.beta_off, op.K)
                 out = op.out
 
-                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out):
+                var = self._sl(self.bn_var, op.beta_off, op.K)
+
+                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    decay = self.bn_decay
+                    if self.defer_moving:                    # store mode: batch variance -> bn_var, moving statistics untouched
+                        mm, mv, decay = None, var, -1.0
                     # (timing probe of tools/whatif_probe.py: finalize only, `a` keeps the previous step's values)
                     if self._probe_skip_apply and ("/block" in op.name or "/Block8" in op.name):
-                        _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, self.bn_decay,
-                                                     mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "fin")
+                        _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, decay,
+                                                     mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv), s), "fin")
                         return
-                    _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, self.bn_decay,
+                    _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, decay,
                                                     op.y.data_ptr(), op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
-                                                    mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), s), "bn_apply_fused")
+                                                    mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv), s), "bn_apply_fused")
                 L.append(run)
             elif op.kind == "frozen":
                 d = self._tune(op, self._desc(op, op.out, epilogue=ops.EPI_AFFINE, relu=op.relu,
@@ -733,6 +744,17 @@ class Net:
             _lib.check(_lib.lib().mbx_filter_prepare(self.Wb.data_ptr(), self.Wd.data_ptr(), self.filter_table.data_ptr(),
                                                      self.filter_entries, self.filter_blocks,
                                                      torch.cuda.current_stream().cuda_stream), "filter_prepare")
+
+    def apply_moving_update(self, skip_ctl=None, skipped_steps=None):
+        """The deferred moving-average update of every training-mode batch-norm layer (defer_moving), one launch.
+        skip_ctl / skipped_steps: device tensors (step control block; int64 counter of skipped steps) or None."""
+        lo = self.head_bt_start if self.fine_tune else 0          # --fine_tune: the backbone's batch norm is frozen (train.py:124-131)
+        n = self.nBt - lo
+        if n > 0 and self.mode == "train":
+            _lib.check(_lib.lib().mbx_bn_moving_update(self.MM.data_ptr() + 4 * lo, self.MV.data_ptr() + 4 * lo,
+                                                       self.bn_mean.data_ptr() + 4 * lo, self.bn_var.data_ptr() + 4 * lo, n,
+                                                       self.bn_decay, ops._p(skip_ctl), ops._p(skipped_steps),
+                                                       torch.cuda.current_stream().cuda_stream), "bn_moving_update")
 
     def fold_bn(self):
         """Frozen BN -> per-channel scale/shift for the conv epilogue (detect.py:313-326)."""

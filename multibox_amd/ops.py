@@ -150,6 +150,7 @@ I5_TILE_CONFIGS = (33, 34, 35, 36, 37)         # 128x64, 128x128, 192x128, 256x1
 I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
 I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
 _TUNED = {}          # repr(shape key) -> tile_config: one measurement per distinct conv in a process
+TUNE_STATS = {"hits": 0, "remeasured": 0, "rejected": 0}    # table entries used as they are / shapes measured here / entries refused
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")
 
 
@@ -181,11 +182,15 @@ def autotune(desc: ConvDesc, key, candidates=None, iters=10):
     key = repr(key)
     if key in _TUNED:
         desc.tile_config = _TUNED[key]
-        # one launch to make sure the table's choice still APPLIES to this shape (a table written by an older library whose
-        # kernels covered other shapes must not turn into MBX_ERR_UNSUPPORTED in the middle of a training step)
-        if _lib.lib().mbx_conv(C.byref(desc), _stream()) == 0:
+        # make sure the table's choice still APPLIES to this shape (a table written by an older library whose kernels covered
+        # other shapes must not turn into MBX_ERR_UNSUPPORTED in the middle of a training step): mbx_conv_supported runs
+        # every check of mbx_conv without a launch -- nothing is written, nothing asynchronous can fail behind it
+        if _lib.lib().mbx_conv_supported(C.byref(desc)) == 0:
+            TUNE_STATS["hits"] += 1
             return desc.tile_config
-        del _TUNED[key]
+        del _TUNED[key]                                # (also dropped from the file by the next save_tune_cache)
+        TUNE_STATS["rejected"] += 1
+    TUNE_STATS["remeasured"] += 1
     if candidates is None:
         candidates = (0, 2, 4, 5, 6, 9, 10, 12, 13, 14)      # the tiles that won somewhere on the B=64 layer shapes
         if os.environ.get("MBX_AUTOTUNE_SET") == "all":

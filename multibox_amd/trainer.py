@@ -78,6 +78,13 @@ class Trainer:
         self.events = []                               # things a log should show (BN-backward fall-back, ...)
         self._timeouts_seen = 0
         self._stop_flag = torch.zeros((), **f32)       # request_stop(): copied into the step control block every step
+        # A skipped step (control word non-zero) is skipped EVERYWHERE: the forward pass only records the batch statistics
+        # and the moving averages are updated in the optimiser phase behind the same gate (Net.apply_moving_update), which
+        # also counts the skipped steps; check_health() takes them off global_step again (the learning-rate schedule,
+        # NUM_TRAIN_ITERATIONS and checkpoint names count APPLIED steps).
+        net.defer_moving = True
+        self.skipped_steps = torch.zeros((), dtype=torch.int64, device=net.dev)
+        self._skipped_seen = 0
         # backward segments = gradient buckets (each also ends in one grouped weight-gradient launch and is one hipGraph).
         # Four of 60 MB; data-parallel runs cut the LAST one once more: the 2 M parameters at the bottom of the network
         # (stem, Mixed_5b, block35: 6.7 MB of the 240) get a bucket of their own, so that the all-reduce nothing overlaps
@@ -98,6 +105,7 @@ class Trainer:
             if self.overlap_cus and not self.reducer.enabled:
                 n_segments, by_work = int(os.environ.get("MBX_WG_GROUPS", "8")), True
         self._side = None
+        self.exposed_events = None                     # a list: step() brackets reducer.wait() with an event pair (bench.py)
         self._segments = self._make_segments(n_segments, tail_params=tail, by_work=by_work)
 
     def refresh_frozen_reg(self):
@@ -185,6 +193,10 @@ class Trainer:
             falls back to the three-launch BN backward (no grid barrier), drops its captured graphs (re-captured in
             this process by the next step()) and carries on; the event is recorded in self.events.  Raises only if
             timeouts are seen after the fallback.
+        Steps the optimiser skipped since the last call (counted on the device by the gated moving-statistics launch; the
+        same number on every rank, the control word being summed over ranks) are taken off global_step and recorded in
+        self.events.  A stop request is evaluated FIRST: the steps behind it were not applied, so whatever the repeated
+        (or never set) batch of the exhausted rank did to the matcher does not turn a clean end of input into an error.
         Returns {"stop": a rank called request_stop(), "fallback": this call switched the BN backward}."""
         net = self.net
         wg_bad = sum(0 if g.completed_ok() else 1 for g in getattr(self, "wgrad_groups", []))
@@ -195,6 +207,15 @@ class Trainer:
             if dist.get_world_size(self.pg) > 1:
                 dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.pg)
         t, m, w, stop = (int(v) for v in bad.tolist())
+        sk = getattr(self, "skipped_steps", None)
+        skipped = (int(sk) - self._skipped_seen) if sk is not None else 0
+        if skipped:
+            self._skipped_seen += skipped
+            self.events.append({"event": "skipped_steps", "count": skipped, "global_step_before": self.global_step,
+                                "global_step": self.global_step - skipped, "stop_requested": bool(stop), "barrier_timeouts": t})
+            self.global_step -= skipped                # only applied steps count
+        if stop:
+            return {"stop": True, "fallback": False}
         if m:
             raise RuntimeError("bipartite matching failed on %d rank(s) (non-finite predictions or n_gt > P)" % m)
         if w:
@@ -399,7 +420,16 @@ class Trainer:
             for i, (_, lo, hi) in enumerate(self._segments):
                 self._run_segment(i)
                 reduce(i, lo, hi)
-        red.wait()
+        if self.exposed_events is not None and red.enabled:
+            # diagnostics (bench.py, N > 1): how long the training stream sits behind the last collectives -- the part of the
+            # all-reduce the backward pass did not hide
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            red.wait()
+            e1.record()
+            self.exposed_events.append((e0, e1))
+        else:
+            red.wait()
         self._optimizer()
         self.global_step += 1
 
@@ -447,6 +477,7 @@ class Trainer:
             else:
                 _lib.check(l.mbx_rmsprop_ema_step(P(net.Bt, lo), P(net.Btg, lo), P(self.Btms, lo), P(self.Btmom, lo), P(self.Btema, lo),
                                                   None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, on, None, ctl, s), "rmsprop beta")
+        net.apply_moving_update(net.step_ctl, self.skipped_steps)      # moving statistics: this step's batch statistics, gated
         lo, n = self.bt_lo, net.nBt - self.bt_lo
         _lib.check(l.mbx_ema_update(P(self.MMema, lo), P(net.MM, lo), n, d, ctl, s), "ema moving_mean")
         _lib.check(l.mbx_ema_update(P(self.MVema, lo), P(net.MV, lo), n, d, ctl, s), "ema moving_var")

@@ -162,6 +162,14 @@ def _bcast_worker(rank, world, port, q):
     if rank == 1:
         tr.request_stop()
     ok = ok and tr.check_health()["stop"] is True
+    # ... and it is evaluated FIRST: with the request up, a failed matching on the exhausted rank (its repeated batch;
+    # those steps were not applied) ends the run cleanly instead of raising
+
+    class StopLoss:
+        status = torch.tensor([0, 2 if rank == 1 else 0], dtype=torch.int32)
+    tr.loss = StopLoss()
+    ok = ok and tr.check_health() == {"stop": True, "fallback": False}
+    tr._stop_flag.zero_()
     # health: rank 1 reports a failed matching, both ranks must raise
 
     class FakeLoss:

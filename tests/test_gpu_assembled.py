@@ -160,17 +160,22 @@ tr = Trainer(net, pri, max_num_bboxes=13, use_graph=False)
 images, gt, n = synthetic_batch(B, 299, 13, seed=3)
 tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
 w0, ema0 = net.W.clone(), tr.Wema.clone()
+mm0, mv0, mme0 = net.MM.clone(), net.MV.clone(), tr.MMema.clone()
 tr.step()
 torch.cuda.synchronize()
 print("TIMEOUTS", net.barrier_timeouts(), "NAN_IN_GRAD", bool(torch.isnan(net.Wg).any()), "POISON_WORD", float(net.step_ctl[0]) > 0)
 print("STEP_APPLIED", not (torch.equal(net.W, w0) and torch.equal(tr.Wema, ema0)))
+# a skipped step is skipped EVERYWHERE: moving statistics (and their shadows) bit-unchanged, the batch statistics recorded
+print("MOVING_UNTOUCHED", torch.equal(net.MM, mm0) and torch.equal(net.MV, mv0) and torch.equal(tr.MMema, mme0), bool((net.bn_var != 0).any()))
+print("GLOBAL_STEP_BEFORE_CHECK", tr.global_step)
 h = tr.check_health()
-print("FALLBACK", h["fallback"], net.no_onepass, len(tr.events))
+print("FALLBACK", h["fallback"], net.no_onepass, [e["event"] for e in tr.events], tr.global_step)
 tr.step()
 torch.cuda.synchronize()
 print("AFTER", net.barrier_timeouts() - tr._timeouts_seen, bool(torch.isfinite(net.Wg).all()), not torch.equal(net.W, w0), float(net.step_ctl[0]))
+print("MOVING_UPDATED", not torch.equal(net.MM, mm0) and not torch.equal(net.MV, mv0), tr.global_step)
 h = tr.check_health()
-print("SECOND_CHECK", h["fallback"])
+print("SECOND_CHECK", h["fallback"], tr.global_step)
 """
 
 
@@ -186,8 +191,9 @@ def test_barrier_timeout_falls_back_in_process(torch_cuda):
     assert "NAN_IN_GRAD True" in out and "POISON_WORD True" in out, out[-800:]
     assert int(out.split("TIMEOUTS")[1].split()[0]) > 0
     assert "STEP_APPLIED False" in out, out[-800:]
-    assert "FALLBACK True True 1" in out, out[-800:]
-    assert "AFTER 0 True True 0.0" in out and "SECOND_CHECK False" in out, out[-800:]
+    assert "MOVING_UNTOUCHED True True" in out and "GLOBAL_STEP_BEFORE_CHECK 1" in out, out[-800:]
+    assert "FALLBACK True True ['skipped_steps', 'bn_backward_fallback'] 0" in out, out[-800:]            # the skipped step does not count
+    assert "AFTER 0 True True 0.0" in out and "MOVING_UPDATED True 1" in out and "SECOND_CHECK False 1" in out, out[-800:]
     assert "continuing with the three-launch BN backward" in r.stderr
 
 
@@ -306,3 +312,34 @@ def test_overlapped_weight_gradients_bit_identical(torch_cuda):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "overlap_check.py"), "96", "3", "16"],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, MBX_DETERMINISTIC="1"))
     assert r.returncode == 0 and "OVERLAP_CHECK OK" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_deferred_moving_update_bit_identical(torch_cuda):
+    """The moving-average update of the batch-norm statistics applied behind the backward pass in one gated launch
+    (Net.defer_moving, mbx_bn_moving_update: what the Trainer uses so that a skipped step leaves them untouched) gives the
+    bits of the in-place update of mbx_bn_finalize / mbx_bn_apply_fused (train.py:94-99); with the control word raised it
+    changes nothing and counts the step."""
+    torch = torch_cuda
+    from multibox_amd.engine import Net
+    from multibox_amd.synth import synthetic_batch
+    B = 2
+    images, _, _ = synthetic_batch(B, 299, 13, seed=5)
+    nets = [Net(batch=B, input_size=299, k=5, mode="train", seed=2, repeats=(1, 1, 1)) for _ in range(2)]
+    a, b = nets
+    b.defer_moving = True
+    mm0, mv0 = b.MM.clone(), b.MV.clone()
+    for net in nets:
+        net.set_input(torch.from_numpy(images).cuda())
+        net.forward()
+    torch.cuda.synchronize()
+    assert torch.equal(b.MM, mm0) and torch.equal(b.MV, mv0) and not torch.equal(a.MM, mm0)
+    ctl = torch.tensor([0.0, 1.0], device="cuda")                       # a stop request: skipped, counted
+    skipped = torch.zeros((), dtype=torch.int64, device="cuda")
+    b.apply_moving_update(ctl, skipped)
+    torch.cuda.synchronize()
+    assert torch.equal(b.MM, mm0) and torch.equal(b.MV, mv0) and int(skipped) == 1
+    ctl.zero_()
+    b.apply_moving_update(ctl, skipped)
+    torch.cuda.synchronize()
+    assert torch.equal(a.MM, b.MM) and torch.equal(a.MV, b.MV) and int(skipped) == 1
+    assert torch.equal(a.bn_mean, b.bn_mean) and torch.equal(a.bn_rstd, b.bn_rstd)

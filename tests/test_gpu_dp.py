@@ -126,18 +126,29 @@ def _worker_shipped(rank, world, port, out_dir, B=4):
     n_onepass = sum(1 for op in net.convs if getattr(op, "bn_ws_off", -1) >= 0)
     n_persistent = sum(1 for _, d, _ in net.tune_registry if d.tile_config > 32)
     tr.set_batch(*_batch(torch, rank, B))
-    healthy, fallback = True, False
-    for _ in range(2):                       # steps, health check (may fall back, both ranks together), more steps
-        for _ in range(3 if B == 4 else 2):  # (B = 64: 240 MB of gradients cross gloo's host path every step)
+    healthy, fallback, checks = True, False, []
+    for rnd in range(3):                     # steps, health check (may fall back, both ranks together), more steps
+        n_steps = 3 if B == 4 else 2         # (B = 64: 240 MB of gradients cross gloo's host path every step)
+        before = net.barrier_timeouts()
+        for _ in range(n_steps):
             tr.step()
         torch.cuda.synchronize()
+        rec = {"round": rnd, "steps": n_steps, "bn_backward_before": "three-launch" if net.no_onepass else "one-launch",
+               "timeouts_in_round": net.barrier_timeouts() - before, "error": None}
         try:
-            fallback = tr.check_health()["fallback"] or fallback
-        except RuntimeError:
+            h = tr.check_health()
+            fallback = h["fallback"] or fallback
+            rec.update(fallback_taken=bool(h["fallback"]), skipped_steps_total=int(tr.skipped_steps), global_step=tr.global_step)
+        except RuntimeError as e:
             healthy = False
+            rec["error"] = str(e)
+        checks.append(rec)
     torch.save({"W": net.W.cpu(), "Bt": net.Bt.cpu(), "Wg": net.Wg.cpu(), "loss": tr.losses(), "healthy": healthy,
                 "fallback": fallback, "timeouts": net.barrier_timeouts(), "onepass_layers": n_onepass,
-                "persistent_launches": n_persistent, "events": tr.events}, os.path.join(out_dir, "s_rank%d.pt" % rank))
+                "persistent_launches": n_persistent, "events": tr.events, "checks": checks,
+                "bn_backward_at_end": "three-launch" if net.no_onepass else "one-launch",
+                "applied_steps": tr.global_step, "skipped_steps": int(tr.skipped_steps)},
+               os.path.join(out_dir, "s_rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -162,14 +173,32 @@ def test_two_rank_shipped_configuration(tmp_path, B):
         p.join(900)
         assert p.exitcode == 0
     r0, r1 = torch.load(tmp_path / "s_rank0.pt"), torch.load(tmp_path / "s_rank1.pt")
+    # WHICH branch happened is part of the result: written to gpurun_out/ (merged back from the GPU box)
+    import json
+    branch = {"batch_per_rank": B, "bn_max_workgroups": 96, "ranks_on_one_gpu": 2,
+              "branch": "fallback to the three-launch BN backward" if r0["fallback"] else "one-launch BN backward held",
+              "rank0": {k: r0[k] for k in ("checks", "timeouts", "fallback", "bn_backward_at_end", "applied_steps", "skipped_steps",
+                                           "onepass_layers", "persistent_launches", "healthy")},
+              "rank1": {k: r1[k] for k in ("checks", "timeouts", "fallback", "bn_backward_at_end", "applied_steps", "skipped_steps", "healthy")}}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "test_two_rank_shipped_B%d.json" % B), "w") as f:
+        json.dump(branch, f, indent=1)
     assert r0["onepass_layers"] > 100                                   # the one-launch BN backward really ran
-    assert r0["healthy"] and r1["healthy"]
+    # a time-out AFTER the fall-back (or any other failed health check) fails the test on either rank
+    assert r0["healthy"] and r1["healthy"], branch
+    assert r0["applied_steps"] == r1["applied_steps"] and r0["skipped_steps"] == r1["skipped_steps"], branch   # skipped together
     if B == 4:
-        assert r0["timeouts"] == 0 and r1["timeouts"] == 0 and not r0["fallback"]
+        assert r0["timeouts"] == 0 and r1["timeouts"] == 0 and not r0["fallback"], branch
     else:
         assert r0["persistent_launches"] > 100                          # queued igemm5 launches under contention
-        assert r0["fallback"] == r1["fallback"] and (r0["fallback"] or r0["timeouts"] + r1["timeouts"] == 0), (r0["events"], r1["events"])
-        print("B=64 two ranks on one GPU: timeouts", r0["timeouts"], r1["timeouts"], "fallback", r0["fallback"])
+        assert r0["fallback"] == r1["fallback"], branch
+        if r0["fallback"]:
+            # taken once, together; every round AFTER it clean (no time-outs, no skipped steps) and on the three-launch form
+            after = [c for c in r0["checks"] + r1["checks"] if c["bn_backward_before"] == "three-launch"]
+            assert after and all(c["timeouts_in_round"] == 0 and c["error"] is None for c in after), branch
+            assert r0["bn_backward_at_end"] == r1["bn_backward_at_end"] == "three-launch", branch
+        else:
+            assert r0["timeouts"] + r1["timeouts"] == 0 and r0["skipped_steps"] == 0, branch
     # four / six steps on: all-reduced gradients and weights identical on both ranks, bit for bit
     assert torch.equal(r0["Wg"], r1["Wg"]) and torch.equal(r0["W"], r1["W"]) and torch.equal(r0["Bt"], r1["Bt"])
     assert bool(torch.isfinite(r0["W"]).all()) and all(np.isfinite(x) for x in r0["loss"])

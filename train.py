@@ -131,6 +131,7 @@ def main():
                 exhausted[0] = True
                 if world == 1:
                     real.close()
+                    print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP, cfg.get("KEEP_CHECKPOINT_EVERY_N_HOURS", 10000.0)))
                     raise SystemExit("input exhausted at step %d" % tr.global_step)
                 tr.request_stop()
         return None
@@ -154,9 +155,11 @@ def main():
             if health["stop"]:
                 if real is not None:
                     real.close()
+                if rank == 0:                                 # slim.learning.train saves when the input runs out (OutOfRange)
+                    print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP, cfg.get("KEEP_CHECKPOINT_EVERY_N_HOURS", 10000.0)))
                 if world > 1:
                     torch.distributed.destroy_process_group()
-                raise SystemExit("input exhausted on at least one rank; stopped at step %d" % tr.global_step)
+                raise SystemExit("input exhausted on at least one rank; stopped at step %d (applied steps)" % tr.global_step)
         if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
             loc, conf, reg, total = tr.losses()
             now = time.time()
