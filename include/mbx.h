@@ -179,6 +179,12 @@ typedef struct {
      CUs to a kernel running beside this one on another stream (the capped grouped weight gradient of the previous
      backward segment, mbx_conv_wgrad_grouped_capped; RCCL).  Results do not depend on it.                          */
   int32_t max_workgroups;
+  /* tile_config 128 + S (S = 2..32): SPLIT-K for long-K convolutions with few output tiles (forward, bf16 store with or
+     without statistics): S slices of the K range per 128 x 64 tile as float32 partial tiles in this workspace
+     (mbx_conv_splitk_workspace_bytes(), 16-byte aligned), then one launch that adds the slices in slice order
+     (deterministic), rounds, stores y and writes the statistics partials (a row per 16 pixels).  The float32 sum is
+     grouped differently from the one-pass kernels: results agree with them to 1 bf16 ulp, not bit for bit.          */
+  void* splitk_ws; int64_t splitk_ws_bytes;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
@@ -192,6 +198,7 @@ int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
  * epilogue -- WITHOUT a launch: what mbx_conv would return short of a launch error.  For callers that keep a table of
  * measured tile choices and must not find out in the middle of a step that an entry no longer applies.               */
 int mbx_conv_supported(const mbx_conv_desc* desc /*HOST*/);
+size_t mbx_conv_splitk_workspace_bytes(const mbx_conv_desc* desc /*HOST*/);   /* 0 unless tile_config is a split-K one */
 
 /* Weight gradient (TF autodiff of slim.conv2d, train.py:263):
  * dw[k][r][s][c] += sum_{n,oh,ow} dy[n,oh,ow,k] * x[n, oh*stride-pad_t+r, ow*stride-pad_l+s, c]
@@ -349,6 +356,25 @@ int mbx_head_gather(const float* h, int ld_h, int N, int cells, int k, int P, in
                     float* locs, float* logits, mbx_stream_t stream);
 int mbx_head_scatter(const float* d_locs, const float* d_logits, int N, int cells, int k, int P,
                      int off, void* g, int ld_g, mbx_stream_t stream);
+
+/* All heads of the network in ONE launch each way (at most 8; model.py:198-324 has six): the per-head calls above cost a
+ * kernel launch each for a few kilobytes.  `h` / `ld_h` are read by the gather, `g` / `ld_g` written by the scatter.  */
+typedef struct {
+  const float* h; int32_t ld_h;   /* float32 conv output [N*cells, ld_h] */
+  void* g; int32_t ld_g;          /* bf16 gradient [N*cells, ld_g] */
+  int32_t cells, k, off;          /* grid cells, boxes per cell, prior offset of the head */
+} mbx_head;
+int mbx_head_gather_all(const mbx_head* heads /*HOST*/, int n_heads, int N, int P, float* locs, float* logits,
+                        mbx_stream_t stream);
+int mbx_head_scatter_all(const float* d_locs, const float* d_logits, const mbx_head* heads /*HOST*/, int n_heads, int N,
+                         int P, mbx_stream_t stream);
+
+/* Start of a training step's backward pass in one launch: grads[0, n_grads) and bn_ws[0, n_ws) (float32 counts, multiples
+ * of 4, 16-byte aligned buffers) are cleared; before grads[ctl_index] -- word [0] of the step control block, the grid-
+ * barrier time-outs of the PREVIOUS step (mbx_bn_bwd_onepass step_poison, summed over ranks) -- is cleared, its value is
+ * added to *timeouts_total (DEVICE uint64, may be NULL), so that a time-out between two host checks is not lost.        */
+int mbx_step_begin(float* grads, int64_t n_grads, float* bn_ws, int64_t n_ws, int64_t ctl_index, uint64_t* timeouts_total,
+                   mbx_stream_t stream);
 
 /* ---------------------------------------------------------- parameters (A8, K16-K18)
  * Filters live as float32 masters in one flat buffer (KRSC each); the bf16 copies the

@@ -45,6 +45,7 @@ _SIGS = {
     "mbx_conv_stats_rows": (I, [P]),
     "mbx_conv": (I, [P, P]),
     "mbx_conv_supported": (I, [P]),
+    "mbx_conv_splitk_workspace_bytes": (SZ, [P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
     "mbx_conv_wgrad_scaled": (I, [P, P, C.c_int64, I, F, P, P, P]),
     "mbx_wgrad_plan_bytes": (SZ, [P, I, I]),
@@ -71,6 +72,9 @@ _SIGS = {
     "mbx_pack_input": (I, [P, C.c_int64, P, P]),
     "mbx_head_gather": (I, [P, I, I, I, I, I, I, P, P, P]),
     "mbx_head_scatter": (I, [P, P, I, I, I, I, I, P, I, P]),
+    "mbx_head_gather_all": (I, [P, I, I, I, P, P, P]),
+    "mbx_head_scatter_all": (I, [P, P, P, I, I, I, P]),
+    "mbx_step_begin": (I, [P, C.c_int64, P, C.c_int64, C.c_int64, P, P]),
     "mbx_filter_prepare": (I, [P, P, P, I, I, P]),
     "mbx_rmsprop_ema_step": (I, [P, P, P, P, P, P, C.c_int64, F, F, F, F, F, F, I, P, P, P]),
     "mbx_ema_update": (I, [P, P, C.c_int64, F, P, P]),
@@ -81,6 +85,12 @@ _lib = None
 
 class MbxError(RuntimeError):
     pass
+
+
+class Head(C.Structure):
+    """mbx_head (include/mbx.h)."""
+    _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int32), ("g", C.c_void_p), ("ld_g", C.c_int32), ("cells", C.c_int32),
+                ("k", C.c_int32), ("off", C.c_int32)]
 
 
 class FilterEntry(C.Structure):

@@ -48,7 +48,9 @@ conv_igemm3_kernel(const ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wn = wave % WNW, wm = wave / WNW;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int split = 0;                                        // split-K slice of this block (float32 partial tiles only)
+  if constexpr (EV == 5) { const int nt = p.tiles_m * p.tiles_n; split = lid / nt; lid -= split * nt; }
   const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -108,7 +110,9 @@ conv_igemm3_kernel(const ConvK p) {
       nk = ((p.R - kr0 + 1) >> 1) * ((p.S - ks0 + 1) >> 1) * (p.C_in >> 6);
     }
   }
-  int kc = chunk * 8, kr = kr0, ks = ks0;
+  int kt0 = 0;                                          // first K step of this block (split-K slices start later)
+  if constexpr (EV == 5) { kt0 = split * p.kps; nk = min(p.kps, nk - kt0); }
+  int kc = chunk * 8 + kt0 * 64, kr = kr0, ks = ks0;
   while (kc >= p.C_in) { kc -= p.C_in; if ((ks += kstep) >= p.S) { ks = ks0; kr += kstep; } }
   const int ldx2 = p.ldx * 2;
   int st_issue = 0, st_comp = 0;                        // ring positions
@@ -139,7 +143,7 @@ conv_igemm3_kernel(const ConvK p) {
     /* the filter lane's own K position (its chunk differs from the pixel lane's): linear in K, except in the     \
        tap-skipping walk, where C_in % 64 == 0 and a K tile lies inside one tap */                             \
     const int kb = (SH && kstep == 2) ? ((kr * p.S + ks) * p.C_in + kc + (chunkw - chunk) * 8) * 2                \
-                                      : ((LT) * 64 + chunkw * 8) * 2;                                          \
+                                      : (((LT) + kt0) * 64 + chunkw * 8) * 2;                                  \
     const bool kvw = (SH && kstep == 2) ? kv : (kb < p.Ktot * 2);                                              \
     u32x4* sw = sp + BM * 8;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                           \
@@ -231,7 +235,7 @@ conv_igemm3_kernel(const ConvK p) {
       const int m = m0 + wm * TM + b * 16 + frow;
       if (m >= p.M) continue;
       const int img = (int)fast_div((unsigned)m, p.mg_hw, p.sh_hw), pix = m - img * p.HW_out;
-      float* yrow = reinterpret_cast<float*>(p.y) + img * p.y_img_stride + pix * p.ldy;
+      float* yrow = reinterpret_cast<float*>(p.y) + split * p.y_split_stride + img * p.y_img_stride + pix * p.ldy;
 #pragma unroll
       for (int a = 0; a < NI; ++a) {
         const int c0 = n0 + cl0 + 32 * (a >> 1) + 4 * (a & 1);
@@ -1023,6 +1027,70 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
   }
 }
 
+// ------------------------------------------------------------------------------------------ split-K reduce
+// Long-K convolutions with few output tiles (the 3x3 head convolutions on the 1536-channel feature map: K = 13 824, at most
+// 64 tiles of 128 x 64 on 256 CUs) run as `ksplit` K slices per tile -- float32 partial tiles [slice][M][ldp] from the
+// float32-store instantiation of conv_igemm3_kernel -- and this kernel adds the slices IN SLICE ORDER (deterministic),
+// rounds to bf16, stores y and writes the batch-norm statistics partials of the stored values (one row of [C][2] per 64
+// pixels), i.e. everything the EV = 1 epilogue does.  One workgroup per 64 pixels; lane = one 4-channel group of one row.
+constexpr int kSplitRows = 16;                        // pixels per workgroup of the reduce launch = per statistics row
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice_stride, int M, int C, int ldp,
+                     unsigned short* __restrict__ y, int HW_out, long long y_img_stride, int ldy, float* __restrict__ stats) {
+  __shared__ float red[kSplitRows][256][2];             // [row][channel][value | value^2] of the STORED values (C <= 256 per pass)
+  const int m0 = blockIdx.x * kSplitRows, tid = threadIdx.x;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int cw = min(256, C - cb), c4 = (cw + 3) >> 2;     // 4-channel groups of this pass
+    if (cb) __syncthreads();                            // (red is reused per pass)
+    for (int item = tid; item < kSplitRows * c4; item += 256) {
+      const int r = item / c4, gq = item - r * c4, m = m0 + r, c = cb + 4 * gq;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const float* src = part + (size_t)m * ldp + c;
+        a = *reinterpret_cast<const float4*>(src);
+        int sl = 1;
+        for (; sl + 3 < ksplit; sl += 4) {              // four slices' loads in flight, added in slice order
+          const float4 b0 = *reinterpret_cast<const float4*>(src + (sl + 0) * slice_stride);
+          const float4 b1 = *reinterpret_cast<const float4*>(src + (sl + 1) * slice_stride);
+          const float4 b2 = *reinterpret_cast<const float4*>(src + (sl + 2) * slice_stride);
+          const float4 b3 = *reinterpret_cast<const float4*>(src + (sl + 3) * slice_stride);
+          a.x = (((a.x + b0.x) + b1.x) + b2.x) + b3.x; a.y = (((a.y + b0.y) + b1.y) + b2.y) + b3.y;
+          a.z = (((a.z + b0.z) + b1.z) + b2.z) + b3.z; a.w = (((a.w + b0.w) + b1.w) + b2.w) + b3.w;
+        }
+        for (; sl < ksplit; ++sl) {
+          const float4 b = *reinterpret_cast<const float4*>(src + sl * slice_stride);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+      }
+      const float v[4] = {a.x, a.y, a.z, a.w};
+      unsigned q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j] = f2bf(v[j]);
+        const float f = (m < M && c + j < C) ? bf2f((unsigned short)q[j]) : 0.f;
+        if (4 * gq + j < 256) { red[r][4 * gq + j][0] = f; red[r][4 * gq + j][1] = f * f; }
+      }
+      if (m < M) {
+        const int img = m / HW_out, pix = m - img * HW_out;
+        unsigned short* dst = y + img * y_img_stride + (long long)pix * ldy + c;
+        if (c + 3 < C) *reinterpret_cast<u32x2*>(dst) = u32x2{q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+        else for (int j = 0; j < 4; ++j) if (c + j < C) dst[j] = (unsigned short)q[j];
+      }
+    }
+    if (stats) {
+      __syncthreads();
+      if (tid < cw) {
+        float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < kSplitRows; ++r) { x1 += red[r][tid][0]; x2 += red[r][tid][1]; }
+        float* o = stats + ((size_t)blockIdx.x * C + cb + tid) * 2;
+        o[0] = x1;
+        o[1] = x2;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
 struct TileCfg { int BM, BN; float eff; };
 const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {128, 32, 0.60f}, {64, 64, 0.70f},
@@ -1053,6 +1121,15 @@ int pick_cfg(long M, int C_out) {
 constexpr int kNumCfgs = 14;
 constexpr int kI5Flag = 32;      // mbx_conv_desc.tile_config = 32 + t: igemm5 tile t (conv5.hip), persistent launch
 constexpr int kI7Cfg = 65;       // mbx_conv_desc.tile_config = 65: igemm7 (conv7.hip), persistent pointwise launch with the filter panel in LDS
+constexpr int kSplitFlag = 128;  // mbx_conv_desc.tile_config = 128 + S: split-K in S slices (float32 partials + reduce launch)
+constexpr int kSplitMax = 32;
+// slices really used and K steps per slice for a request of S slices over nk K steps (no empty slice)
+inline void splitk_geom(int nk, int S, int& ksplit, int& kps) {
+  if (S > nk) S = nk;
+  if (S < 1) S = 1;
+  kps = (nk + S - 1) / S;
+  ksplit = (nk + kps - 1) / kps;
+}
 int choose_cfg(long M, int C_out, int desc_cfg) {
   static int force = -2;
   if (force == -2) { const char* e = getenv("MBX_FORCE_CFG"); force = e ? atoi(e) : -1; }
@@ -1093,10 +1170,10 @@ int launch_igemm(ConvK& k, hipStream_t s) {
         attr_set3[EV] = true;                                                                                 \
       }                                                                                                       \
       if (k.pw)                                                                                               \
-        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1, NSTG>), dim3(k.tiles_m * k.tiles_n),       \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 1, NSTG>), dim3(k.tiles_m * k.tiles_n * (EV == 5 ? k.ksplit : 1)), \
                            dim3(64 * WNW * WMW), lds, s, k);                                                  \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>), dim3(k.tiles_m * k.tiles_n),       \
+        hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>), dim3(k.tiles_m * k.tiles_n * (EV == 5 ? k.ksplit : 1)), \
                            dim3(64 * WNW * WMW), lds, s, k);                                                  \
       break;
     static bool attr_sh[2] = {false, false};
@@ -1149,6 +1226,7 @@ int check_desc(const mbx_conv_desc* d) {
 extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   if (!d) return MBX_ERR_INVALID_ARG;
   const long M = (long)d->N * d->H_out * d->W_out;
+  if (d->tile_config > kSplitFlag) return (int)((M + kSplitRows - 1) / kSplitRows);   // split-K: the reduce launch writes a row per 16 pixels
   if (d->tile_config == kI7Cfg) return (int)((M + 127) / 128);
   if (d->tile_config > kI5Flag) {
     const int i = d->tile_config - kI5Flag - 1;
@@ -1162,6 +1240,12 @@ extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
 static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry);
 extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) { return conv_impl(d, stream, 0); }
 extern "C" int mbx_conv_supported(const mbx_conv_desc* d) { return conv_impl(d, nullptr, 1); }
+extern "C" size_t mbx_conv_splitk_workspace_bytes(const mbx_conv_desc* d) {
+  if (!d || d->tile_config <= kSplitFlag || d->tile_config > kSplitFlag + kSplitMax) return 0;
+  int ksplit, kps;
+  splitk_geom((d->R * d->S * d->C_in + 63) >> 6, d->tile_config - kSplitFlag, ksplit, kps);
+  return (size_t)4 * d->N * d->H_out * d->W_out * (((d->C_out + 7) / 8) * 8) * ksplit;
+}
 
 static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   int st = check_desc(d);
@@ -1214,6 +1298,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   k.work_counter = d->work_counter;
   k.max_wg = d->max_workgroups;
   k.dry = dry;
+  k.ksplit = 1; k.kps = 1 << 30; k.y_split_stride = 0;
 #ifdef MBX_I5_STAMPS
   {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
@@ -1239,6 +1324,30 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     k.skip_taps = k.parity = 1;
   }
   hipStream_t s = mbx_s(stream);
+  if (d->tile_config > kSplitFlag) {
+    // split-K: forward convolutions with a bf16 store (+ statistics) epilogue only; partials in the caller's workspace
+    const int S = d->tile_config - kSplitFlag;
+    if (S < 2 || S > kSplitMax || d->transposed || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->rscale != 0.f)
+      return MBX_ERR_UNSUPPORTED;
+    const int ldp = ((d->C_out + 7) / 8) * 8;
+    int ksplit, kps;
+    splitk_geom((k.Ktot + 63) >> 6, S, ksplit, kps);
+    const long long slice = (long long)k.M * ldp;
+    if (!d->splitk_ws || (reinterpret_cast<uintptr_t>(d->splitk_ws) & 15) || d->splitk_ws_bytes < (int64_t)(4 * slice * ksplit) ||
+        slice * ksplit >= (1LL << 31))
+      return MBX_ERR_WORKSPACE;
+    ConvK g = k;
+    g.epi = MBX_EPI_STORE_F32; g.stats = nullptr; g.relu = 0;
+    g.y = d->splitk_ws; g.ldy = ldp; g.y_img_stride = k.HW_out * ldp;
+    g.ksplit = ksplit; g.kps = kps; g.y_split_stride = slice;
+    st = launch_igemm<128, 64, 2, 2>(g, s);
+    if (st != MBX_OK || dry) return st;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((k.M + kSplitRows - 1) / kSplitRows), dim3(256), 0, s, reinterpret_cast<const float*>(d->splitk_ws),
+                       ksplit, slice, k.M, k.C_out, ldp, reinterpret_cast<unsigned short*>(k.y), k.HW_out,
+                       (long long)k.y_img_stride, k.ldy, k.stats);
+    MBX_LAUNCH_CHECK();
+    return MBX_OK;
+  }
   if (d->tile_config == kI7Cfg) return mbx_launch_igemm7(&k, s);
   if (d->tile_config > kI5Flag) return mbx_launch_igemm5(&k, d->tile_config - kI5Flag - 1, s);
   switch (choose_cfg(k.M, k.C_out, d->tile_config)) {

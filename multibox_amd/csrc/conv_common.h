@@ -38,6 +38,9 @@ struct ConvK {
   int* work_counter;                   // igemm5: tiles after a workgroup's first come from this counter (NULL: static)
   int max_wg;                          // persistent launches: grid cap (0: one workgroup per CU); host side only
   int dry;                             // host side only: mbx_conv_supported() -- every check, no launch
+  // split-K (float32 partial tiles, igemm3 EV = 5 only): slice `lid / (tiles_m tiles_n)` multiplies K steps
+  // [slice * kps, ...) and stores to y + slice * y_split_stride floats; ksplit = 1: the whole K range
+  int ksplit, kps; long long y_split_stride;
 #ifdef MBX_I5_STAMPS
   unsigned long long* stamps;          // debug build: wall_clock64() per tile phase of the first 8 tiles of 64 blocks
   int dbg;                             // debug build: MBX_I5_DBG timing probes (bit 0: compute waves idle, bit 1: loaders do not wait)

@@ -812,6 +812,68 @@ head_scatter_kernel(const float* __restrict__ d_locs, const float* __restrict__ 
   }
 }
 
+// every detection head of the network in ONE launch (a kernel costs >= 4.4 us in the replayed step whatever it does: six
+// gathers behind six tiny head convolutions were 26 us of launches for 160 KB of data)
+constexpr int kMaxHeads = 8;
+struct HeadTable {
+  const float* h[kMaxHeads]; unsigned short* g[kMaxHeads];
+  int ld_h[kMaxHeads], ld_g[kMaxHeads], cells[kMaxHeads], k[kMaxHeads], off[kMaxHeads];
+  int start[kMaxHeads + 1];                  // prefix sums of the per-head element counts
+  int n;
+};
+
+__global__ void __launch_bounds__(kT)
+head_gather_all_kernel(const HeadTable t, int P, float* __restrict__ locs, float* __restrict__ logits) {
+  const int total = t.start[t.n];
+  for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    int j = 0;
+    while (j + 1 < t.n && i >= t.start[j + 1]) ++j;
+    const int e = i - t.start[j], k = t.k[j], cells = t.cells[j];
+    const int a = e % k, q = e / k, cell = q % cells, n = q / cells;
+    const float* row = t.h[j] + (size_t)(n * cells + cell) * t.ld_h[j];
+    const size_t p = (size_t)n * P + t.off[j] + cell * k + a;
+    *reinterpret_cast<float4*>(locs + p * 4) = make_float4(row[a * 4], row[a * 4 + 1], row[a * 4 + 2], row[a * 4 + 3]);
+    logits[p] = row[4 * k + a];
+  }
+}
+
+__global__ void __launch_bounds__(kT)
+head_scatter_all_kernel(const HeadTable t, int P, const float* __restrict__ d_locs, const float* __restrict__ d_logits) {
+  const int total = t.start[t.n];
+  for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    int j = 0;
+    while (j + 1 < t.n && i >= t.start[j + 1]) ++j;
+    const int e = i - t.start[j], k = t.k[j], cells = t.cells[j], ld = t.ld_g[j];
+    const int ch = e % ld, q = e / ld, cell = q % cells, n = q / cells;
+    const size_t p = (size_t)n * P + t.off[j] + cell * k;
+    float v = 0.f;
+    if (ch < 4 * k) v = d_locs[(p + ch / 4) * 4 + (ch & 3)];
+    else if (ch < 5 * k) v = d_logits[p + (ch - 4 * k)];
+    t.g[j][e] = (unsigned short)f2bf(v);
+  }
+}
+
+// start of a step's backward pass in ONE launch: the gradient buffer and the BN-backward workspace cleared (two fills),
+// and the grid-barrier time-outs of the PREVIOUS step -- word `ctl` of the gradient buffer, which this launch clears --
+// added to a running total first (was: five small torch kernels over the per-layer flags)
+__global__ void __launch_bounds__(kT)
+step_begin_kernel(float* __restrict__ G, long long nG, float* __restrict__ ws, long long nws, long long ctl,
+                  unsigned long long* __restrict__ timeouts_total) {
+  const long long n4 = nG >> 2, w4 = nws >> 2;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n4 + w4; i += (long long)gridDim.x * kT) {
+    if (i < n4) {
+      if (timeouts_total && i == (ctl >> 2)) {         // this lane is the one that clears the control word: read it first
+        const float t = G[ctl];
+        if (t > 0.f) *timeouts_total += (unsigned long long)t;
+      }
+      reinterpret_cast<float4*>(G)[i] = z;
+    } else {
+      reinterpret_cast<float4*>(ws)[i - n4] = z;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------- filter prepare
 // dst[c][r'][s'][kq] = src[kq][R-1-r'][S-1-s'][c]: a [K] x [C] transpose per tap.  Each workgroup moves a
 // 64(k) x 32(c) patch of one tap through LDS so that both the reads (contiguous in c) and the writes
@@ -1184,6 +1246,61 @@ extern "C" int mbx_head_scatter(const float* d_locs, const float* d_logits, int 
   MBX_ENTER();
   hipLaunchKernelGGL(head_scatter_kernel, dim3(grid_for((long long)N * cells * ld_g)), dim3(kT), 0, mbx_s(stream), d_locs,
                      d_logits, N, cells, k, P, off, (us)g, ld_g);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+static int fill_head_table(const mbx_head* heads, int n_heads, int N, int P, bool scatter, HeadTable& t) {
+  if (!heads || n_heads <= 0 || n_heads > kMaxHeads || N <= 0 || P <= 0) return MBX_ERR_INVALID_ARG;
+  long long acc = 0;
+  t.n = n_heads;
+  for (int j = 0; j < n_heads; ++j) {
+    const mbx_head& H = heads[j];
+    if (H.cells <= 0 || H.k <= 0 || H.off < 0 || H.off + H.cells * H.k > P) return MBX_ERR_INVALID_ARG;
+    if (scatter ? (!H.g || H.ld_g < 5 * H.k) : (!H.h || H.ld_h < 5 * H.k)) return MBX_ERR_INVALID_ARG;
+    t.h[j] = H.h; t.g[j] = reinterpret_cast<unsigned short*>(H.g);
+    t.ld_h[j] = H.ld_h; t.ld_g[j] = H.ld_g; t.cells[j] = H.cells; t.k[j] = H.k; t.off[j] = H.off;
+    t.start[j] = (int)acc;
+    acc += (long long)N * H.cells * (scatter ? H.ld_g : H.k);
+    if (acc >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  }
+  for (int j = n_heads; j <= kMaxHeads; ++j) t.start[j] = (int)acc;
+  return MBX_OK;
+}
+
+extern "C" int mbx_head_gather_all(const mbx_head* heads, int n_heads, int N, int P, float* locs, float* logits,
+                                   mbx_stream_t stream) {
+  if (!locs || !logits) return MBX_ERR_INVALID_ARG;
+  HeadTable t;
+  const int st = fill_head_table(heads, n_heads, N, P, false, t);
+  if (st != MBX_OK) return st;
+  MBX_ENTER();
+  hipLaunchKernelGGL(head_gather_all_kernel, dim3(grid_for(t.start[t.n])), dim3(kT), 0, mbx_s(stream), t, P, locs, logits);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_head_scatter_all(const float* d_locs, const float* d_logits, const mbx_head* heads, int n_heads, int N,
+                                    int P, mbx_stream_t stream) {
+  if (!d_locs || !d_logits) return MBX_ERR_INVALID_ARG;
+  HeadTable t;
+  const int st = fill_head_table(heads, n_heads, N, P, true, t);
+  if (st != MBX_OK) return st;
+  MBX_ENTER();
+  hipLaunchKernelGGL(head_scatter_all_kernel, dim3(grid_for(t.start[t.n])), dim3(kT), 0, mbx_s(stream), t, P, d_locs, d_logits);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_step_begin(float* grads, int64_t n_grads, float* bn_ws, int64_t n_ws, int64_t ctl_index,
+                              uint64_t* timeouts_total, mbx_stream_t stream) {
+  if (!grads || n_grads <= 0 || n_grads % 4 || n_ws < 0 || n_ws % 4 || (n_ws && !bn_ws) || !al16(grads) || (bn_ws && !al16(bn_ws)) ||
+      (timeouts_total && (ctl_index < 0 || ctl_index >= n_grads)))
+    return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  hipLaunchKernelGGL(step_begin_kernel, dim3(grid_for((n_grads + n_ws) / 4)), dim3(kT), 0, mbx_s(stream), grads,
+                     (long long)n_grads, bn_ws, (long long)n_ws, (long long)ctl_index,
+                     reinterpret_cast<unsigned long long*>(timeouts_total));
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

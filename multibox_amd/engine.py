@@ -458,7 +458,10 @@ class Net:
                 op.y = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)      # pre-BN output, kept for backward
                 self._bufs.append(op.y)
                 d = self._desc(op, View(op.y, op.out.N, op.out.H, op.out.W, op.K))
-                max_stats = max(max_stats, max(ops.conv_stats_rows(d), (op.M + 63) // 64) * op.K * 2)     # any tile height
+                rows = max(ops.conv_stats_rows(d), (op.M + 63) // 64)                                   # any tile height
+                if ops.splitk_slices(d, self.n_cus):
+                    rows = max(rows, (op.M + 15) // 16)                                                   # split-K: a row per 16 pixels
+                max_stats = max(max_stats, rows * op.K * 2)
                 if op.trainable:
                     # dy of EVERY layer stays alive until the grouped weight-gradient launch at the end of its backward
                     # segment (3.2 GB at BATCH_SIZE 64: sized for 288 GB of HBM, not for reuse)
@@ -473,8 +476,7 @@ class Net:
                 op.bn_ws_off = ws_floats
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
-        self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)
-        self._bn_flag_idx = None
+        self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)    # workgroups that gave up on a grid barrier, ever
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
         self.m12 = torch.zeros(2 * 2048, dtype=torch.float32, device=dev)
@@ -524,6 +526,18 @@ class Net:
             if op.kind == "bn":
                 yv = View(op.y, op.out.N, op.out.H, op.out.W, op.K)
                 d = self._tune(op, self._desc(op, yv, stats=self.stats_scratch), "fwd")
+                S_ = ops.splitk_slices(d, self.n_cus) if torch.device(self.dev).type == "cuda" else 0
+                if S_:
+                    # long K, few tiles (the 3x3 head convolutions on the 1536-channel map): K slices + a reduce launch
+                    d.tile_config = ops.SPLITK_FLAG + S_
+                    need = int(l.mbx_conv_splitk_workspace_bytes(C.byref(d)))
+                    if getattr(self, "splitk_ws", None) is None or self.splitk_ws.numel() * 4 < need:
+                        self.splitk_ws = torch.empty(need // 4, dtype=torch.float32, device=self.dev)
+                        self._splitk_descs = getattr(self, "_splitk_descs", [])
+                    self._splitk_descs.append(d)
+                    for d_ in self._splitk_descs:          # (all of them share the one workspace: launches are stream-ordered)
+                        d_.splitk_ws, d_.splitk_ws_bytes = self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4
+                    _lib.check(l.mbx_conv_supported(C.byref(d)), "split-K " + op.name)
                 rows = ops.conv_stats_rows(d)
                 mean, rstd = self._sl(self.bn_mean, op.beta_off, op.K), self._sl(self.bn_rstd, op.beta_off, op.K)
                 mm, mv = self._sl(self.MM, op.beta_off, op.K), self._sl(self.MV, op.beta_off, op.K)
@@ -558,14 +572,11 @@ class Net:
                 L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
             elif op.kind == "head":
                 d = self._desc(op, op.out, epilogue=ops.EPI_STORE_F32)
-                cells, kk, off = op.head
-
-                def run(d=d, op=op, cells=cells, kk=kk, off=off):
-                    s = st()
-                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
-                    _lib.check(l.mbx_head_gather(op.out.buf.data_ptr(), self.head_ld, self.B, cells, kk, self.P, off,
-                                                 self.locs.data_ptr(), self.logits.data_ptr(), s), "head_gather")
-                L.append(run)
+                L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
+                if op is self.heads[-1]:
+                    # every head's [M_g, head_ld] float32 output -> locations / logits in prior order (model.py:296-319): ONE launch
+                    L.append(lambda: _lib.check(l.mbx_head_gather_all(self.head_table, len(self.heads), self.B, self.P,
+                                                                      self.locs.data_ptr(), self.logits.data_ptr(), st()), "head_gather_all"))
         return L
 
     # ------------------------------------------------------------------- backward
@@ -586,7 +597,23 @@ class Net:
         src = self.pending_acc.pop(key, None)
         return (1, src) if src is not None else (0, None)
 
+    def _make_head_table(self):
+        """mbx_head table of the detection heads (HOST array, read at launch time)."""
+        arr = (_lib.Head * len(self.heads))()
+        for j, op in enumerate(self.heads):
+            cells, kk, off = op.head
+            op.head_grad = None
+            if self.mode == "train":
+                op.head_grad = View(torch.zeros((op.M, self.head_ld), dtype=torch.bfloat16, device=self.dev),
+                                    op.out.N, op.out.H, op.out.W, self.head_ld)
+                self._bufs.append(op.head_grad.buf)
+            arr[j].h, arr[j].ld_h = op.out.buf.data_ptr(), self.head_ld
+            arr[j].g, arr[j].ld_g = (op.head_grad.buf.data_ptr() if op.head_grad is not None else None), self.head_ld
+            arr[j].cells, arr[j].k, arr[j].off = cells, kk, off
+        self.head_table = arr
+
     def _build_backward(self):
+        self._make_head_table()
         if self.mode != "train":
             self.fwd_launches = self._build_forward_launches()
             self.bwd_launches = []
@@ -645,12 +672,12 @@ class Net:
             dw = self._sl(self.Wg, op.w_off, K * op.R * op.S * op.Cin)
             if op.kind == "head":
                 cells, kk, off = op.head
-                g = View(torch.zeros((M, self.head_ld), dtype=torch.bfloat16, device=self.dev), op.out.N, op.out.H, op.out.W, self.head_ld)
-                self._bufs.append(g.buf)
+                g = op.head_grad                    # bf16 [M_g, head_ld], filled by the one scatter launch for all heads
                 dyv, scale, db = g, 1.0, None
-                pre = lambda s, g=g, cells=cells, kk=kk, off=off: _lib.check(
-                    l.mbx_head_scatter(self.d_locs.data_ptr(), self.d_logits.data_ptr(), self.B, cells, kk, self.P, off,
-                                       g.buf.data_ptr(), self.head_ld, s), "head_scatter")
+                pre = None
+                if op is self.heads[-1]:            # (first in backward order)
+                    pre = lambda s: _lib.check(l.mbx_head_scatter_all(self.d_locs.data_ptr(), self.d_logits.data_ptr(), self.head_table,
+                                                                      len(self.heads), self.B, self.P, s), "head_scatter_all")
             elif op.kind == "residual":
                 gout = self._gview(op.out)          # G[i]: complete (and relu-masked) when this op's backward runs
                 gs = self._gview(op.skip)           # G[i-1] lives in its own buffer: first writer adds G[i] (acc_src)
@@ -826,30 +853,21 @@ class Net:
             total += f * (3.0 if (train and op.trainable) else 1.0)
         return total
 
-    def _timeout_flags(self):
-        """Device tensor of the per-layer grid-barrier timeout flags of the LAST backward pass (or None)."""
-        if self.mode != "train":
-            return None                    # (not `or self.no_onepass`: after a fall-back the last one-launch step's flags still count)
-        if self._bn_flag_idx is None:
-            idx = [op.bn_ws_off + 4 * 2 * op.K + 1 for op in self.convs if getattr(op, "bn_ws_off", -1) >= 0]
-            self._bn_flag_idx = torch.tensor(idx, device=self.bn_ws.device) if idx else False
-        if self._bn_flag_idx is False:
-            return None
-        return self.bn_ws.view(torch.int32)[self._bn_flag_idx]
-
     def barrier_timeouts(self):
-        """Number of one-launch BN-backward launches whose grid barrier gave up (their workgroups were not all resident)
-        SINCE THE NET WAS BUILT: the per-step flags are folded into a running total before the workspace is cleared, so a
-        timeout between two health checks is not lost.  0 in a healthy run.  Host sync."""
-        f = self._timeout_flags()
-        return int(self.bn_timeouts_total) + (int((f != 0).sum()) if f is not None else 0)
+        """Workgroups of one-launch BN-backward launches that gave up on their grid barrier (the grid was not resident)
+        SINCE THE NET WAS BUILT: word [0] of the step control block (every such workgroup adds 1; data-parallel runs sum it
+        over ranks with the gradients) is folded into a running total before it is cleared at the start of the next
+        backward pass, so a timeout between two health checks is not lost.  0 in a healthy run.  Host sync."""
+        if self.mode != "train":
+            return 0
+        return int(self.bn_timeouts_total) + int(float(self.step_ctl[0]))
 
     def zero_grads(self):
-        f = self._timeout_flags()
-        if f is not None:
-            self.bn_timeouts_total += (f != 0).sum()            # (device-side: no sync)
-        self.G.zero_()              # Wg, Btg and the step control block
-        self.bn_ws.zero_()          # accumulators / arrival counters of the one-launch BN backward
+        """ONE launch (mbx_step_begin): Wg, Btg, the step control block and the accumulators / arrival counters of the
+        one-launch BN backward cleared; the control word's time-out count kept in bn_timeouts_total first."""
+        _lib.check(_lib.lib().mbx_step_begin(self.G.data_ptr(), self.G.numel(), self.bn_ws.data_ptr(), self.bn_ws.numel(),
+                                             self.nBt, self.bn_timeouts_total.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "step_begin")
 
     def backward(self):
         """d_locs / d_logits must hold the loss gradients; fills Wg / Btg.  (Eager form: all data-gradient launches,

@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("acc_src", C.c_void_p), ("acc_img_stride", C.c_int64), ("ld_acc", C.c_int32),
         ("work_counter", C.c_void_p),
         ("max_workgroups", C.c_int32),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -149,6 +150,22 @@ I5_FLAG = 32                                   # tile_config 32 + t: persistent 
 I5_TILE_CONFIGS = (33, 34, 35, 36, 37)         # 128x64, 128x128, 192x128, 256x128, 256x64
 I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
 I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
+SPLITK_FLAG = 128                              # tile_config 128 + S: split-K in S slices (float32 partials + reduce launch)
+
+
+def splitk_slices(desc: ConvDesc, n_cus=256):
+    """Split-K slices for a forward convolution by rule (0: none): long K (>= 8192) and at most 96 tiles of 128 x 64, i.e.
+    less than half the CUs busy for hundreds of K steps -- the two 3x3 head convolutions on the 1536-channel feature map
+    at BATCH_SIZE 64 (80 us each at 89-135 TFLOP/s without it).  MBX_SPLITK=0 turns it off (A/B)."""
+    if os.environ.get("MBX_SPLITK", "1") == "0" or desc.transposed or desc.epilogue != EPI_STORE or desc.accumulate or desc.skip:
+        return 0
+    ktot = desc.R * desc.S * desc.C_in
+    M = desc.N * desc.H_out * desc.W_out
+    tiles = ((M + 127) // 128) * ((desc.C_out + 63) // 64)
+    if ktot < 8192 or tiles > 96:
+        return 0
+    s = int(os.environ.get("MBX_SPLITK_SLICES", "0")) or max(2, min(16, (2 * n_cus) // tiles))
+    return min(s, 32)
 _TUNED = {}          # repr(shape key) -> tile_config: one measurement per distinct conv in a process
 TUNE_STATS = {"hits": 0, "remeasured": 0, "rejected": 0}    # table entries used as they are / shapes measured here / entries refused
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")

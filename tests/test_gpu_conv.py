@@ -139,6 +139,60 @@ def test_conv_epilogues(T):
     assert ok, "accumulate: " + msg
 
 
+@pytest.mark.parametrize("g", [("sk1", 16, 8, 8, 1536, 96, 3, 3, 1, (1, 1, 1, 1)), ("sk2", 16, 8, 8, 1536, 256, 3, 3, 2, (0, 0, 1, 1)),
+                               ("sk3", 3, 9, 9, 200, 40, 3, 3, 1, (1, 1, 1, 1)), ("sk4", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3))],
+                         ids=["head_6x6", "head_s2", "ragged", "1x7"])
+@pytest.mark.parametrize("S", [2, 5, 16])
+def test_conv_split_k(T, g, S):
+    """tile_config 128 + S (round 4): K slices as float32 partial tiles + one reduce launch that rounds, stores and writes the
+    batch-norm statistics partials.  Against the float32 reference at the stated 1-bf16-ulp tolerance (the float32 sum is
+    grouped differently from the one-pass kernels: NOT bit-identical to them, by design), statistics = sums of the STORED
+    values, neighbours of the output slice untouched, a second launch bit-identical (fixed slice order: deterministic)."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S_, st, pads = g
+    x, w = make_case(torch, g, seed=7)
+    Ho, Wo = out_hw(H, W, R, S_, st, pads)
+    ref = ref_conv(torch, x, w, st, pads)
+    xb = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    outs = []
+    for rep in range(2):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S_, st, pads[0], pads[1], yb)
+        d.tile_config = ops.SPLITK_FLAG + S
+        rows = ops.conv_stats_rows(d)
+        assert rows == (N * Ho * Wo + 15) // 16
+        stats = torch.full((rows, Co, 2), float("nan"), dtype=torch.float32, device="cuda")
+        d = ops.make_desc(xb, wd, Co, R, S_, st, pads[0], pads[1], yb, stats=stats)
+        d.tile_config = ops.SPLITK_FLAG + S
+        assert l.mbx_conv(C.byref(d), torch.cuda.current_stream().cuda_stream) == -4          # no workspace: MBX_ERR_WORKSPACE
+        need = int(l.mbx_conv_splitk_workspace_bytes(C.byref(d)))
+        assert need > 0
+        ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device="cuda")
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), need
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        out = yb.tensor()
+        ok, msg = close(torch, out, ref)
+        assert ok, msg
+        full = yb.buf.reshape(N, Ho, Wo, Co + 24)
+        assert float(full[..., :16].abs().max()) == 0 and float(full[..., 16 + Co:].abs().max()) == 0
+        st_sum = stats.sum(0).cpu()
+        o32 = out.float().cpu().reshape(-1, Co)
+        assert torch.allclose(st_sum[:, 0], o32.sum(0), rtol=1e-4, atol=1e-3 * float(o32.abs().sum(0).max()))
+        assert torch.allclose(st_sum[:, 1], (o32 * o32).sum(0), rtol=1e-4)
+        outs.append((out.clone(), stats.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # what it does not apply to is refused: data gradients, residual / accumulate epilogues
+    d.transposed = 1
+    assert l.mbx_conv_supported(C.byref(d)) == -2
+
+
 @pytest.mark.parametrize("g", [("e1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("e7", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
                                ("e3", 2, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1)),
                                # more tiles than CUs (308 of 128x64, 2.4 per workgroup of 128x128 ...): the queue really hands tiles out

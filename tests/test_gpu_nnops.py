@@ -265,6 +265,42 @@ def test_glue_kernels(T):
     assert torch.equal(gb[:, :4 * k], bfr(torch, dl[:, off:off + cells * k].reshape(N * cells, 4 * k)))
     assert torch.equal(gb[:, 4 * k:5 * k], bfr(torch, dz[:, off:off + cells * k].reshape(N * cells, k)))
     assert float(gb[:, 5 * k:].abs().max()) == 0
+    # every head in ONE launch (mbx_head_gather_all / mbx_head_scatter_all) = the per-head calls, bit for bit:
+    # the six heads of the 299x299 / k = 5 network (grids 8, 6, 4, 3, 2 with k boxes per cell, 1 with one: P = 646)
+    import ctypes as C
+    N, P, ld = 3, 646, 32
+    grids = [(8, 5), (6, 5), (4, 5), (3, 5), (2, 5), (1, 1)]
+    heads = (_lib.Head * len(grids))()
+    hs, gs, keep, off = [], [], [], 0
+    for j, (g_, k) in enumerate(grids):
+        hj = torch.randn(N * g_ * g_, ld, generator=gen).cuda()
+        gj = torch.ones((N * g_ * g_, ld), dtype=torch.bfloat16, device="cuda")
+        hs.append(hj); gs.append(gj)
+        heads[j].h, heads[j].ld_h, heads[j].g, heads[j].ld_g = hj.data_ptr(), ld, gj.data_ptr(), ld
+        heads[j].cells, heads[j].k, heads[j].off = g_ * g_, k, off
+        off += g_ * g_ * k
+    assert off == P
+    la, za = torch.zeros((N, P, 4), device="cuda"), torch.zeros((N, P), device="cuda")
+    lb, zb = torch.zeros((N, P, 4), device="cuda"), torch.zeros((N, P), device="cuda")
+    _lib.check(l.mbx_head_gather_all(heads, len(grids), N, P, la.data_ptr(), za.data_ptr(), S()))
+    for j, (g_, k) in enumerate(grids):
+        _lib.check(l.mbx_head_gather(hs[j].data_ptr(), ld, N, g_ * g_, k, P, heads[j].off, lb.data_ptr(), zb.data_ptr(), S()))
+    assert torch.equal(la, lb) and torch.equal(za, zb) and float(la.abs().min()) > 0
+    dl, dz = torch.randn(N, P, 4, generator=gen).cuda(), torch.randn(N, P, generator=gen).cuda()
+    _lib.check(l.mbx_head_scatter_all(dl.data_ptr(), dz.data_ptr(), heads, len(grids), N, P, S()))
+    for j, (g_, k) in enumerate(grids):
+        ref = torch.ones((N * g_ * g_, ld), dtype=torch.bfloat16, device="cuda")
+        _lib.check(l.mbx_head_scatter(dl.data_ptr(), dz.data_ptr(), N, g_ * g_, k, P, heads[j].off, ref.data_ptr(), ld, S()))
+        assert torch.equal(gs[j], ref), j
+    # mbx_step_begin: both buffers cleared, the control word's count folded into the running total first
+    G = torch.randn(4096 + 64, generator=gen).cuda()
+    ws = torch.randn(1024, generator=gen).cuda()
+    tot = torch.full((), 5, dtype=torch.int64, device="cuda")
+    G[136] = 7.0
+    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), S()))
+    assert float(G.abs().max()) == 0 and float(ws.abs().max()) == 0 and int(tot) == 12
+    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), S()))
+    assert int(tot) == 12
 
 
 def test_filter_prepare(T):
