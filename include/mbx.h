@@ -286,6 +286,21 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
  * the train op, which the reference's py_func error aborts as a whole, loss.py:82).                                  */
 int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* batch_mean, const float* batch_var,
                          int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps, mbx_stream_t stream);
+/* BATCH-NORM GROUPS.  Sibling convolutions (same pixels, independent inputs: the two 3x3 branches of a block35,
+ * model.py:11-17; the stride-2 branches of Mixed_7a, model.py:166-178) are normalised by ONE set of launches: their
+ * pre-BN outputs are channel slices of one contiguous [M, C] tensor (each convolution writes its slice: ldy = C), beta /
+ * mean / rstd / moving statistics are contiguous in member order, and the activation / gradient VIEW places the members'
+ * channels wherever the concat layout wants them: channel c of the [M, C] tensor is channel c + offset[i] of the view,
+ * i = the last entry with c_begin[i] <= c.  c_begin ascending from 0, everything a multiple of 8, offsets >= 0 (the
+ * view pointer is that of the lowest member).  map = NULL: the identity.  A kernel costs >= 4.4 us in the replayed
+ * step whatever it does; a group of two saves a finalize, an apply and a backward launch per step and block.          */
+typedef struct { int32_t n; int32_t c_begin[4]; int32_t offset[4]; } mbx_chan_map;
+/* mbx_bn_finalize over up to 4 members: member p's convolution wrote parts[p] = [rows[p]][Cs[p]][2]. */
+int mbx_bn_finalize_parts(const float* const* parts /*HOST array of DEVICE pointers*/, const int32_t* rows /*HOST*/,
+                          const int32_t* Cs /*HOST*/, int n_parts, int64_t count, float eps, float decay, float* mean,
+                          float* rstd, float* moving_mean, float* moving_var, mbx_stream_t stream);
+int mbx_bn_apply_mapped(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
+                        int relu, void* a, int ld_a, const mbx_chan_map* a_map /*HOST*/, mbx_stream_t stream);
 /* Frozen BN folded into the conv epilogue (detect.py:313-326, train.py:124-131):
  * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
 int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,
@@ -306,6 +321,14 @@ int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int rel
                      int64_t M, int C, const float* mean, const float* rstd, const float* beta,
                      const float* m12, void* dy /*bf16 [M,C]*/, mbx_stream_t stream);
 
+/* ... with the gradient view `da` addressed through a group's channel map (a must be NULL: mask from y) */
+int mbx_bn_bwd_reduce_mapped(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
+                             const float* mean, const float* rstd, const float* beta, float* partial,
+                             const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
+int mbx_bn_bwd_apply_mapped(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
+                            const float* mean, const float* rstd, const float* beta, const float* m12, void* dy,
+                            const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
+
 /* The same backward pass in ONE launch (relu mask recomputed from y): every workgroup keeps its slice of
  * (da, y) in registers across a grid barrier, so da and y are read once.  Available when the layer fits
  * one resident workgroup per CU (mbx_bn_bwd_onepass_supported; everything but the 5 stem layers at
@@ -324,6 +347,10 @@ int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64
                        const float* mean, const float* rstd, const float* beta, float* dbeta /*[C] +=*/,
                        void* dy /*bf16 [M,C]*/, void* ws, int max_workgroups, float* step_poison /*or NULL*/,
                        mbx_stream_t stream);
+
+int mbx_bn_bwd_onepass_mapped(const void* da, int ld_da, int relu, const void* y, int64_t M, int C, const float* mean,
+                              const float* rstd, const float* beta, float* dbeta, void* dy, void* ws, int max_workgroups,
+                              float* step_poison, const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
 
 /* ---------------------------------------------------------------------- pooling (K9)
  * NHWC bf16 views.  max: k x k, stride, VALID (model.py:103,115,157,180); argmax (uint8 tap

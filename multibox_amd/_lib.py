@@ -55,6 +55,11 @@ _SIGS = {
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
     "mbx_bn_moving_update": (I, [P, P, P, P, C.c_int64, F, P, P, P]),
+    "mbx_bn_finalize_parts": (I, [P, P, P, I, C.c_int64, F, F, P, P, P, P, P]),
+    "mbx_bn_apply_mapped": (I, [P, C.c_int64, I, P, P, P, I, P, I, P, P]),
+    "mbx_bn_bwd_reduce_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),
+    "mbx_bn_bwd_apply_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P, P]),
+    "mbx_bn_bwd_onepass_mapped": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P, P, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
@@ -85,6 +90,11 @@ _lib = None
 
 class MbxError(RuntimeError):
     pass
+
+
+class ChanMap(C.Structure):
+    """mbx_chan_map (include/mbx.h)."""
+    _fields_ = [("n", C.c_int32), ("c_begin", C.c_int32 * 4), ("offset", C.c_int32 * 4)]
 
 
 class Head(C.Structure):

@@ -3,6 +3,7 @@
 // accesses per lane along the NHWC channel axis, grid-stride loops capped at 2048 blocks.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -24,6 +25,18 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 }
 __device__ __forceinline__ u32x4 ld8(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st8(unsigned short* p, const u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// Channel map of a batch-norm GROUP (several sibling convolutions normalised by one set of launches): channel c of the
+// group's contiguous [M, C] tensors (y, dy) lives at channel c + off[i] of the strided activation / gradient view, where
+// i is the last entry with cb[i] <= c (n = 0: the identity).  Lane-constant wherever a lane owns a channel group.
+struct ChanMap { int n; int cb[4]; int off[4]; };
+__device__ __forceinline__ int chan_off(const ChanMap& m, int c) {
+  int o = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < m.n && c >= m.cb[i]) o = m.off[i];
+  return o;
+}
+inline int chan_map_max(const ChanMap& m) { int o = 0; for (int i = 0; i < m.n; ++i) if (m.off[i] > o) o = m.off[i]; return o; }
 
 inline int grid_for(long long work_items) {
   long long b = (work_items + kT - 1) / kT;
@@ -71,6 +84,39 @@ bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double inv_c
   }
 }
 
+// the same for a GROUP: channel c belongs to part p (cstart[p] <= c < cstart[p + 1]), whose convolution wrote its own
+// partial rows [rows[p]][C[p]][2]; mean / rstd / moving statistics are the group's contiguous arrays
+struct PartTable { const float* part[4]; int rows[4], C[4], cstart[5]; int n; };
+__global__ void __launch_bounds__(kT)
+bn_finalize_parts_kernel(const PartTable t, double inv_count, float eps, float decay, float* __restrict__ mean,
+                         float* __restrict__ rstd, float* __restrict__ mmean, float* __restrict__ mvar) {
+  const int c = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < t.n && c >= t.cstart[pi + 1]) ++pi;
+  const float* part = t.part[pi];
+  const int rows = t.rows[pi], C = t.C[pi], cl = c - t.cstart[pi];
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += kT) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + cl) * 2);
+    s1 += v.x; s2 += v.y;
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    const double m = s1 * inv_count;
+    double var = s2 * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (decay < 0.f) {
+      if (mmean) mmean[c] = (float)m;
+      if (mvar) mvar[c] = (float)var;
+    } else {
+      if (mmean) mmean[c] -= (1.0f - decay) * (mmean[c] - (float)m);
+      if (mvar) mvar[c] -= (1.0f - decay) * (mvar[c] - (float)var);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kT)
 bn_fold_kernel(const float* mm, const float* mv, const float* beta, float eps, int C, float* scale, float* shift) {
   const int c = blockIdx.x * kT + threadIdx.x;
@@ -87,13 +133,14 @@ bn_fold_kernel(const float* mm, const float* mv, const float* beta, float eps, i
 __global__ void __launch_bounds__(kT)
 bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ mean,
                 const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
-                unsigned short* __restrict__ a, int ld_a) {
+                unsigned short* __restrict__ a, int ld_a, const ChanMap map) {
   const int C8 = C >> 3;
   if (C8 <= kT) {
     const int rpi = kT / C8;                              // rows per sweep of the workgroup
     const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
     if (rr >= rpi) return;
     const int c = vc << 3;
+    a += chan_off(map, c);                                // (lane-constant: the lane owns this channel group)
     float mu[8], rs[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; be[j] = beta[c + j]; }
@@ -121,7 +168,7 @@ bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const 
       float v = (f[j] - mean[c + j]) * rstd[c + j] + beta[c + j];
       f[j] = relu ? fmaxf(v, 0.f) : v;
     }
-    st8(a + m * ld_a + c, pack8(f));
+    st8(a + m * ld_a + c + chan_off(map, c), pack8(f));
   }
 }
 
@@ -147,12 +194,13 @@ __global__ void __launch_bounds__(kT)
 bn_bwd_reduce_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
                      const unsigned short* __restrict__ y, long long M, int C,
                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
-                     int rpi, int rpb, float* __restrict__ partial) {
+                     int rpi, int rpb, float* __restrict__ partial, const ChanMap map) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16]
   const int C8 = C >> 3;
   const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
   const bool active = rr < rpi;
   const int c = vc << 3;
+  da += chan_off(map, c);                                 // (lane-constant)
   float s1[8], s2[8], mu[8], rs[8], be[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -219,14 +267,14 @@ __global__ void __launch_bounds__(kT)
 bn_bwd_apply_kernel(const unsigned short* __restrict__ da, int ld_da, const unsigned short* __restrict__ a, int ld_a,
                     const unsigned short* __restrict__ y, long long M, int C,
                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
-                    const float* __restrict__ m12, unsigned short* __restrict__ dy) {
+                    const float* __restrict__ m12, unsigned short* __restrict__ dy, const ChanMap map) {
   const int C8 = C >> 3;
   const long long total = M * C8;
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
     const long long m = i / C8;
     const int c = (int)(i - m * C8) << 3;
     float g[8], yy[8], aa[8], o[8];
-    unpack8(ld8(da + m * ld_da + c), g);
+    unpack8(ld8(da + m * ld_da + c + chan_off(map, c)), g);
     unpack8(ld8(y + m * C + c), yy);
     if (MASK == 1) unpack8(ld8(a + m * ld_a + c), aa);
 #pragma unroll
@@ -386,7 +434,7 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
                       long long M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ beta, float* __restrict__ dbeta, unsigned short* __restrict__ dy,
                       float* __restrict__ ws, int rpi, int rpb, float inv_M, unsigned spin_limit, int fault,
-                      float* __restrict__ step_poison) {
+                      float* __restrict__ step_poison, const ChanMap map, int map_max) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16] partial sums, then [2C] totals
   __shared__ int s_timeout;                                      // this workgroup gave up on the grid barrier
   const int C8 = C >> 3;
@@ -398,7 +446,8 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
   const int nrows = nr > 0 ? (int)nr : 0;
   // slice-relative buffer descriptors: 32-bit offsets, rows past the slice read zeros / are not stored
   // (an empty slice gets zero-length descriptors: nothing is ever addressed through them)
-  const __amdgpu_buffer_rsrc_t gr = ob_rsrc(da + r0 * ld_da, nrows ? (unsigned)(((nrows - 1) * ld_da + C) * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t gr = ob_rsrc(da + r0 * ld_da, nrows ? (unsigned)(((nrows - 1) * ld_da + C + map_max) * 2) : 0u);
+  const int cg = c + chan_off(map, c);                                         // this lane's channels in the gradient view
   const __amdgpu_buffer_rsrc_t yr = ob_rsrc(y + r0 * C, (unsigned)(nrows * C * 2));
   const __amdgpu_buffer_rsrc_t dr = ob_rsrc(dy + r0 * C, (unsigned)(nrows * C * 2));
   constexpr unsigned kPast = 0x80000000u;
@@ -407,7 +456,7 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
   for (int i = 0; i < NV; ++i) {
     const int lr = rr + i * rpi;
     const bool ok = active && lr < nrows;
-    vg[i] = ob_load16(gr, ok ? (unsigned)((lr * ld_da + c) * 2) : kPast);   // zero gradient adds nothing to the sums
+    vg[i] = ob_load16(gr, ok ? (unsigned)((lr * ld_da + cg) * 2) : kPast);  // zero gradient adds nothing to the sums
     vy[i] = ob_load16(yr, ok ? (unsigned)((lr * C + c) * 2) : kPast);
   }
   float s1[8], s2[8], mu[8], rs[8], be[8];
@@ -1025,13 +1074,57 @@ extern "C" int mbx_bn_fold(const float* mm, const float* mv, const float* beta, 
   return MBX_OK;
 }
 
-extern "C" int mbx_bn_apply(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
-                            int relu, void* a, int ld_a, mbx_stream_t stream) {
+// mbx_chan_map (HOST) -> the kernels' by-value ChanMap; NULL = identity.  Entries: ascending c_begin starting at 0,
+// multiples of 8, offsets >= 0 and multiples of 8 (16-byte accesses).
+static int to_chan_map(const mbx_chan_map* m, int C, ChanMap& out) {
+  memset(&out, 0, sizeof(out));
+  if (!m) return MBX_OK;
+  if (m->n < 0 || m->n > 4) return MBX_ERR_INVALID_ARG;
+  for (int i = 0; i < m->n; ++i) {
+    if (m->c_begin[i] % 8 || m->offset[i] % 8 || m->offset[i] < 0 || m->c_begin[i] >= C ||
+        (i == 0 ? m->c_begin[0] != 0 : m->c_begin[i] <= m->c_begin[i - 1]))
+      return MBX_ERR_INVALID_ARG;
+    out.cb[i] = m->c_begin[i]; out.off[i] = m->offset[i];
+  }
+  out.n = m->n;
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_apply_mapped(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
+                                   int relu, void* a, int ld_a, const mbx_chan_map* map, mbx_stream_t stream) {
   if (!y || !a || !mean || !rstd || !beta || M <= 0 || C <= 0 || C % 8 || ld_a % 8 || !al16(y) || !al16(a))
     return MBX_ERR_INVALID_ARG;
+  ChanMap cm;
+  if (to_chan_map(map, C, cm) != MBX_OK) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)y, (long long)M, C,
-                     mean, rstd, beta, relu, (us)a, ld_a);
+                     mean, rstd, beta, relu, (us)a, ld_a, cm);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_apply(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
+                            int relu, void* a, int ld_a, mbx_stream_t stream) {
+  return mbx_bn_apply_mapped(y, M, C, mean, rstd, beta, relu, a, ld_a, nullptr, stream);
+}
+
+extern "C" int mbx_bn_finalize_parts(const float* const* parts, const int32_t* rows, const int32_t* Cs, int n_parts,
+                                     int64_t count, float eps, float decay, float* mean, float* rstd, float* mmean,
+                                     float* mvar, mbx_stream_t stream) {
+  if (!parts || !rows || !Cs || n_parts <= 0 || n_parts > 4 || !mean || !rstd || count <= 0) return MBX_ERR_INVALID_ARG;
+  PartTable t;
+  memset(&t, 0, sizeof(t));
+  int c = 0;
+  for (int i = 0; i < n_parts; ++i) {
+    if (!parts[i] || rows[i] <= 0 || Cs[i] <= 0) return MBX_ERR_INVALID_ARG;
+    t.part[i] = parts[i]; t.rows[i] = rows[i]; t.C[i] = Cs[i]; t.cstart[i] = c;
+    c += Cs[i];
+  }
+  for (int i = n_parts; i <= 4; ++i) t.cstart[i] = c;
+  t.n = n_parts;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(c), dim3(kT), 0, mbx_s(stream), t, 1.0 / (double)count, eps, decay, mean,
+                     rstd, mmean, mvar);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -1052,14 +1145,22 @@ static int bn_bwd_args_ok(const void* da, int ld_da, const void* a, int ld_a, in
 extern "C" int mbx_bn_bwd_reduce(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
                                  int C, const float* mean, const float* rstd, const float* beta, float* partial,
                                  mbx_stream_t stream) {
+  return mbx_bn_bwd_reduce_mapped(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta, partial, nullptr, stream);
+}
+
+extern "C" int mbx_bn_bwd_reduce_mapped(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
+                                        int C, const float* mean, const float* rstd, const float* beta, float* partial,
+                                        const mbx_chan_map* da_map, mbx_stream_t stream) {
   if (!partial || !bn_bwd_args_ok(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta)) return MBX_ERR_INVALID_ARG;
   if (C > 2048) return MBX_ERR_UNSUPPORTED;
+  ChanMap cm;
+  if (to_chan_map(da_map, C, cm) != MBX_OK || (da_map && da_map->n && a)) return MBX_ERR_INVALID_ARG;
   const BnBwdGeom g = bn_bwd_geom(M, C);
   MBX_ENTER();
   const size_t lds = (size_t)g.rows_per_iter * g.C8 * 16 * sizeof(float);
 #define MBX_BN_RED(MASK)                                                                                              \
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<MASK>, dim3(g.rows), dim3(kT), lds, mbx_s(stream), (cus)da, ld_da, (cus)a, \
-                     ld_a, (cus)y, (long long)M, C, mean, rstd, beta, g.rows_per_iter, g.rpb, partial)
+                     ld_a, (cus)y, (long long)M, C, mean, rstd, beta, g.rows_per_iter, g.rpb, partial, cm)
   if (!relu) MBX_BN_RED(0); else if (a) MBX_BN_RED(1); else MBX_BN_RED(2);
 #undef MBX_BN_RED
   MBX_LAUNCH_CHECK();
@@ -1079,12 +1180,20 @@ extern "C" int mbx_bn_bwd_finalize(const float* partial, int rows, int C, int64_
 extern "C" int mbx_bn_bwd_apply(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
                                 int C, const float* mean, const float* rstd, const float* beta, const float* m12,
                                 void* dy, mbx_stream_t stream) {
+  return mbx_bn_bwd_apply_mapped(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta, m12, dy, nullptr, stream);
+}
+
+extern "C" int mbx_bn_bwd_apply_mapped(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M,
+                                       int C, const float* mean, const float* rstd, const float* beta, const float* m12,
+                                       void* dy, const mbx_chan_map* da_map, mbx_stream_t stream) {
   if (!m12 || !dy || !al16(dy) || !bn_bwd_args_ok(da, ld_da, a, ld_a, relu, y, M, C, mean, rstd, beta))
     return MBX_ERR_INVALID_ARG;
+  ChanMap cm;
+  if (to_chan_map(da_map, C, cm) != MBX_OK || (da_map && da_map->n && a)) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
 #define MBX_BN_APP(MASK)                                                                                            \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<MASK>, dim3(grid_for(M * (C / 8))), dim3(kT), 0, mbx_s(stream), (cus)da,   \
-                     ld_da, (cus)a, ld_a, (cus)y, (long long)M, C, mean, rstd, beta, m12, (us)dy)
+                     ld_da, (cus)a, ld_a, (cus)y, (long long)M, C, mean, rstd, beta, m12, (us)dy, cm)
   if (!relu) MBX_BN_APP(0); else if (a) MBX_BN_APP(1); else MBX_BN_APP(2);
 #undef MBX_BN_APP
   MBX_LAUNCH_CHECK();
@@ -1123,6 +1232,17 @@ extern "C" int mbx_bn_bwd_onepass_supported(int64_t M, int C, int max_workgroups
 extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64_t M, int C, const float* mean,
                                   const float* rstd, const float* beta, float* dbeta, void* dy, void* ws,
                                   int max_workgroups, float* step_poison, mbx_stream_t stream) {
+  return mbx_bn_bwd_onepass_mapped(da, ld_da, relu, y, M, C, mean, rstd, beta, dbeta, dy, ws, max_workgroups, step_poison,
+                                   nullptr, stream);
+}
+
+extern "C" int mbx_bn_bwd_onepass_mapped(const void* da, int ld_da, int relu, const void* y, int64_t M, int C,
+                                         const float* mean, const float* rstd, const float* beta, float* dbeta, void* dy,
+                                         void* ws, int max_workgroups, float* step_poison, const mbx_chan_map* da_map,
+                                         mbx_stream_t stream) {
+  ChanMap cm;
+  if (C <= 0 || to_chan_map(da_map, C, cm) != MBX_OK) return MBX_ERR_INVALID_ARG;
+  const int map_max = chan_map_max(cm);
   if (!da || !y || !mean || !rstd || (relu && !beta) || !dy || !ws || M <= 0 || C <= 0 || C % 8 || ld_da % 8 || !al16(da) ||
       !al16(y) || !al16(dy) || !al16(ws) || !al16(mean) || !al16(rstd) || (relu && !al16(beta)))
     return MBX_ERR_INVALID_ARG;
@@ -1138,7 +1258,7 @@ extern "C" int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const voi
 #define MBX_OB(NV, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_bwd_onepass_kernel<NV, RELU>), dim3(g.G), dim3(kObT), lds, mbx_s(stream), (cus)da, ld_da,      \
                      (cus)y, (long long)M, C, mean, rstd, beta, dbeta, (us)dy, (float*)ws, g.rpi, g.rpb,               \
-                     (float)(1.0 / (double)M), spin_limit, fault, step_poison)
+                     (float)(1.0 / (double)M), spin_limit, fault, step_poison, cm, map_max)
 #define MBX_OB_NV(NV) do { if (relu) MBX_OB(NV, true); else MBX_OB(NV, false); } while (0)
   if (g.nv <= 2) MBX_OB_NV(2);
   else if (g.nv <= 4) MBX_OB_NV(4);

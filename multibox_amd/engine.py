@@ -67,6 +67,32 @@ class ConvOp:
     w_off = b_off = beta_off = dw_off = -1
 
 
+class BnGroup:
+    """Sibling convolutions normalised by ONE finalize / apply / backward launch (mbx.h, BATCH-NORM GROUPS): their pre-BN
+    outputs (and gradients) are channel slices of one contiguous [M, K] tensor, member i at channels koff[i]."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        self.K = sum(m.K for m in members)
+        self.koff, k = [], 0
+        for m in members:
+            self.koff.append(k)
+            k += m.K
+        self.y = self.dy = None
+        self.rows = [0] * len(members)          # statistics partial rows of each member's convolution (tile height)
+        self.stats_off = [0] * len(members)     # float offsets of the members' partial rows in Net.stats_scratch
+
+    def chan_map(self, views):
+        """(base channel, mbx_chan_map) placing member i's channels at views[i].ch_off of the common buffer."""
+        rel = [v.ch_off - ko for v, ko in zip(views, self.koff)]
+        base = min(rel)
+        m = _lib.ChanMap()
+        m.n = len(self.members)
+        for i, (ko, r) in enumerate(zip(self.koff, rel)):
+            m.c_begin[i], m.offset[i] = ko, r - base
+        return base, m
+
+
 class Net:
     def __init__(self, batch, input_size=299, k=5, mode="train", fine_tune=False, device="cuda", seed=2,
                  bn_decay=0.9997, repeats=(10, 20, 9), bn_max_workgroups=0, wgrad_overlap_cus=None):
@@ -108,6 +134,7 @@ class Net:
         # timing probes of tools/whatif_probe.py (wrong results while set: work is REMOVED to bound what a restructuring could save)
         self._probe_skip_apply = self._probe_skip_bn_bwd = False
         self.convs, self.fwd, self.bwd = [], [], []
+        self._bn_group_requests, self.bn_groups = [], []
         self.grad_alias = {}       # id(activation buffer) -> gradient buffer
         self.written = set()       # gradient regions already written in the backward pass (build time)
         self.heads = []
@@ -159,6 +186,13 @@ class Net:
         self.fwd.append(op)
         return op
 
+    def group_bn(self, *members):
+        """Declare sibling convolutions (consecutive in forward order, same pixels, mutually independent inputs) a batch-
+        norm group.  Taken up only where it applies (training-mode BN on all of them, outputs in one buffer; _alloc_scratch);
+        MBX_BN_GROUPS=0 turns it off (A/B)."""
+        if os.environ.get("MBX_BN_GROUPS", "1") != "0" and len(members) >= 2:
+            self._bn_group_requests.append(members)
+
     def _build(self):
         B, S, k = self.B, self.S, self.k
         P = "InceptionResnetV2/"
@@ -188,8 +222,9 @@ class Net:
         z = self.alloc(s5, s5, 528)
         self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 48), (Q + "Branch_2/Conv2d_0a_1x1", 64), (Q + "Branch_0/Conv2d_1x1", 96)],
                   t5, z.slice(0, 208), 1, 1)
-        self.conv([(Q + "Branch_1/Conv2d_0b_5x5", 64)], z.slice(0, 48), z.slice(208, 64), 5, 5)
-        self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 96)], z.slice(48, 64), z.slice(432, 96), 3, 3)
+        ga = self.conv([(Q + "Branch_1/Conv2d_0b_5x5", 64)], z.slice(0, 48), z.slice(208, 64), 5, 5)
+        gb = self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 96)], z.slice(48, 64), z.slice(432, 96), 3, 3)
+        self.group_bn(ga, gb)
         self.conv([(Q + "Branch_2/Conv2d_0c_3x3", 96)], z.slice(432, 96), z.slice(272, 96), 3, 3)
         p5 = self.alloc(s5, s5, 192)
         self.pool("avg", t5, p5, 3, 1, pad=1, scope=Q + "Branch_3/AvgPool_0a_3x3")
@@ -209,8 +244,9 @@ class Net:
                 self.share_grad(z, zg)
             self.conv([(Q + "Branch_1/Conv2d_0a_1x1", 32), (Q + "Branch_2/Conv2d_0a_1x1", 32), (Q + "Branch_0/Conv2d_1x1", 32)],
                       net, z.slice(0, 96), 1, 1)
-            self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 32)], z.slice(0, 32), z.slice(96, 32), 3, 3)
-            self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 48)], z.slice(32, 32), z.slice(192, 48), 3, 3)
+            ga = self.conv([(Q + "Branch_1/Conv2d_0b_3x3", 32)], z.slice(0, 32), z.slice(96, 32), 3, 3)
+            gb = self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 48)], z.slice(32, 32), z.slice(192, 48), 3, 3)
+            self.group_bn(ga, gb)           # independent siblings (model.py:11-17): one finalize / apply / backward launch
             self.conv([(Q + "Branch_2/Conv2d_0c_3x3", 64)], z.slice(192, 48), z.slice(128, 64), 3, 3)
             out = self.alloc(s5, s5, 320)
             self.residual(Q + "Conv2d_1x1", z.slice(64, 128), net, out, 0.17, True, trunk0)
@@ -254,8 +290,9 @@ class Net:
         t7 = self.alloc(s6, s6, 1056)       # [t0 256 | t1 256 | t2 256 | t2b 288]
         self.conv([(Q + "Branch_0/Conv2d_0a_1x1", 256), (Q + "Branch_1/Conv2d_0a_1x1", 256), (Q + "Branch_2/Conv2d_0a_1x1", 256)],
                   net, t7.slice(0, 768), 1, 1)
-        self.conv([(Q + "Branch_0/Conv2d_1a_3x3", 384)], t7.slice(0, 256), o7.slice(0, 384), 3, 3, 2, "VALID")
-        self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 288)], t7.slice(256, 256), o7.slice(384, 288), 3, 3, 2, "VALID")
+        ga = self.conv([(Q + "Branch_0/Conv2d_1a_3x3", 384)], t7.slice(0, 256), o7.slice(0, 384), 3, 3, 2, "VALID")
+        gb = self.conv([(Q + "Branch_1/Conv2d_1a_3x3", 288)], t7.slice(256, 256), o7.slice(384, 288), 3, 3, 2, "VALID")
+        self.group_bn(ga, gb)
         self.conv([(Q + "Branch_2/Conv2d_0b_3x3", 288)], t7.slice(512, 256), t7.slice(768, 288), 3, 3)
         self.conv([(Q + "Branch_2/Conv2d_1a_3x3", 320)], t7.slice(768, 288), o7.slice(672, 320), 3, 3, 2, "VALID")
         self.pool("max", net, o7.slice(992, 1088), 3, 2, scope=Q + "Branch_3/MaxPool_1a_3x3")
@@ -453,28 +490,74 @@ class Net:
         max_y = max_stats = max_bwd = 0
         self.y_tmp = {}
         l = _lib.lib()
+        # batch-norm groups that apply: training-mode BN on every member, same pixels / relu / trainability, consecutive in
+        # forward order, outputs in ONE buffer, betas contiguous, the group small enough for the lane-owns-a-channel-group kernels
+        for op in self.convs:
+            op.group = None
+        for members in self._bn_group_requests:
+            idx = [self.fwd.index(m) for m in members]
+            ok = all(m.kind == "bn" and m.M == members[0].M and m.relu == members[0].relu and m.trainable == members[0].trainable and
+                     m.out.buf is members[0].out.buf and m.out.ld == members[0].out.ld and m.K % 8 == 0 for m in members)
+            ok = ok and idx == list(range(idx[0], idx[0] + len(idx))) and len(members) <= 4
+            ok = ok and all(b.beta_off == a.beta_off + a.K for a, b in zip(members, members[1:]))
+            g = BnGroup(members)
+            ok = ok and g.K <= 2048 and g.chan_map([m.out for m in members])[0] >= 0
+            if ok:
+                self.bn_groups.append(g)
+                for m in members:
+                    m.group = g
         for op in self.convs:
             if op.kind == "bn":
-                op.y = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)      # pre-BN output, kept for backward
-                self._bufs.append(op.y)
-                d = self._desc(op, View(op.y, op.out.N, op.out.H, op.out.W, op.K))
+                g = op.group
+                lead = g is None or op is g.members[0]
+                K_all = op.K if g is None else g.K
+                N_, H_, W_ = op.out.N, op.out.H, op.out.W
+                if lead:
+                    ybuf = torch.empty((op.M, K_all), dtype=torch.bfloat16, device=dev)      # pre-BN output, kept for backward
+                    self._bufs.append(ybuf)
+                    if g is not None:
+                        g.y = ybuf
+                else:
+                    ybuf = g.y
+                ko = 0 if g is None else g.koff[g.members.index(op)]
+                op.y_view = View(ybuf, N_, H_, W_, op.K, K_all, ko)
+                d = self._desc(op, op.y_view)
                 rows = max(ops.conv_stats_rows(d), (op.M + 63) // 64)                                   # any tile height
-                if ops.splitk_slices(d, self.n_cus):
+                if g is None and ops.splitk_slices(d, self.n_cus):
                     rows = max(rows, (op.M + 15) // 16)                                                   # split-K: a row per 16 pixels
-                max_stats = max(max_stats, rows * op.K * 2)
+                if g is None:
+                    op.stats_off = 0
+                    max_stats = max(max_stats, rows * op.K * 2)
+                else:
+                    i = g.members.index(op)
+                    g.stats_off[i] = 0 if i == 0 else g.stats_off[i - 1] + g._bound
+                    g._bound = rows * op.K * 2
+                    op.stats_off = g.stats_off[i]
+                    max_stats = max(max_stats, op.stats_off + g._bound)
                 if op.trainable:
                     # dy of EVERY layer stays alive until the grouped weight-gradient launch at the end of its backward
                     # segment (3.2 GB at BATCH_SIZE 64: sized for 288 GB of HBM, not for reuse)
-                    op.dy = torch.empty((op.M, op.K), dtype=torch.bfloat16, device=dev)
-                    self._bufs.append(op.dy)
-                    max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, op.K) * op.K * 2)
-        # one-launch BN backward: per-layer accumulators + arrival counter, zeroed with the gradients every step
+                    if lead:
+                        dybuf = torch.empty((op.M, K_all), dtype=torch.bfloat16, device=dev)
+                        self._bufs.append(dybuf)
+                        if g is not None:
+                            g.dy = dybuf
+                        max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, K_all) * K_all * 2)
+                    else:
+                        dybuf = g.dy
+                    op.dy_view = View(dybuf, N_, H_, W_, op.K, K_all, ko)
+        # one-launch BN backward: per-layer (per-group) accumulators + arrival counter, zeroed with the gradients every step
         ws_floats = 0
         for op in self.convs:
             op.bn_ws_off = -1
-            if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, op.K, self.chain_cap or self.bn_max_wg):
+            g = getattr(op, "group", None)
+            if g is not None and op is not g.members[0]:
+                op.bn_ws_off = g.members[0].bn_ws_off
+                continue
+            K_all = op.K if g is None else g.K
+            if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, K_all, self.chain_cap or self.bn_max_wg):
                 op.bn_ws_off = ws_floats
-                ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(op.K) // 4 + 7) // 8 * 8
+                ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(K_all) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
         self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)    # workgroups that gave up on a grid barrier, ever
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
@@ -523,8 +606,40 @@ class Net:
             if isinstance(op, PoolOp):
                 L.append(op.forward)
                 continue
-            if op.kind == "bn":
-                yv = View(op.y, op.out.N, op.out.H, op.out.W, op.K)
+            if op.kind == "bn" and op.group is not None:
+                # member of a batch-norm group: its convolution writes its channel slice of the group's [M, K] tensor and its
+                # own statistics partials; the LAST member's launch is followed by ONE finalize and ONE apply for the group
+                g = op.group
+                i = g.members.index(op)
+                d = self._tune(op, self._desc(op, op.y_view, stats=self.stats_scratch[op.stats_off:]), "fwd")
+                g.rows[i] = ops.conv_stats_rows(d)
+                assert g.rows[i] * op.K * 2 <= (g.stats_off[i + 1] - g.stats_off[i] if i + 1 < len(g.members) else 1 << 62)
+                if i + 1 < len(g.members):
+                    L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
+                    continue
+                lead, n = g.members[0], len(g.members)
+                parts = (C.c_void_p * n)(*[self.stats_scratch.data_ptr() + 4 * o for o in g.stats_off])
+                rows_a, cs_a = (C.c_int32 * n)(*g.rows), (C.c_int32 * n)(*[m.K for m in g.members])
+                base, amap = g.chan_map([m.out for m in g.members])
+                a_ptr = op.out.buf.data_ptr() + 2 * base
+                mean, rstd = self._sl(self.bn_mean, lead.beta_off, g.K), self._sl(self.bn_rstd, lead.beta_off, g.K)
+                mm, mv = self._sl(self.MM, lead.beta_off, g.K), self._sl(self.MV, lead.beta_off, g.K)
+                var, beta = self._sl(self.bn_var, lead.beta_off, g.K), self._sl(self.Bt, lead.beta_off, g.K)
+
+                def run(d=d, op=op, g=g, parts=parts, rows_a=rows_a, cs_a=cs_a, amap=amap, a_ptr=a_ptr, mean=mean, rstd=rstd,
+                        mm=mm, mv=mv, var=var, beta=beta, n=n):
+                    s = st()
+                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    decay = self.bn_decay
+                    if self.defer_moving:
+                        mm, mv, decay = None, var, -1.0
+                    _lib.check(l.mbx_bn_finalize_parts(parts, rows_a, cs_a, n, op.M, BN_EPS, decay, mean.data_ptr(), rstd.data_ptr(),
+                                                       ops._p(mm), ops._p(mv), s), "bn_finalize_parts")
+                    _lib.check(l.mbx_bn_apply_mapped(g.y.data_ptr(), op.M, g.K, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                                                     int(op.relu), a_ptr, op.out.ld, C.byref(amap), s), "bn_apply_mapped")
+                L.append(run)
+            elif op.kind == "bn":
+                yv = op.y_view
                 d = self._tune(op, self._desc(op, yv, stats=self.stats_scratch), "fwd")
                 S_ = ops.splitk_slices(d, self.n_cus) if torch.device(self.dev).type == "cuda" else 0
                 if S_:
@@ -558,7 +673,7 @@ class Net:
                                                      mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv), s), "fin")
                         return
                     _lib.check(l.mbx_bn_apply_fused(self.stats_scratch.data_ptr(), rows, op.M, BN_EPS, decay,
-                                                    op.y.data_ptr(), op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
+                                                    op.y_view.ptr, op.M, op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld,
                                                     mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv), s), "bn_apply_fused")
                 L.append(run)
             elif op.kind == "frozen":
@@ -691,34 +806,51 @@ class Net:
                 else:
                     pre = None
             else:   # bn
-                da = self._gview(op.out)
-                dyv = View(op.dy, op.out.N, op.out.H, op.out.W, K)
-                mean, rstd = self._sl(self.bn_mean, op.beta_off, K), self._sl(self.bn_rstd, op.beta_off, K)
-                dbeta = self._sl(self.Btg, op.beta_off, K)
-                rows = l.mbx_bn_bwd_rows(M, K)
+                dyv = op.dy_view
                 scale, db = 1.0, None
+                g = op.group
+                if g is not None and op is not g.members[-1]:
+                    pre = None                      # the group's ONE backward launch ran in front of its last member's data gradient
+                else:
+                    # (a group: the [M, K] tensors of all members, the gradient view addressed through the group's channel map)
+                    lead = op if g is None else g.members[0]
+                    Kb = K if g is None else g.K
+                    y_ptr, dy_ptr = (op.y_view.ptr, op.dy_view.ptr) if g is None else (g.y.data_ptr(), g.dy.data_ptr())
+                    if g is None:
+                        da, da_ptr, dmap = self._gview(op.out), self._gview(op.out).ptr, None
+                    else:
+                        gviews = [self._gview(m.out) for m in g.members]
+                        assert all(v.buf is gviews[0].buf and v.ld == gviews[0].ld for v in gviews)
+                        base, cm = g.chan_map(gviews)
+                        da, da_ptr, dmap = gviews[0], gviews[0].buf.data_ptr() + 2 * base, C.byref(cm)
+                        self._keep = getattr(self, "_keep", []) + [cm]
+                    mean, rstd = self._sl(self.bn_mean, lead.beta_off, Kb), self._sl(self.bn_rstd, lead.beta_off, Kb)
+                    dbeta = self._sl(self.Btg, lead.beta_off, Kb)
+                    rows = l.mbx_bn_bwd_rows(M, Kb)
+                    beta = self._sl(self.Bt, lead.beta_off, Kb)
+                    ws_off = lead.bn_ws_off
 
-                beta = self._sl(self.Bt, op.beta_off, K)
+                    def pre_onepass(s, op=op, da=da, da_ptr=da_ptr, dmap=dmap, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, Kb=Kb, M=M,
+                                    y_ptr=y_ptr, dy_ptr=dy_ptr, ws_off=ws_off):
+                        # da and y are read once: the slice stays in registers across a grid barrier
+                        _lib.check(l.mbx_bn_bwd_onepass_mapped(da_ptr, da.ld, int(op.relu), y_ptr, M, Kb, mean.data_ptr(),
+                                                               rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
+                                                               dy_ptr, self.bn_ws.data_ptr() + 4 * ws_off,
+                                                               self.cu_cap or self.bn_max_wg, self.step_ctl.data_ptr(), dmap, s),
+                                   "bn_bwd_onepass")
 
-                def pre_onepass(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, K=K, M=M):
-                    # da and y are read once: the slice stays in registers across a grid barrier
-                    _lib.check(l.mbx_bn_bwd_onepass(da.ptr, da.ld, int(op.relu), op.y.data_ptr(), M, K, mean.data_ptr(),
-                                                    rstd.data_ptr(), beta.data_ptr(), dbeta.data_ptr(),
-                                                    op.dy.data_ptr(), self.bn_ws.data_ptr() + 4 * op.bn_ws_off,
-                                                    self.cu_cap or self.bn_max_wg, self.step_ctl.data_ptr(), s),
-                               "bn_bwd_onepass")
-
-                def pre(s, op=op, da=da, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, K=K, M=M):
-                    # relu mask recomputed from y (a = NULL): the activation is not re-read in the backward pass
-                    _lib.check(l.mbx_bn_bwd_reduce(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
-                                                   mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                                                   self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce")
-                    _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, K, M, dbeta.data_ptr(),
-                                                     self.m12.data_ptr(), s), "bn_bwd_finalize")
-                    _lib.check(l.mbx_bn_bwd_apply(da.ptr, da.ld, None, 0, int(op.relu), op.y.data_ptr(), M, K,
-                                                  mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
-                                                  op.dy.data_ptr(), s), "bn_bwd_apply")
-                if op.bn_ws_off >= 0:
+                    def pre(s, op=op, da=da, da_ptr=da_ptr, dmap=dmap, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, Kb=Kb,
+                            M=M, y_ptr=y_ptr, dy_ptr=dy_ptr):
+                        # relu mask recomputed from y (a = NULL): the activation is not re-read in the backward pass
+                        _lib.check(l.mbx_bn_bwd_reduce_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
+                                                              mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                                                              self.bwd_scratch.data_ptr(), dmap, s), "bn_bwd_reduce")
+                        _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, Kb, M, dbeta.data_ptr(),
+                                                         self.m12.data_ptr(), s), "bn_bwd_finalize")
+                        _lib.check(l.mbx_bn_bwd_apply_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
+                                                             mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
+                                                             dy_ptr, dmap, s), "bn_bwd_apply")
+                if pre is not None and (op.bn_ws_off if g is None else g.members[0].bn_ws_off) >= 0:
                     # chosen at CALL time: Trainer.check_health() falls back to the three launches (and re-captures its
                     # graphs) when a grid barrier has timed out -- e.g. RCCL kernels holding more CUs than bn_max_wg allows for
                     def pre(s, one=pre_onepass, three=pre):

@@ -377,3 +377,94 @@ def test_rmsprop_ema_step(T):
     _lib.check(l.mbx_rmsprop_ema_step(dw.data_ptr(), dg.data_ptr(), dms.data_ptr(), None, dema.data_ptr(), wb.data_ptr(), n,
                                       lr, decay, 0.0, eps, wd, d, 1, reg.data_ptr(), skip.data_ptr(), S()))
     assert not torch.equal(dw, w0)
+
+
+@pytest.mark.parametrize("M,Ks,offs,relu", [(2 * 35 * 35, (32, 48), (96, 192), 1), (4096, (384, 288), (0, 384), 1),
+                                             (2450, (64, 96), (208, 432), 1), (777, (24, 8, 40), (64, 8, 128), 0)])
+def test_bn_group_entry_points(T, M, Ks, offs, relu):
+    """BATCH-NORM GROUPS (round 4, mbx.h): sibling layers normalised by ONE finalize / apply / backward launch over their
+    concatenated [M, sum K] tensors, the strided activation / gradient view addressed through an mbx_chan_map, against
+    the per-layer launches: finalize, apply and the three-launch backward bit-identical; the one-launch backward (fp32
+    atomics) within the tolerance of test_bn_backward_onepass; channels of the view outside the members untouched."""
+    torch = T
+    from multibox_amd import _lib, ops
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(M + sum(Ks))
+    Kt, n = sum(Ks), len(Ks)
+    koff = [sum(Ks[:i]) for i in range(n)]
+    ld = max(o + k for o, k in zip(offs, Ks)) + 16
+    y = (torch.randn(M, Kt, generator=gen) * 2 + 0.5).to(torch.bfloat16).cuda()
+    beta = (torch.randn(Kt, generator=gen) * 0.3).cuda()
+    rows = [3, 5, 2, 4][:n]
+    parts = [torch.rand(r, k, 2, generator=gen).cuda() * M for r, k in zip(rows, Ks)]
+    for p_, k, ko in zip(parts, Ks, koff):              # consistent sums: s2 >= s1^2 / M
+        yy = y[:, ko:ko + k].float()
+        p_[:, :, 0] = yy.sum(0) / p_.shape[0]
+        p_[:, :, 1] = (yy * yy).sum(0) / p_.shape[0]
+    rel = [o - ko for o, ko in zip(offs, koff)]
+    base = min(rel)
+    cm = _lib.ChanMap()
+    cm.n = n
+    for i in range(n):
+        cm.c_begin[i], cm.offset[i] = koff[i], rel[i] - base
+    # ---- forward: group finalize + apply vs per member
+    mean_g, rstd_g, mm_g, mv_g = (torch.zeros(Kt, device="cuda") for _ in range(4))
+    mv_g.fill_(1.0)
+    pa = (C.c_void_p * n)(*[p_.data_ptr() for p_ in parts])
+    _lib.check(l.mbx_bn_finalize_parts(pa, (C.c_int32 * n)(*rows), (C.c_int32 * n)(*Ks), n, M, 0.001, 0.9, mean_g.data_ptr(),
+                                       rstd_g.data_ptr(), mm_g.data_ptr(), mv_g.data_ptr(), S()))
+    a_g = torch.full((M, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_bn_apply_mapped(y.data_ptr(), M, Kt, mean_g.data_ptr(), rstd_g.data_ptr(), beta.data_ptr(), relu,
+                                     a_g.data_ptr() + 2 * base, ld, C.byref(cm), S()))
+    a_r = torch.full((M, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    mean_r, rstd_r, mm_r, mv_r = (torch.zeros(Kt, device="cuda") for _ in range(4))
+    mv_r.fill_(1.0)
+    for p_, r, k, ko, o in zip(parts, rows, Ks, koff, offs):
+        yk = y[:, ko:ko + k].contiguous()
+        _lib.check(l.mbx_bn_finalize(p_.data_ptr(), r, k, M, 0.001, 0.9, mean_r.data_ptr() + 4 * ko, rstd_r.data_ptr() + 4 * ko,
+                                     mm_r.data_ptr() + 4 * ko, mv_r.data_ptr() + 4 * ko, S()))
+        _lib.check(l.mbx_bn_apply(yk.data_ptr(), M, k, mean_r.data_ptr() + 4 * ko, rstd_r.data_ptr() + 4 * ko, beta.data_ptr() + 4 * ko,
+                                  relu, a_r.data_ptr() + 2 * o, ld, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(mean_g, mean_r) and torch.equal(rstd_g, rstd_r) and torch.equal(mm_g, mm_r) and torch.equal(mv_g, mv_r)
+    assert torch.equal(a_g, a_r)
+    assert float((a_g[:, :min(offs)].float() - 7.0).abs().max() if min(offs) else 0.0) == 0
+    # ---- backward: three launches (deterministic) and one launch, gradient view through the map
+    da = torch.zeros((M, ld), dtype=torch.bfloat16, device="cuda")
+    for k, o in zip(Ks, offs):
+        da[:, o:o + k] = torch.randn(M, k, generator=gen).to(torch.bfloat16).cuda()
+    rows_b = l.mbx_bn_bwd_rows(M, Kt)
+    partial = torch.zeros((rows_b, Kt, 2), device="cuda")
+    dbeta_g, m12 = torch.ones(Kt, device="cuda"), torch.zeros(2 * Kt, device="cuda")
+    dy_g = torch.zeros((M, Kt), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_bn_bwd_reduce_mapped(da.data_ptr() + 2 * base, ld, None, 0, relu, y.data_ptr(), M, Kt, mean_g.data_ptr(),
+                                          rstd_g.data_ptr(), beta.data_ptr(), partial.data_ptr(), C.byref(cm), S()))
+    _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows_b, Kt, M, dbeta_g.data_ptr(), m12.data_ptr(), S()))
+    _lib.check(l.mbx_bn_bwd_apply_mapped(da.data_ptr() + 2 * base, ld, None, 0, relu, y.data_ptr(), M, Kt, mean_g.data_ptr(),
+                                         rstd_g.data_ptr(), beta.data_ptr(), m12.data_ptr(), dy_g.data_ptr(), C.byref(cm), S()))
+    dy_r, dbeta_r = torch.zeros((M, Kt), dtype=torch.bfloat16, device="cuda"), torch.ones(Kt, device="cuda")
+    for k, ko, o in zip(Ks, koff, offs):
+        yk, dyk = y[:, ko:ko + k].contiguous(), torch.zeros((M, k), dtype=torch.bfloat16, device="cuda")
+        rk = l.mbx_bn_bwd_rows(M, k)
+        pk, m12k = torch.zeros((rk, k, 2), device="cuda"), torch.zeros(2 * k, device="cuda")
+        args = (da.data_ptr() + 2 * o, ld, None, 0, relu, yk.data_ptr(), M, k, mean_g.data_ptr() + 4 * ko, rstd_g.data_ptr() + 4 * ko,
+                beta.data_ptr() + 4 * ko)
+        _lib.check(l.mbx_bn_bwd_reduce(*args, pk.data_ptr(), S()))
+        _lib.check(l.mbx_bn_bwd_finalize(pk.data_ptr(), rk, k, M, dbeta_r.data_ptr() + 4 * ko, m12k.data_ptr(), S()))
+        _lib.check(l.mbx_bn_bwd_apply(*args, m12k.data_ptr(), dyk.data_ptr(), S()))
+        dy_r[:, ko:ko + k] = dyk
+    torch.cuda.synchronize()
+    # (the partial-row grouping of the reduce differs with the channel count: sums agree to float32 rounding, dy to 1 ulp)
+    assert torch.allclose(dbeta_g, dbeta_r, rtol=1e-4, atol=1e-3)
+    ok, msg = close_bf16(dy_g, dy_r)
+    assert ok, "group three-launch backward: " + msg
+    if l.mbx_bn_bwd_onepass_supported(M, Kt, 0):
+        ws = torch.zeros(l.mbx_bn_bwd_onepass_workspace_bytes(Kt) // 4, device="cuda")
+        dy_o, dbeta_o = torch.zeros((M, Kt), dtype=torch.bfloat16, device="cuda"), torch.ones(Kt, device="cuda")
+        _lib.check(l.mbx_bn_bwd_onepass_mapped(da.data_ptr() + 2 * base, ld, relu, y.data_ptr(), M, Kt, mean_g.data_ptr(), rstd_g.data_ptr(),
+                                               beta.data_ptr(), dbeta_o.data_ptr(), dy_o.data_ptr(), ws.data_ptr(), 0, None, C.byref(cm), S()))
+        torch.cuda.synchronize()
+        assert int(ws.view(torch.int32)[4 * 2 * Kt + 1]) == 0                       # no barrier time-out
+        assert torch.allclose(dbeta_o, dbeta_g, rtol=1e-4, atol=1e-3)
+        ok, msg = close_bf16(dy_o, dy_g)
+        assert ok, "group one-launch backward: " + msg
