@@ -283,9 +283,12 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
  * skip_ctl (DEVICE, two float32, may be NULL): the step control block of mbx_rmsprop_ema_step -- if either word is
  * non-zero the launch changes nothing except *skipped_steps += 1 (DEVICE uint64, may be NULL): a poisoned step or a
  * step after a stop request is skipped EVERYWHERE, moving statistics included (train.py:94-99 updates them as part of
- * the train op, which the reference's py_func error aborts as a whole, loss.py:82).                                  */
+ * the train op, which the reference's py_func error aborts as a whole, loss.py:82).
+ * ema_mean / ema_var (may be NULL): the ExponentialMovingAverage shadows of the two (train.py:253-259), updated from the
+ * NEW values in the same launch: ema -= (1-ema_decay)*(ema - moving) -- mbx_ema_update's expression.                  */
 int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* batch_mean, const float* batch_var,
-                         int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps, mbx_stream_t stream);
+                         int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps,
+                         float* ema_mean, float* ema_var, float ema_decay, mbx_stream_t stream);
 /* BATCH-NORM GROUPS.  Sibling convolutions (same pixels, independent inputs: the two 3x3 branches of a block35,
  * model.py:11-17; the stride-2 branches of Mixed_7a, model.py:166-178) are normalised by ONE set of launches: their
  * pre-BN outputs are channel slices of one contiguous [M, C] tensor (each convolution writes its slice: ldy = C), beta /
@@ -348,6 +351,19 @@ int mbx_bn_bwd_onepass(const void* da, int ld_da, int relu, const void* y, int64
                        void* dy /*bf16 [M,C]*/, void* ws, int max_workgroups, float* step_poison /*or NULL*/,
                        mbx_stream_t stream);
 
+/* Three-launch backward of a layer whose activation feeds ONLY a 3x3 / stride-2 VALID max-pool (the two stem pools,
+ * model.py:103,115: 177 MB and 124 MB tensors): the activation gradient is gathered from the pool's output gradient gy
+ * [N,Ho,Wo,C] and its argmax bytes on the fly (mbx_maxpool_bwd's arithmetic, rounded to bf16 as it would store it: the
+ * per-element values are those of mbx_maxpool_bwd; the statistics partials are grouped by 2 x 2 pixel blocks, so the
+ * sums agree with mbx_bn_bwd_reduce to float32 rounding), so the max-pool backward launch, the write of its result and
+ * the two reads of it disappear.  y / dy: [N*H*W, C] contiguous; relu mask from y; partial rows: mbx_bn_bwd_rows_pooled. */
+int mbx_bn_bwd_rows_pooled(int N, int H, int W, int C);
+int mbx_bn_bwd_reduce_pooled(const void* gy, int64_t gy_img_stride, int ld_gy, const uint8_t* argmax, int N, int H, int W,
+                             int Ho, int Wo, int relu, const void* y, int C, const float* mean, const float* rstd,
+                             const float* beta, float* partial /*[mbx_bn_bwd_rows_pooled(N,H,W,C), C, 2]*/, mbx_stream_t stream);
+int mbx_bn_bwd_apply_pooled(const void* gy, int64_t gy_img_stride, int ld_gy, const uint8_t* argmax, int N, int H, int W,
+                            int Ho, int Wo, int relu, const void* y, int C, const float* mean, const float* rstd,
+                            const float* beta, const float* m12, void* dy, mbx_stream_t stream);
 int mbx_bn_bwd_onepass_mapped(const void* da, int ld_da, int relu, const void* y, int64_t M, int C, const float* mean,
                               const float* rstd, const float* beta, float* dbeta, void* dy, void* ws, int max_workgroups,
                               float* step_poison, const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
@@ -399,9 +415,10 @@ int mbx_head_scatter_all(const float* d_locs, const float* d_logits, const mbx_h
 /* Start of a training step's backward pass in one launch: grads[0, n_grads) and bn_ws[0, n_ws) (float32 counts, multiples
  * of 4, 16-byte aligned buffers) are cleared; before grads[ctl_index] -- word [0] of the step control block, the grid-
  * barrier time-outs of the PREVIOUS step (mbx_bn_bwd_onepass step_poison, summed over ranks) -- is cleared, its value is
- * added to *timeouts_total (DEVICE uint64, may be NULL), so that a time-out between two host checks is not lost.        */
+ * added to *timeouts_total (DEVICE uint64, may be NULL), so that a time-out between two host checks is not lost.
+ * zero_scalar (float32, may be NULL) is cleared too: the reg_loss accumulator mbx_rmsprop_ema_step adds to.              */
 int mbx_step_begin(float* grads, int64_t n_grads, float* bn_ws, int64_t n_ws, int64_t ctl_index, uint64_t* timeouts_total,
-                   mbx_stream_t stream);
+                   float* zero_scalar, mbx_stream_t stream);
 
 /* ---------------------------------------------------------- parameters (A8, K16-K18)
  * Filters live as float32 masters in one flat buffer (KRSC each); the bf16 copies the

@@ -54,11 +54,14 @@ _SIGS = {
     "mbx_conv_wgrad_grouped_capped": (I, [P, P, I, P]),
     "mbx_bn_finalize": (I, [P, I, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply": (I, [P, C.c_int64, I, P, P, P, I, P, I, P]),
-    "mbx_bn_moving_update": (I, [P, P, P, P, C.c_int64, F, P, P, P]),
+    "mbx_bn_moving_update": (I, [P, P, P, P, C.c_int64, F, P, P, P, P, F, P]),
     "mbx_bn_finalize_parts": (I, [P, P, P, I, C.c_int64, F, F, P, P, P, P, P]),
     "mbx_bn_apply_mapped": (I, [P, C.c_int64, I, P, P, P, I, P, I, P, P]),
     "mbx_bn_bwd_reduce_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),
     "mbx_bn_bwd_apply_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P, P]),
+    "mbx_bn_bwd_rows_pooled": (I, [I, I, I, I]),
+    "mbx_bn_bwd_reduce_pooled": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, P, I, P, P, P, P, P]),
+    "mbx_bn_bwd_apply_pooled": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, P, I, P, P, P, P, P, P]),
     "mbx_bn_bwd_onepass_mapped": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P, P, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
@@ -79,7 +82,7 @@ _SIGS = {
     "mbx_head_scatter": (I, [P, P, I, I, I, I, I, P, I, P]),
     "mbx_head_gather_all": (I, [P, I, I, I, P, P, P]),
     "mbx_head_scatter_all": (I, [P, P, P, I, I, I, P]),
-    "mbx_step_begin": (I, [P, C.c_int64, P, C.c_int64, C.c_int64, P, P]),
+    "mbx_step_begin": (I, [P, C.c_int64, P, C.c_int64, C.c_int64, P, P, P]),
     "mbx_filter_prepare": (I, [P, P, P, I, I, P]),
     "mbx_rmsprop_ema_step": (I, [P, P, P, P, P, P, C.c_int64, F, F, F, F, F, F, I, P, P, P]),
     "mbx_ema_update": (I, [P, P, C.c_int64, F, P, P]),

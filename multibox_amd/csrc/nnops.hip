@@ -658,6 +658,150 @@ maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
   }
 }
 
+// Gradient of a 3x3 / stride-2 VALID max-pool's INPUT for the 2 x 2 pixel block (2a + dh, 2b + dw), channels c .. c+7,
+// gathered from the pool's output gradient and its argmax bytes -- for the batch-norm backward kernels that read it on the
+// fly instead of from a stored tensor (bn_bwd_*_pool_kernel).  The block's four pixels are covered by the same four windows
+// (oh in {a-1, a}, ow in {b-1, b}): 4 x 24 bytes of loads serve 4 pixels (the per-pixel gather of maxpool_bwd_kernel moves
+// 96 bytes per pixel through L2 and was what a first, per-pixel version of these kernels spent their time on).  Same
+// additions in the same order as maxpool_bwd_kernel<3, 2>, rounded to bf16 as it stores them: the same values.
+struct PoolSrc { const unsigned short* gy; long long gys; int ld_gy; const unsigned char* argmax; int H, W, Ho, Wo, C, Hb, Wb; };
+__device__ __forceinline__ void pool3s2_grad_block(const PoolSrc& p, int n, int a, int b, int c, float (&g)[4][8]) {
+  u32x4 gv[4];
+  u32x2 av[4];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                          // windows (a-1,b-1), (a-1,b), (a,b-1), (a,b)
+    const int oh = a - 1 + (i >> 1), ow = b - 1 + (i & 1);
+    const bool v = oh >= 0 && oh < p.Ho && ow >= 0 && ow < p.Wo;
+    ok[i] = v;
+    const long long o = ((long long)n * p.Ho + (v ? oh : 0)) * p.Wo + (v ? ow : 0);
+    av[i] = v ? *reinterpret_cast<const u32x2*>(p.argmax + o * p.C + c) : u32x2{0xffffffffu, 0xffffffffu};   // (no tap is 255)
+    gv[i] = v ? ld8(p.gy + n * p.gys + ((long long)oh * p.Wo + ow) * p.ld_gy + c) : u32x4{0u, 0u, 0u, 0u};
+  }
+  float w[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack8(gv[i], w[i]);
+  (void)ok;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = ((j < 4 ? av[i].x : av[i].y) >> (8 * (j & 3))) & 0xffu;
+    // pixel (dh, dw) <- window i with tap (2a + dh - 2 oh) * 3 + (2b + dw - 2 ow), windows in ascending (oh, ow) order
+    float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
+    if (t[0] == 8u) p00 += w[0][j];
+    if (t[1] == 6u) p00 += w[1][j];
+    if (t[2] == 2u) p00 += w[2][j];
+    if (t[3] == 0u) p00 += w[3][j];
+    if (t[1] == 7u) p01 += w[1][j];
+    if (t[3] == 1u) p01 += w[3][j];
+    if (t[2] == 5u) p10 += w[2][j];
+    if (t[3] == 3u) p10 += w[3][j];
+    if (t[3] == 4u) p11 += w[3][j];
+    g[0][j] = bf2f(f2bf(p00)); g[1][j] = bf2f(f2bf(p01)); g[2][j] = bf2f(f2bf(p10)); g[3][j] = bf2f(f2bf(p11));
+  }
+}
+
+// bn_bwd_reduce_kernel<2 / 0> and bn_bwd_apply_kernel<2 / 0> for a layer whose output feeds ONLY a 3x3 / 2 max-pool (the two
+// stem pools, model.py:103,115): the activation gradient is gathered from the pool's output gradient on the fly, the
+// max-pool backward launch and its 2 + 2 x 2 bytes per element of write / re-read disappear (177 MB and 124 MB tensors).
+// A "row" of these kernels is a 2 x 2 pixel block (n, a, b); Mb = N Hb Wb of them, Hb = ceil(H / 2), Wb = ceil(W / 2).
+template <bool RELU>
+__global__ void __launch_bounds__(kT)
+bn_bwd_reduce_pool_kernel(const PoolSrc ps, const unsigned short* __restrict__ y, long long Mb, int C,
+                          const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
+                          int rpi, int rpb, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // [rpi][C8][16]
+  const int C8 = C >> 3;
+  const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+  const bool active = rr < rpi;
+  const int c = vc << 3;
+  float s1[8], s2[8], mu[8], rs[8], be[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[c + j]; rs[j] = rstd[c + j];
+    be[j] = RELU ? beta[c + j] : 0.f;
+  }
+  const long long r0 = (long long)blockIdx.x * rpb;
+  long long r1 = r0 + rpb;
+  if (r1 > Mb) r1 = Mb;
+  const unsigned HWb = (unsigned)(ps.Hb * ps.Wb);
+  if (active)
+    for (long long m = r0 + rr; m < r1; m += rpi) {
+      const unsigned mu_ = (unsigned)m, n = mu_ / HWb, rem = mu_ - n * HWb, a = rem / (unsigned)ps.Wb, b = rem - a * (unsigned)ps.Wb;
+      float g[4][8];
+      pool3s2_grad_block(ps, (int)n, (int)a, (int)b, c, g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = 2 * (int)a + (q >> 1), w = 2 * (int)b + (q & 1);
+        if (h >= ps.H || w >= ps.W) continue;
+        float yy[8];
+        unpack8(ld8(y + (((long long)n * ps.H + h) * ps.W + w) * C + c), yy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (yy[j] - mu[j]) * rs[j];
+          const float gj = (!RELU || xh + be[j] > 0.f) ? g[q][j] : 0.f;
+          s1[j] += gj;
+          s2[j] += gj * xh;
+        }
+      }
+    }
+  if (active) {
+    float* o = sred + ((size_t)rr * C8 + vc) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = s1[j]; o[8 + j] = s2[j]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int r = 0; r < rpi; ++r) {
+      const float* o = sred + ((size_t)r * C8 + threadIdx.x) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+    }
+    float* p = partial + ((size_t)blockIdx.x * C + (threadIdx.x << 3)) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[2 * j] = s1[j]; p[2 * j + 1] = s2[j]; }
+  }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kT)
+bn_bwd_apply_pool_kernel(const PoolSrc ps, const unsigned short* __restrict__ y, long long Mb, int C, long long M,
+                         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta,
+                         const float* __restrict__ m12, unsigned short* __restrict__ dy) {
+  const int C8 = C >> 3;
+  const long long total = Mb * C8;
+  const unsigned HWb = (unsigned)(ps.Hb * ps.Wb);
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8) << 3;
+    const unsigned mu_ = (unsigned)m, n = mu_ / HWb, rem = mu_ - n * HWb, a = rem / (unsigned)ps.Wb, b = rem - a * (unsigned)ps.Wb;
+    float g[4][8], mu[8], rs[8], be[8], q1[8], q2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mean[c + j]; rs[j] = rstd[c + j]; be[j] = RELU ? beta[c + j] : 0.f; q1[j] = m12[c + j]; q2[j] = m12[C + c + j];
+    }
+    pool3s2_grad_block(ps, (int)n, (int)a, (int)b, c, g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = 2 * (int)a + (q >> 1), w = 2 * (int)b + (q & 1);
+      if (h >= ps.H || w >= ps.W) continue;
+      const long long row = ((long long)n * ps.H + h) * ps.W + w;
+      float yy[8], o[8];
+      unpack8(ld8(y + row * C + c), yy);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (yy[j] - mu[j]) * rs[j];
+        const float gj = (!RELU || xh + be[j] > 0.f) ? g[q][j] : 0.f;
+        o[j] = rs[j] * (gj - q1[j] - xh * q2[j]);
+      }
+      st8(dy + row * C + c, pack8(o));
+    }
+  }
+}
+
 template <int KK, int SS>
 __global__ void __launch_bounds__(kT)
 maxpool_bwd_kernel(const unsigned short* __restrict__ dy, long long dys, int ld_dy,
@@ -907,7 +1051,8 @@ head_scatter_all_kernel(const HeadTable t, int P, const float* __restrict__ d_lo
 // added to a running total first (was: five small torch kernels over the per-layer flags)
 __global__ void __launch_bounds__(kT)
 step_begin_kernel(float* __restrict__ G, long long nG, float* __restrict__ ws, long long nws, long long ctl,
-                  unsigned long long* __restrict__ timeouts_total) {
+                  unsigned long long* __restrict__ timeouts_total, float* __restrict__ scalar) {
+  if (scalar && blockIdx.x == 0 && threadIdx.x == 0) *scalar = 0.f;      // (the regularisation-loss accumulator of the optimiser)
   const long long n4 = nG >> 2, w4 = nws >> 2;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n4 + w4; i += (long long)gridDim.x * kT) {
@@ -1037,14 +1182,19 @@ ema_update_kernel(float* __restrict__ ema, const float* __restrict__ v, long lon
 __global__ void __launch_bounds__(kT)
 bn_moving_update_kernel(float* __restrict__ mm, float* __restrict__ mv, const float* __restrict__ bmean,
                         const float* __restrict__ bvar, long long n, float decay, const float* __restrict__ skip_ctl,
-                        unsigned long long* __restrict__ skipped) {
+                        unsigned long long* __restrict__ skipped, float* __restrict__ ema_m, float* __restrict__ ema_v,
+                        float ema_d) {
   if (skip_ctl && (skip_ctl[0] != 0.f || skip_ctl[1] != 0.f)) {
     if (skipped && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1ull;  // (one writer: launches are stream-ordered)
     return;
   }
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
-    mm[i] -= (1.0f - decay) * (mm[i] - bmean[i]);                          // bn_finalize_kernel's expressions
-    mv[i] -= (1.0f - decay) * (mv[i] - bvar[i]);
+    const float m = mm[i] - (1.0f - decay) * (mm[i] - bmean[i]);           // bn_finalize_kernel's expressions
+    const float v = mv[i] - (1.0f - decay) * (mv[i] - bvar[i]);
+    mm[i] = m;
+    mv[i] = v;
+    if (ema_m) { const float e = ema_m[i]; ema_m[i] = e - (1.0f - ema_d) * (e - m); }   // ema_update_kernel's, on the new values
+    if (ema_v) { const float e = ema_v[i]; ema_v[i] = e - (1.0f - ema_d) * (e - v); }
   }
 }
 
@@ -1310,6 +1460,62 @@ extern "C" int mbx_maxpool_bwd(const void* dy, int64_t dys, int ld_dy, const uin
   return MBX_OK;
 }
 
+static int pool_src_ok(const void* gy, int ld_gy, const uint8_t* argmax, int N, int H, int W, int Ho, int Wo, int C, PoolSrc& ps,
+                       int64_t gys) {
+  if (!gy || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || ld_gy % 8 || !al16(gy) || (reinterpret_cast<uintptr_t>(argmax) & 7))
+    return MBX_ERR_INVALID_ARG;
+  if (Ho != (H - 3) / 2 + 1 || Wo != (W - 3) / 2 + 1) return MBX_ERR_INVALID_ARG;     // 3x3 / stride 2, VALID
+  if ((long long)N * H * W >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+  ps.gy = (cus)gy; ps.gys = gys; ps.ld_gy = ld_gy; ps.argmax = argmax; ps.H = H; ps.W = W; ps.Ho = Ho; ps.Wo = Wo; ps.C = C;
+  ps.Hb = (H + 1) / 2; ps.Wb = (W + 1) / 2;
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_rows_pooled(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 2048) return MBX_ERR_INVALID_ARG;
+  return bn_bwd_geom((long long)N * ((H + 1) / 2) * ((W + 1) / 2), C).rows;
+}
+
+extern "C" int mbx_bn_bwd_reduce_pooled(const void* gy, int64_t gy_img_stride, int ld_gy, const uint8_t* argmax, int N, int H,
+                                        int W, int Ho, int Wo, int relu, const void* y, int C, const float* mean,
+                                        const float* rstd, const float* beta, float* partial, mbx_stream_t stream) {
+  PoolSrc ps;
+  int st = pool_src_ok(gy, ld_gy, argmax, N, H, W, Ho, Wo, C, ps, gy_img_stride);
+  if (st != MBX_OK) return st;
+  if (!y || !al16(y) || !mean || !rstd || (relu && !beta) || !partial || C > 2048) return MBX_ERR_INVALID_ARG;
+  const long long Mb = (long long)N * ps.Hb * ps.Wb;              // 2 x 2 pixel blocks: the "rows" of this launch
+  const BnBwdGeom g = bn_bwd_geom(Mb, C);
+  MBX_ENTER();
+  const size_t lds = (size_t)g.rows_per_iter * g.C8 * 16 * sizeof(float);
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<true>, dim3(g.rows), dim3(kT), lds, mbx_s(stream), ps, (cus)y, Mb, C, mean, rstd,
+                       beta, g.rows_per_iter, g.rpb, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<false>, dim3(g.rows), dim3(kT), lds, mbx_s(stream), ps, (cus)y, Mb, C, mean, rstd,
+                       beta, g.rows_per_iter, g.rpb, partial);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_bwd_apply_pooled(const void* gy, int64_t gy_img_stride, int ld_gy, const uint8_t* argmax, int N, int H,
+                                       int W, int Ho, int Wo, int relu, const void* y, int C, const float* mean,
+                                       const float* rstd, const float* beta, const float* m12, void* dy, mbx_stream_t stream) {
+  PoolSrc ps;
+  int st = pool_src_ok(gy, ld_gy, argmax, N, H, W, Ho, Wo, C, ps, gy_img_stride);
+  if (st != MBX_OK) return st;
+  if (!y || !al16(y) || !mean || !rstd || (relu && !beta) || !m12 || !dy || !al16(dy)) return MBX_ERR_INVALID_ARG;
+  const long long M = (long long)N * H * W, Mb = (long long)N * ps.Hb * ps.Wb;
+  MBX_ENTER();
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<true>, dim3(grid_for(Mb * (C / 8))), dim3(kT), 0, mbx_s(stream), ps, (cus)y, Mb, C, M,
+                       mean, rstd, beta, m12, (us)dy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<false>, dim3(grid_for(Mb * (C / 8))), dim3(kT), 0, mbx_s(stream), ps, (cus)y, Mb, C, M,
+                       mean, rstd, beta, m12, (us)dy);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 extern "C" int mbx_avgpool_fwd(const void* x, int64_t xs, int ldx, int N, int H, int W, int C, int k, int pad, void* y,
                                int64_t ys, int ldy, int Ho, int Wo, mbx_stream_t stream) {
   if (!pool_args_ok(x, ldx, y, ldy, N, H, W, C, k, Ho, Wo) || pad < 0 || pad >= k) return MBX_ERR_INVALID_ARG;
@@ -1413,14 +1619,14 @@ extern "C" int mbx_head_scatter_all(const float* d_locs, const float* d_logits, 
 }
 
 extern "C" int mbx_step_begin(float* grads, int64_t n_grads, float* bn_ws, int64_t n_ws, int64_t ctl_index,
-                              uint64_t* timeouts_total, mbx_stream_t stream) {
+                              uint64_t* timeouts_total, float* zero_scalar, mbx_stream_t stream) {
   if (!grads || n_grads <= 0 || n_grads % 4 || n_ws < 0 || n_ws % 4 || (n_ws && !bn_ws) || !al16(grads) || (bn_ws && !al16(bn_ws)) ||
       (timeouts_total && (ctl_index < 0 || ctl_index >= n_grads)))
     return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   hipLaunchKernelGGL(step_begin_kernel, dim3(grid_for((n_grads + n_ws) / 4)), dim3(kT), 0, mbx_s(stream), grads,
                      (long long)n_grads, bn_ws, (long long)n_ws, (long long)ctl_index,
-                     reinterpret_cast<unsigned long long*>(timeouts_total));
+                     reinterpret_cast<unsigned long long*>(timeouts_total), zero_scalar);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -1449,11 +1655,12 @@ extern "C" int mbx_rmsprop_ema_step(float* w, const float* g, float* ms, float* 
 
 extern "C" int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* batch_mean, const float* batch_var,
                                     int64_t n, float decay, const float* skip_ctl, uint64_t* skipped_steps,
-                                    mbx_stream_t stream) {
+                                    float* ema_mean, float* ema_var, float ema_decay, mbx_stream_t stream) {
   if (!moving_mean || !moving_var || !batch_mean || !batch_var || n <= 0 || decay < 0.f) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
   hipLaunchKernelGGL(bn_moving_update_kernel, dim3(grid_for(n)), dim3(kT), 0, mbx_s(stream), moving_mean, moving_var,
-                     batch_mean, batch_var, (long long)n, decay, skip_ctl, reinterpret_cast<unsigned long long*>(skipped_steps));
+                     batch_mean, batch_var, (long long)n, decay, skip_ctl, reinterpret_cast<unsigned long long*>(skipped_steps),
+                     ema_mean, ema_var, ema_decay);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

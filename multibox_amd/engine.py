@@ -337,11 +337,12 @@ class Net:
         f4 = -(-f // 2)
         n4 = self.alloc(f4, f4, 256)
         self.conv([(H + "Conv", 256)], feat, n4, 3, 3, 2, "SAME", is_head=True, need_dx=not self.fine_tune)
-        h4 = self.alloc(f4, f4, 128)
-        self.conv([(H + "4x4/Conv", 128)], n4, h4, 3, 3, is_head=True)
+        h432 = self.alloc(f4, f4, 384)      # [4x4/Conv 128 | 3x3/Conv 128 | 2x2/Conv 128]: siblings on n4, one batch-norm group
+        h4, h32 = h432.slice(0, 128), h432.slice(128, 256)
+        ga = self.conv([(H + "4x4/Conv", 128)], n4, h4, 3, 3, is_head=True)
         grids.append((H + "4x4/", h4, f4, k))
-        h32 = self.alloc(f4, f4, 256)
-        self.conv([(H + "3x3/Conv", 128), (H + "2x2/Conv", 128)], n4, h32, 1, 1, is_head=True)
+        gb = self.conv([(H + "3x3/Conv", 128), (H + "2x2/Conv", 128)], n4, h32, 1, 1, is_head=True)
+        self.group_bn(ga, gb)
         h3 = self.alloc(f4 - 1, f4 - 1, 96)
         self.conv([(H + "3x3/Conv_1", 96)], h32.slice(0, 128), h3, 2, 2, 1, "VALID", is_head=True)
         grids.append((H + "3x3/", h3, f4 - 1, k))
@@ -774,6 +775,13 @@ class Net:
         for op in reversed(self.fwd):
             if isinstance(op, PoolOp):
                 if op.needs_backward():
+                    prod = self._pool_producer(op)
+                    if prod is not None:
+                        # the pool's input is the activation of a batch-norm layer on the three-launch backward and nothing else
+                        # reads it: that layer's backward gathers its gradient from the pool's output gradient on the fly
+                        # (mbx_bn_bwd_*_pooled) -- no max-pool backward launch, its result never stored
+                        prod.fused_pool = op
+                        continue
                     gx = self._gview(op.x)
                     acc, src = self._claim(gx)
                     assert src is None, "a pooling layer cannot be the first writer of a residual block's input gradient"
@@ -816,7 +824,10 @@ class Net:
                     lead = op if g is None else g.members[0]
                     Kb = K if g is None else g.K
                     y_ptr, dy_ptr = (op.y_view.ptr, op.dy_view.ptr) if g is None else (g.y.data_ptr(), g.dy.data_ptr())
-                    if g is None:
+                    fpool = getattr(op, "fused_pool", None)
+                    if fpool is not None:
+                        da = da_ptr = dmap = None
+                    elif g is None:
                         da, da_ptr, dmap = self._gview(op.out), self._gview(op.out).ptr, None
                     else:
                         gviews = [self._gview(m.out) for m in g.members]
@@ -850,6 +861,19 @@ class Net:
                         _lib.check(l.mbx_bn_bwd_apply_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
                                                              mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                              dy_ptr, dmap, s), "bn_bwd_apply")
+                    if fpool is not None:
+                        gy = self._gview(fpool.out)
+                        rows = l.mbx_bn_bwd_rows_pooled(fpool.x.N, fpool.x.H, fpool.x.W, Kb)     # (<= the plain form's: bwd_scratch fits)
+                        assert 0 < rows * Kb * 2 <= self.bwd_scratch.numel()
+
+                        def pre(s, op=op, gy=gy, fpool=fpool, mean=mean, rstd=rstd, beta=beta, dbeta=dbeta, rows=rows, Kb=Kb, M=M,
+                                y_ptr=y_ptr, dy_ptr=dy_ptr):
+                            geo = (gy.ptr, gy.img_stride, gy.ld, fpool.argmax.data_ptr(), fpool.x.N, fpool.x.H, fpool.x.W, fpool.out.H,
+                                   fpool.out.W, int(op.relu), y_ptr, Kb, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr())
+                            _lib.check(l.mbx_bn_bwd_reduce_pooled(*geo, self.bwd_scratch.data_ptr(), s), "bn_bwd_reduce_pooled")
+                            _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, Kb, M, dbeta.data_ptr(),
+                                                             self.m12.data_ptr(), s), "bn_bwd_finalize")
+                            _lib.check(l.mbx_bn_bwd_apply_pooled(*geo, self.m12.data_ptr(), dy_ptr, s), "bn_bwd_apply_pooled")
                 if pre is not None and (op.bn_ws_off if g is None else g.members[0].bn_ws_off) >= 0:
                     # chosen at CALL time: Trainer.check_health() falls back to the three launches (and re-captures its
                     # graphs) when a grid barrier has timed out -- e.g. RCCL kernels holding more CUs than bn_max_wg allows for
@@ -891,6 +915,22 @@ class Net:
         self.fwd_launches = self._build_forward_launches()
         self._default_groups = None
 
+    def _pool_producer(self, pool):
+        """The batch-norm layer whose activation is `pool`'s input if the pool's backward can ride in that layer's three-launch
+        BN backward (3x3 / 2 VALID max-pool; the activation has no other reader; the layer is not in a group and too large
+        for the one-launch form: the two stem pools at BATCH_SIZE 64), else None.  MBX_POOL_FUSE=0 turns it off (A/B)."""
+        if os.environ.get("MBX_POOL_FUSE", "1") == "0" or pool.kind != "max" or pool.k != 3 or pool.stride != 2 or pool.pad != 0 \
+                or pool.argmax is None:
+            return None
+        readers = [o for o in self.fwd if o is not pool and o.x.buf is pool.x.buf]
+        if readers:
+            return None
+        for c in self.convs:
+            if c.out.buf is pool.x.buf and c.out.ch_off == pool.x.ch_off and c.out.C == pool.x.C and c.out.ld == pool.x.ld == pool.x.C:
+                ok = c.kind == "bn" and c.trainable and c.group is None and c.bn_ws_off < 0 and c.need_dx is not None
+                return c if ok else None
+        return None
+
     def make_wgrad_groups(self, job_lists):
         """One grouped weight-gradient launch (ops.WgradGroup) per list of jobs; the caller runs each after the
         backward launches its jobs belong to (Trainer: at the end of every backward segment)."""
@@ -904,15 +944,18 @@ class Net:
                                                      self.filter_entries, self.filter_blocks,
                                                      torch.cuda.current_stream().cuda_stream), "filter_prepare")
 
-    def apply_moving_update(self, skip_ctl=None, skipped_steps=None):
+    def apply_moving_update(self, skip_ctl=None, skipped_steps=None, ema_mean=None, ema_var=None, ema_decay=0.0):
         """The deferred moving-average update of every training-mode batch-norm layer (defer_moving), one launch.
-        skip_ctl / skipped_steps: device tensors (step control block; int64 counter of skipped steps) or None."""
+        skip_ctl / skipped_steps: device tensors (step control block; int64 counter of skipped steps) or None.
+        ema_mean / ema_var: the EMA shadows of the moving statistics ([nBt] each), updated from the new values in the same launch."""
         lo = self.head_bt_start if self.fine_tune else 0          # --fine_tune: the backbone's batch norm is frozen (train.py:124-131)
         n = self.nBt - lo
         if n > 0 and self.mode == "train":
             _lib.check(_lib.lib().mbx_bn_moving_update(self.MM.data_ptr() + 4 * lo, self.MV.data_ptr() + 4 * lo,
                                                        self.bn_mean.data_ptr() + 4 * lo, self.bn_var.data_ptr() + 4 * lo, n,
                                                        self.bn_decay, ops._p(skip_ctl), ops._p(skipped_steps),
+                                                       None if ema_mean is None else ema_mean.data_ptr() + 4 * lo,
+                                                       None if ema_var is None else ema_var.data_ptr() + 4 * lo, float(ema_decay),
                                                        torch.cuda.current_stream().cuda_stream), "bn_moving_update")
 
     def fold_bn(self):
@@ -995,10 +1038,11 @@ class Net:
         return int(self.bn_timeouts_total) + int(float(self.step_ctl[0]))
 
     def zero_grads(self):
-        """ONE launch (mbx_step_begin): Wg, Btg, the step control block and the accumulators / arrival counters of the
-        one-launch BN backward cleared; the control word's time-out count kept in bn_timeouts_total first."""
+        """ONE launch (mbx_step_begin): Wg, Btg, the step control block, the accumulators / arrival counters of the
+        one-launch BN backward and the optimiser's regularisation-loss accumulator cleared; the control word's time-out
+        count kept in bn_timeouts_total first."""
         _lib.check(_lib.lib().mbx_step_begin(self.G.data_ptr(), self.G.numel(), self.bn_ws.data_ptr(), self.bn_ws.numel(),
-                                             self.nBt, self.bn_timeouts_total.data_ptr(),
+                                             self.nBt, self.bn_timeouts_total.data_ptr(), self.reg_loss.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream), "step_begin")
 
     def backward(self):

@@ -463,7 +463,7 @@ class Trainer:
         lr = learning_rate(t, self.lr0, self.dsteps, self.lr_factor, self.staircase)
         d = min(self.ema_decay, (1.0 + t) / (10.0 + t))        # ExponentialMovingAverage(num_updates=global_step)
         self.lr = lr
-        net.reg_loss.zero_()
+        # (net.reg_loss was cleared by the step's mbx_step_begin launch: Net.zero_grads)
         P = lambda t_, off=0: None if t_ is None else t_.data_ptr() + 4 * off
         ctl = net.step_ctl.data_ptr()                  # non-zero -> every launch below is a no-op (poisoned step / stop request)
         for buf, lo, hi, on in self.opt_ranges:
@@ -477,10 +477,9 @@ class Trainer:
             else:
                 _lib.check(l.mbx_rmsprop_ema_step(P(net.Bt, lo), P(net.Btg, lo), P(self.Btms, lo), P(self.Btmom, lo), P(self.Btema, lo),
                                                   None, n, lr, self.rms_decay, self.momentum, self.eps, 0.0, d, on, None, ctl, s), "rmsprop beta")
-        net.apply_moving_update(net.step_ctl, self.skipped_steps)      # moving statistics: this step's batch statistics, gated
-        lo, n = self.bt_lo, net.nBt - self.bt_lo
-        _lib.check(l.mbx_ema_update(P(self.MMema, lo), P(net.MM, lo), n, d, ctl, s), "ema moving_mean")
-        _lib.check(l.mbx_ema_update(P(self.MVema, lo), P(net.MV, lo), n, d, ctl, s), "ema moving_var")
+        # moving statistics <- this step's batch statistics, and their EMA shadows (train.py:257) from the new values: one gated launch
+        assert self.bt_lo == (net.head_bt_start if net.fine_tune else 0)
+        net.apply_moving_update(net.step_ctl, self.skipped_steps, self.MMema, self.MVema, d)
         net.prepare_filters()
 
     def losses(self):

@@ -297,9 +297,10 @@ def test_glue_kernels(T):
     ws = torch.randn(1024, generator=gen).cuda()
     tot = torch.full((), 5, dtype=torch.int64, device="cuda")
     G[136] = 7.0
-    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), S()))
-    assert float(G.abs().max()) == 0 and float(ws.abs().max()) == 0 and int(tot) == 12
-    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), S()))
+    sc = torch.full((1,), 3.0, device="cuda")
+    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), sc.data_ptr(), S()))
+    assert float(G.abs().max()) == 0 and float(ws.abs().max()) == 0 and int(tot) == 12 and float(sc) == 0.0
+    _lib.check(l.mbx_step_begin(G.data_ptr(), G.numel(), ws.data_ptr(), ws.numel(), 136, tot.data_ptr(), None, S()))
     assert int(tot) == 12
 
 
@@ -468,3 +469,56 @@ def test_bn_group_entry_points(T, M, Ks, offs, relu):
         assert torch.allclose(dbeta_o, dbeta_g, rtol=1e-4, atol=1e-3)
         ok, msg = close_bf16(dy_o, dy_g)
         assert ok, "group one-launch backward: " + msg
+
+
+@pytest.mark.parametrize("N,H,W,Cc,relu", [(2, 21, 21, 64, 1), (3, 15, 17, 192, 1), (1, 9, 9, 8, 0)])
+def test_bn_backward_pooled(T, N, H, W, Cc, relu):
+    """Round 4: the three-launch BN backward of a layer that feeds only a 3x3 / 2 max-pool, gathering its activation gradient
+    from the pool's output gradient on the fly (mbx_bn_bwd_reduce_pooled / _apply_pooled) == mbx_maxpool_fwd's argmax ->
+    mbx_maxpool_bwd -> mbx_bn_bwd_reduce / finalize / apply: the same per-element gradients (same additions, same bf16 rounding), statistics
+    summed in another grouping (2 x 2 pixel blocks share their four window loads)."""
+    torch = T
+    from multibox_amd import _lib
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(N * 1000 + H * 10 + Cc)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    M = N * H * W
+    y = (torch.randn(M, Cc, generator=gen) * 2 + 0.5).to(torch.bfloat16).cuda()
+    mean = y.float().mean(0).contiguous()
+    rstd = torch.rsqrt(y.float().var(0, unbiased=False) + 0.001).contiguous()
+    beta = (torch.randn(Cc, generator=gen) * 0.3).cuda()
+    a = torch.zeros((N, H, W, Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_bn_apply(y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), relu, a.data_ptr(), Cc, S()))
+    p = torch.zeros((N, Ho, Wo, Cc), dtype=torch.bfloat16, device="cuda")
+    arg = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device="cuda")
+    _lib.check(l.mbx_maxpool_fwd(a.data_ptr(), H * W * Cc, Cc, N, H, W, Cc, 3, 2, p.data_ptr(), Ho * Wo * Cc, Cc, Ho, Wo, arg.data_ptr(), S()))
+    gy = torch.randn(N, Ho, Wo, Cc, generator=gen).to(torch.bfloat16).cuda()
+    # reference path: pool backward -> stored da -> reduce / finalize / apply
+    da = torch.zeros((N, H, W, Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(l.mbx_maxpool_bwd(gy.data_ptr(), Ho * Wo * Cc, Cc, arg.data_ptr(), N, H, W, Cc, 3, 2, Ho, Wo, da.data_ptr(), H * W * Cc, Cc, 0, S()))
+    out = []
+    for pooled in (False, True):
+        rows = l.mbx_bn_bwd_rows_pooled(N, H, W, Cc) if pooled else l.mbx_bn_bwd_rows(M, Cc)
+        partial = torch.zeros((rows, Cc, 2), device="cuda")
+        dbeta, m12 = torch.zeros(Cc, device="cuda"), torch.zeros(2 * Cc, device="cuda")
+        dy = torch.zeros((M, Cc), dtype=torch.bfloat16, device="cuda")
+        stat = (mean.data_ptr(), rstd.data_ptr(), beta.data_ptr())
+        if pooled:
+            geo = (gy.data_ptr(), Ho * Wo * Cc, Cc, arg.data_ptr(), N, H, W, Ho, Wo, relu, y.data_ptr(), Cc) + stat
+            _lib.check(l.mbx_bn_bwd_reduce_pooled(*geo, partial.data_ptr(), S()))
+            _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta.data_ptr(), m12.data_ptr(), S()))
+            _lib.check(l.mbx_bn_bwd_apply_pooled(*geo, m12.data_ptr(), dy.data_ptr(), S()))
+        else:
+            args = (da.data_ptr(), Cc, None, 0, relu, y.data_ptr(), M, Cc) + stat
+            _lib.check(l.mbx_bn_bwd_reduce(*args, partial.data_ptr(), S()))
+            _lib.check(l.mbx_bn_bwd_finalize(partial.data_ptr(), rows, Cc, M, dbeta.data_ptr(), m12.data_ptr(), S()))
+            _lib.check(l.mbx_bn_bwd_apply(*args, m12.data_ptr(), dy.data_ptr(), S()))
+        torch.cuda.synchronize()
+        out.append((partial, dbeta, m12, dy))
+    # per-element gradients are the stored ones; the partial sums are grouped by 2 x 2 pixel blocks instead of rows:
+    # totals equal to float32 rounding, dy to 1 bf16 ulp
+    assert torch.allclose(out[0][0].double().sum(0), out[1][0].double().sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(out[0][1], out[1][1], rtol=1e-5, atol=1e-3) and torch.allclose(out[0][2], out[1][2], rtol=1e-5, atol=1e-6)
+    ok, msg = close_bf16(out[1][3], out[0][3])
+    assert ok, msg
+    assert float(out[0][3].float().abs().max()) > 0
