@@ -304,6 +304,13 @@ int mbx_bn_finalize_parts(const float* const* parts /*HOST array of DEVICE point
                           float* rstd, float* moving_mean, float* moving_var, mbx_stream_t stream);
 int mbx_bn_apply_mapped(const void* y, int64_t M, int C, const float* mean, const float* rstd, const float* beta,
                         int relu, void* a, int ld_a, const mbx_chan_map* a_map /*HOST*/, mbx_stream_t stream);
+/* mbx_bn_apply followed by mbx_maxpool_fwd (3x3, stride 2, VALID) in ONE pass, for a layer whose activation feeds only that
+ * pool (the two stem pools, model.py:103,115): p[n,oh,ow,c] = max over the window of bf16(relu?((y - mean) rstd + beta)),
+ * argmax = the first maximum's tap (uint8 [N,Ho,Wo,C], may be NULL) -- the activation itself is never stored.
+ * y: bf16 [N*H*W, C] contiguous.  Bit-identical to the two calls.                                                       */
+int mbx_bn_apply_maxpool(const void* y, int N, int H, int W, int C, const float* mean, const float* rstd, const float* beta,
+                         int relu, void* p, int64_t p_img_stride, int ld_p, int Ho, int Wo, uint8_t* argmax,
+                         mbx_stream_t stream);
 /* Frozen BN folded into the conv epilogue (detect.py:313-326, train.py:124-131):
  * scale = 1/sqrt(moving_var+eps), shift = beta - moving_mean*scale.                       */
 int mbx_bn_fold(const float* moving_mean, const float* moving_var, const float* beta, float eps,

@@ -59,6 +59,7 @@ _SIGS = {
     "mbx_bn_apply_mapped": (I, [P, C.c_int64, I, P, P, P, I, P, I, P, P]),
     "mbx_bn_bwd_reduce_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P]),
     "mbx_bn_bwd_apply_mapped": (I, [P, I, P, I, I, P, C.c_int64, I, P, P, P, P, P, P, P]),
+    "mbx_bn_apply_maxpool": (I, [P, I, I, I, I, P, P, P, I, P, C.c_int64, I, I, I, P, P]),
     "mbx_bn_bwd_rows_pooled": (I, [I, I, I, I]),
     "mbx_bn_bwd_reduce_pooled": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, P, I, P, P, P, P, P]),
     "mbx_bn_bwd_apply_pooled": (I, [P, C.c_int64, I, P, I, I, I, I, I, I, P, I, P, P, P, P, P, P]),

@@ -658,6 +658,57 @@ maxpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
   }
 }
 
+// bn_apply_kernel + maxpool_fwd_kernel<3, 2> in ONE pass for a layer whose activation feeds ONLY a 3x3 / 2 VALID max-pool
+// (the two stem pools): every window tap is normalised from y (relu((y - mean) rstd + beta), rounded to bf16 as bn_apply
+// stores it) and reduced straight away -- first maximum in scan order, as maxpool_fwd_kernel -- so the activation (177 MB
+// and 124 MB at BATCH_SIZE 64) is neither written nor read back: the pooled tensor and the argmax bytes are the only outputs.
+// Bit-identical to the two launches it replaces.
+__global__ void __launch_bounds__(kT)
+bn_apply_maxpool3s2_kernel(const unsigned short* __restrict__ y, int N, int H, int W, int C, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
+                           unsigned short* __restrict__ p, long long ps, int ldp, int Ho, int Wo,
+                           unsigned char* __restrict__ argmax) {
+  const int C8 = C >> 3;
+  const unsigned total = (unsigned)N * Ho * Wo * C8;
+  for (unsigned i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
+    unsigned t = i / (unsigned)C8;
+    const int c = (int)(i - t * C8) << 3;
+    const unsigned t2 = t / (unsigned)Wo;
+    const int ow = (int)(t - t2 * Wo);
+    const int n = (int)(t2 / (unsigned)Ho);
+    const int oh = (int)(t2 - (unsigned)n * Ho);
+    u32x4 v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)                       // VALID: every tap lies inside the image
+        v[r * 3 + q] = ld8(y + (((long long)n * H + (oh * 2 + r)) * W + (ow * 2 + q)) * C + c);
+    float mu[8], rs[8], be[8], best[8];
+    unsigned arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; be[j] = beta[c + j]; best[j] = -INFINITY; arg[j] = 0; }
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq) {
+      float f[8];
+      unpack8(v[tq], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = (f[j] - mu[j]) * rs[j] + be[j];
+        a = relu ? fmaxf(a, 0.f) : a;
+        a = bf2f(f2bf(a));                              // (the value bn_apply_kernel stores and maxpool_fwd_kernel reads)
+        if (a > best[j]) { best[j] = a; arg[j] = tq; }
+      }
+    }
+    st8(p + n * ps + ((long long)oh * Wo + ow) * ldp + c, pack8(best));
+    if (argmax) {
+      u32x2 av;
+      av.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+      av.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+      *reinterpret_cast<u32x2*>(argmax + (((long long)n * Ho + oh) * Wo + ow) * C + c) = av;
+    }
+  }
+}
+
 // Gradient of a 3x3 / stride-2 VALID max-pool's INPUT for the 2 x 2 pixel block (2a + dh, 2b + dw), channels c .. c+7,
 // gathered from the pool's output gradient and its argmax bytes -- for the batch-norm backward kernels that read it on the
 // fly instead of from a stored tensor (bn_bwd_*_pool_kernel).  The block's four pixels are covered by the same four windows
@@ -1468,6 +1519,21 @@ static int pool_src_ok(const void* gy, int ld_gy, const uint8_t* argmax, int N, 
   if ((long long)N * H * W >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
   ps.gy = (cus)gy; ps.gys = gys; ps.ld_gy = ld_gy; ps.argmax = argmax; ps.H = H; ps.W = W; ps.Ho = Ho; ps.Wo = Wo; ps.C = C;
   ps.Hb = (H + 1) / 2; ps.Wb = (W + 1) / 2;
+  return MBX_OK;
+}
+
+extern "C" int mbx_bn_apply_maxpool(const void* y, int N, int H, int W, int C, const float* mean, const float* rstd,
+                                    const float* beta, int relu, void* p, int64_t p_img_stride, int ld_p, int Ho, int Wo,
+                                    uint8_t* argmax, mbx_stream_t stream) {
+  if (!y || !p || !mean || !rstd || !beta || N <= 0 || H < 3 || W < 3 || C <= 0 || C % 8 || ld_p % 8 || !al16(y) || !al16(p) ||
+      (argmax && (reinterpret_cast<uintptr_t>(argmax) & 7)))
+    return MBX_ERR_INVALID_ARG;
+  if (Ho != (H - 3) / 2 + 1 || Wo != (W - 3) / 2 + 1) return MBX_ERR_INVALID_ARG;     // 3x3 / stride 2, VALID
+  if ((long long)N * Ho * Wo * (C / 8) >= (1LL << 31) || (long long)N * H * W * C >= (1LL << 40)) return MBX_ERR_UNSUPPORTED;
+  MBX_ENTER();
+  hipLaunchKernelGGL(bn_apply_maxpool3s2_kernel, dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(kT), 0, mbx_s(stream),
+                     (cus)y, N, H, W, C, mean, rstd, beta, relu, (us)p, (long long)p_img_stride, ld_p, Ho, Wo, argmax);
+  MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
 

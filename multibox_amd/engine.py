@@ -605,7 +605,8 @@ class Net:
         st = lambda: torch.cuda.current_stream().cuda_stream
         for op in self.fwd:
             if isinstance(op, PoolOp):
-                L.append(op.forward)
+                if not getattr(op, "fused_fwd", False):          # (else: its producer's BN apply writes the pooled tensor)
+                    L.append(op.forward)
                 continue
             if op.kind == "bn" and op.group is not None:
                 # member of a batch-norm group: its convolution writes its channel slice of the group's [M, K] tensor and its
@@ -662,12 +663,25 @@ class Net:
 
                 var = self._sl(self.bn_var, op.beta_off, op.K)
 
-                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var):
+                fpool = getattr(op, "fused_pool", None)
+                if fpool is not None:
+                    fpool.fused_fwd = True
+
+                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var, fpool=fpool):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     decay = self.bn_decay
                     if self.defer_moving:                    # store mode: batch variance -> bn_var, moving statistics untouched
                         mm, mv, decay = None, var, -1.0
+                    if fpool is not None:
+                        # the activation feeds only a 3x3 / 2 max-pool: normalise and pool in one pass, never store it
+                        po = fpool.out
+                        _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, decay,
+                                                     mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv), s), "bn_finalize")
+                        _lib.check(l.mbx_bn_apply_maxpool(op.y_view.ptr, out.N, out.H, out.W, op.K, mean.data_ptr(), rstd.data_ptr(),
+                                                          beta.data_ptr(), int(op.relu), po.ptr, po.img_stride, po.ld, po.H, po.W,
+                                                          fpool.argmax.data_ptr(), s), "bn_apply_maxpool")
+                        return
                     # (timing probe of tools/whatif_probe.py: finalize only, `a` keeps the previous step's values)
                     if self._probe_skip_apply and ("/block" in op.name or "/Block8" in op.name):
                         _lib.check(l.mbx_bn_finalize(self.stats_scratch.data_ptr(), rows, op.K, op.M, BN_EPS, decay,
@@ -927,7 +941,9 @@ class Net:
             return None
         for c in self.convs:
             if c.out.buf is pool.x.buf and c.out.ch_off == pool.x.ch_off and c.out.C == pool.x.C and c.out.ld == pool.x.ld == pool.x.C:
-                ok = c.kind == "bn" and c.trainable and c.group is None and c.bn_ws_off < 0 and c.need_dx is not None
+                # (never on the one-launch backward: too large for it -- or the deterministic mode, which uses the three launches
+                # everywhere and for good, so that the choice does not depend on a grid cap)
+                ok = c.kind == "bn" and c.trainable and c.group is None and (c.bn_ws_off < 0 or self.deterministic)
                 return c if ok else None
         return None
 

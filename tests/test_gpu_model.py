@@ -64,7 +64,17 @@ def engine_activations(net):
     ReLU) of every batch-norm convolution and the output of every residual block (keyed by its ".../Conv2d_1x1" scope) --
     the teacher-forcing points of oracle.torch_model.Model(force=...)."""
     out = {}
+    import torch
+    from multibox_amd import _lib
     for op in net.convs:
+        if getattr(op, "fused_pool", None) is not None:
+            # this layer's activation feeds only a max-pool and is never stored (the BN apply writes the pooled tensor,
+            # mbx_bn_apply_maxpool): materialise it here from the stored pre-BN output, exactly as mbx_bn_apply would have
+            sl = lambda t: t[op.beta_off:op.beta_off + op.K]
+            _lib.check(_lib.lib().mbx_bn_apply(op.y_view.ptr, op.M, op.K, sl(net.bn_mean).data_ptr(), sl(net.bn_rstd).data_ptr(),
+                                               sl(net.Bt).data_ptr(), int(op.relu), op.out.ptr, op.out.ld,
+                                               torch.cuda.current_stream().cuda_stream), "bn_apply (test)")
+            torch.cuda.synchronize()
         if op.kind in ("bn", "frozen"):
             off = 0
             for m in op.members:

@@ -492,6 +492,13 @@ def test_bn_backward_pooled(T, N, H, W, Cc, relu):
     p = torch.zeros((N, Ho, Wo, Cc), dtype=torch.bfloat16, device="cuda")
     arg = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device="cuda")
     _lib.check(l.mbx_maxpool_fwd(a.data_ptr(), H * W * Cc, Cc, N, H, W, Cc, 3, 2, p.data_ptr(), Ho * Wo * Cc, Cc, Ho, Wo, arg.data_ptr(), S()))
+    # forward twin: normalise + pool in one pass (the activation never stored) == the two launches, bit for bit
+    p2 = torch.zeros((N, Ho, Wo, Cc + 8), dtype=torch.bfloat16, device="cuda")
+    arg2 = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device="cuda")
+    _lib.check(l.mbx_bn_apply_maxpool(y.data_ptr(), N, H, W, Cc, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), relu,
+                                      p2.data_ptr() + 16, Ho * Wo * (Cc + 8), Cc + 8, Ho, Wo, arg2.data_ptr(), S()))
+    torch.cuda.synchronize()
+    assert torch.equal(p2[..., 8:], p) and torch.equal(arg2, arg) and float(p2[..., :8].float().abs().max()) == 0
     gy = torch.randn(N, Ho, Wo, Cc, generator=gen).to(torch.bfloat16).cuda()
     # reference path: pool backward -> stored da -> reduce / finalize / apply
     da = torch.zeros((N, H, W, Cc), dtype=torch.bfloat16, device="cuda")
