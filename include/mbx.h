@@ -198,6 +198,11 @@ int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
  * epilogue -- WITHOUT a launch: what mbx_conv would return short of a launch error.  For callers that keep a table of
  * measured tile choices and must not find out in the middle of a step that an entry no longer applies.               */
 int mbx_conv_supported(const mbx_conv_desc* desc /*HOST*/);
+/* TWO independent convolutions in ONE launch (sibling branches that do not fill the chip on their own: block35's two 3x3
+ * convolutions, forward and data gradient).  Applies when both descriptors resolve to the same 4-wave 128x64 / 64x64 tile
+ * with a store or store + statistics epilogue and general (non-pointwise, non stride-2-gradient) addressing; otherwise
+ * MBX_ERR_UNSUPPORTED and nothing is launched (the caller then issues two mbx_conv).  Bit-identical to two mbx_conv.     */
+int mbx_conv_pair(const mbx_conv_desc* a /*HOST*/, const mbx_conv_desc* b /*HOST*/, mbx_stream_t stream);
 size_t mbx_conv_splitk_workspace_bytes(const mbx_conv_desc* desc /*HOST*/);   /* 0 unless tile_config is a split-K one */
 
 /* Weight gradient (TF autodiff of slim.conv2d, train.py:263):

@@ -45,6 +45,7 @@ _SIGS = {
     "mbx_conv_stats_rows": (I, [P]),
     "mbx_conv": (I, [P, P]),
     "mbx_conv_supported": (I, [P]),
+    "mbx_conv_pair": (I, [P, P, P]),
     "mbx_conv_splitk_workspace_bytes": (SZ, [P]),
     "mbx_conv_wgrad": (I, [P, P, C.c_int64, I, P, P, P]),
     "mbx_conv_wgrad_scaled": (I, [P, P, C.c_int64, I, F, P, P, P]),

@@ -34,9 +34,10 @@ namespace {
 // MODE 1: pointwise (1x1, unit stride, no padding) -- the two-instruction address path, no tap walk: 60 % of the launches.
 // NSTG: ring depth.  3 = two tiles in flight; 2 = one, for 64 KB of LDS per 128x128 eight-wave block, so that TWO
 // blocks share a CU and one's epilogue (HBM-bound: skip read / accumulate / store) overlaps the other's loop.
+// (the body is a device function of (problem, block id, number of blocks) so that conv_igemm3_pair_kernel can run TWO
+// problems in one grid; conv_igemm3_kernel passes blockIdx.x / gridDim.x)
 template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0, int NSTG = 3>
-__global__ void __launch_bounds__(64 * WNW * WMW)
-conv_igemm3_kernel(const ConvK p) {
+__device__ __forceinline__ void conv_igemm3_body(const ConvK& p, const int bid_, const int nblk_) {
   constexpr bool SH = MODE == 2, PW = MODE == 1;
   static_assert(WNW * WMW == 4 || WNW * WMW == 8, "four or eight waves");
   constexpr int NT = 64 * WNW * WMW, RPP = NT / 8;      // threads, tile rows filled per DMA pass
@@ -48,7 +49,7 @@ conv_igemm3_kernel(const ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const int wn = wave % WNW, wm = wave / WNW;
-  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(bid_, nblk_);
   int split = 0;                                        // split-K slice of this block (float32 partial tiles only)
   if constexpr (EV == 5) { const int nt = p.tiles_m * p.tiles_n; split = lid / nt; lid -= split * nt; }
   const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
@@ -274,6 +275,22 @@ conv_igemm3_kernel(const ConvK p) {
       }
     }
   }
+}
+
+template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0, int NSTG = 3>
+__global__ void __launch_bounds__(64 * WNW * WMW)
+conv_igemm3_kernel(const ConvK p) {
+  conv_igemm3_body<BM, BN, WNW, WMW, EV, MODE, NSTG>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// TWO independent problems of the same instantiation in one grid (blocks [0, n0) run p0, the rest p1): the sibling
+// convolutions of a batch-norm group (block35's two 3x3 branches, forward and data gradient) are 9-11 us launches that do
+// not fill the chip; a kernel costs >= 4.4 us whatever it does.  Same code per block: results bit-identical to two launches.
+template <int BM, int BN, int WNW, int WMW, int EV, int MODE = 0, int NSTG = 3>
+__global__ void __launch_bounds__(64 * WNW * WMW)
+conv_igemm3_pair_kernel(const ConvK p0, const ConvK p1, const int n0) {
+  if ((int)blockIdx.x < n0) conv_igemm3_body<BM, BN, WNW, WMW, EV, MODE, NSTG>(p0, (int)blockIdx.x, n0);
+  else conv_igemm3_body<BM, BN, WNW, WMW, EV, MODE, NSTG>(p1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
 }
 
 
@@ -1151,10 +1168,38 @@ int choose_cfg(long M, int C_out, int desc_cfg) {
   return pick_cfg(M, C_out);
 }
 
+// mbx_conv_pair: the first pass over each descriptor runs in CAPTURE mode (ConvK.dry == 2): the launcher records what it
+// would have launched instead of launching it
+struct PairCapture { ConvK k; int bm, bn, wnw, wmw, nstg, ev, mode, valid; };
+thread_local PairCapture g_capture;
+
+template <int BM, int BN, int WNW, int WMW, int EV, int NSTG>
+int launch_pair_inst(const ConvK& a, const ConvK& b, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = NSTG * (size_t)(BM + BN) * 128;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_pair_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int n0 = a.tiles_m * a.tiles_n, n1 = b.tiles_m * b.tiles_n;
+  hipLaunchKernelGGL((conv_igemm3_pair_kernel<BM, BN, WNW, WMW, EV, 0, NSTG>), dim3(n0 + n1), dim3(64 * WNW * WMW), lds, s, a, b, n0);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 template <int BM, int BN, int WNW, int WMW, int NSTG = 3>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
+  if (k.dry == 2) {
+    g_capture.k = k; g_capture.bm = BM; g_capture.bn = BN; g_capture.wnw = WNW; g_capture.wmw = WMW; g_capture.nstg = NSTG;
+    g_capture.ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
+                   : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+    g_capture.mode = k.shift ? 2 : k.pw ? 1 : 0;
+    g_capture.valid = 1;
+    return MBX_OK;
+  }
   {
     const size_t lds = NSTG * (size_t)(BM + BN) * 128;          // the ring; the epilogue works out of the accumulators
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
@@ -1240,6 +1285,33 @@ extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
 static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry);
 extern "C" int mbx_conv(const mbx_conv_desc* d, mbx_stream_t stream) { return conv_impl(d, stream, 0); }
 extern "C" int mbx_conv_supported(const mbx_conv_desc* d) { return conv_impl(d, nullptr, 1); }
+extern "C" int mbx_conv_pair(const mbx_conv_desc* a, const mbx_conv_desc* b, mbx_stream_t stream) {
+  // both descriptors through every check of mbx_conv in capture mode; one grid if they resolved to the SAME instantiation
+  // of one of the pair kernels (4-wave 128x64 / 64x64 tiles, store or store + statistics epilogue, general addressing)
+  PairCapture ca, cb;
+  g_capture.valid = 0;
+  int st = conv_impl(a, stream, 2);
+  if (st != MBX_OK) return st;
+  if (!g_capture.valid) return MBX_ERR_UNSUPPORTED;       // (a persistent or split-K configuration)
+  ca = g_capture;
+  g_capture.valid = 0;
+  st = conv_impl(b, stream, 2);
+  if (st != MBX_OK) return st;
+  if (!g_capture.valid) return MBX_ERR_UNSUPPORTED;
+  cb = g_capture;
+  if (ca.bm != cb.bm || ca.bn != cb.bn || ca.wnw != cb.wnw || ca.wmw != cb.wmw || ca.nstg != cb.nstg || ca.ev != cb.ev ||
+      ca.mode != 0 || cb.mode != 0 || (ca.ev != 0 && ca.ev != 1) || ca.wnw != 2 || ca.wmw != 2 || ca.bn != 64)
+    return MBX_ERR_UNSUPPORTED;
+  ca.k.dry = cb.k.dry = 0;
+  hipStream_t s = mbx_s(stream);
+#define MBX_PAIR(BM_, NSTG_)                                                                                      \
+  if (ca.bm == BM_ && ca.nstg == NSTG_)                                                                           \
+    return ca.ev ? launch_pair_inst<BM_, 64, 2, 2, 1, NSTG_>(ca.k, cb.k, s) : launch_pair_inst<BM_, 64, 2, 2, 0, NSTG_>(ca.k, cb.k, s);
+  MBX_PAIR(128, 2) MBX_PAIR(128, 3) MBX_PAIR(64, 2) MBX_PAIR(64, 3)
+#undef MBX_PAIR
+  return MBX_ERR_UNSUPPORTED;
+}
+
 extern "C" size_t mbx_conv_splitk_workspace_bytes(const mbx_conv_desc* d) {
   if (!d || d->tile_config <= kSplitFlag || d->tile_config > kSplitFlag + kSplitMax) return 0;
   int ksplit, kps;

@@ -79,6 +79,8 @@ class BnGroup:
             self.koff.append(k)
             k += m.K
         self.y = self.dy = None
+        self.fwd_desc, self.dgrad_desc = {}, {}   # member index -> its forward / data-gradient descriptor
+        self.pair_fwd = self.pair_bwd = False     # a group of TWO: both convolutions in one launch (mbx_conv_pair), if it applies
         self.rows = [0] * len(members)          # statistics partial rows of each member's convolution (tile height)
         self.stats_off = [0] * len(members)     # float offsets of the members' partial rows in Net.stats_scratch
 
@@ -616,9 +618,14 @@ class Net:
                 d = self._tune(op, self._desc(op, op.y_view, stats=self.stats_scratch[op.stats_off:]), "fwd")
                 g.rows[i] = ops.conv_stats_rows(d)
                 assert g.rows[i] * op.K * 2 <= (g.stats_off[i + 1] - g.stats_off[i] if i + 1 < len(g.members) else 1 << 62)
+                g.fwd_desc[i] = d
                 if i + 1 < len(g.members):
-                    L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
+                    # (a group of two whose convolutions resolve to the same small-tile kernel run as ONE launch, issued with the
+                    # last member: mbx_conv_pair; decided below, when both descriptors exist)
+                    L.append(lambda d=d, op=op, g=g: None if g.pair_fwd else _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
                     continue
+                if len(g.members) == 2 and torch.device(self.dev).type == "cuda" and os.environ.get("MBX_CONV_PAIR", "1") != "0":
+                    g.pair_fwd = l.mbx_conv_pair(C.byref(g.fwd_desc[0]), C.byref(d), st()) == 0        # (a real launch, like the tuner's)
                 lead, n = g.members[0], len(g.members)
                 parts = (C.c_void_p * n)(*[self.stats_scratch.data_ptr() + 4 * o for o in g.stats_off])
                 rows_a, cs_a = (C.c_int32 * n)(*g.rows), (C.c_int32 * n)(*[m.K for m in g.members])
@@ -631,7 +638,10 @@ class Net:
                 def run(d=d, op=op, g=g, parts=parts, rows_a=rows_a, cs_a=cs_a, amap=amap, a_ptr=a_ptr, mean=mean, rstd=rstd,
                         mm=mm, mv=mv, var=var, beta=beta, n=n):
                     s = st()
-                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
+                    if g.pair_fwd:
+                        _lib.check(l.mbx_conv_pair(C.byref(g.fwd_desc[0]), C.byref(d), s), "pair " + op.name)
+                    else:
+                        _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     decay = self.bn_decay
                     if self.defer_moving:
                         mm, mv, decay = None, var, -1.0
@@ -914,16 +924,29 @@ class Net:
             job.scale = float(scale)
             job.dw, job.db = dw.data_ptr(), (None if db is None else db.data_ptr())
 
-            def run(op=op, pre=pre, ddesc=ddesc):
+            grp = getattr(op, "group", None) if op.kind == "bn" else None
+            if grp is not None and ddesc is not None:
+                grp.dgrad_desc[grp.members.index(op)] = ddesc
+
+            def run(op=op, pre=pre, ddesc=ddesc, grp=grp):
                 s = st()
                 if pre is not None and not (op.kind == "bn" and self._probe_skip_bn_bwd):
                     pre(s)
                 if ddesc is not None:
+                    if grp is not None and grp.pair_bwd:
+                        # both members' data gradients in ONE launch, issued with the last member (first in backward order)
+                        if op is grp.members[-1]:
+                            _lib.check(l.mbx_conv_pair(C.byref(ddesc), C.byref(grp.dgrad_desc[0]), s), "dgrad pair " + op.name)
+                        return
                     ddesc.max_workgroups = self.cu_cap          # (persistent launches; baked into a captured graph)
                     _lib.check(l.mbx_conv(C.byref(ddesc), s), "dgrad " + op.name)
             L.append(run)
             self.bwd_ops.append(op)
             self.bwd_jobs.append(job)
+        if torch.device(self.dev).type == "cuda" and os.environ.get("MBX_CONV_PAIR", "1") != "0":
+            for grp in self.bn_groups:
+                if len(grp.members) == 2 and len(grp.dgrad_desc) == 2:
+                    grp.pair_bwd = l.mbx_conv_pair(C.byref(grp.dgrad_desc[1]), C.byref(grp.dgrad_desc[0]), st()) == 0
         assert not self.pending_acc, "a residual block's input gradient was never written"
         self.bwd_launches = L
         self.fwd_launches = self._build_forward_launches()

@@ -139,6 +139,61 @@ def test_conv_epilogues(T):
     assert ok, "accumulate: " + msg
 
 
+@pytest.mark.parametrize("cfg", [0, 10, 11, 5, 6])
+def test_conv_pair_bit_identical(T, cfg):
+    """mbx_conv_pair (round 4): two independent convolutions of different shape (block35's sibling 3x3 branches: 32 -> 32 and
+    32 -> 48 channels on slices of one buffer; a 5x5 beside a 3x3) in ONE grid == two mbx_conv launches, bit for bit, forward
+    with statistics and as data gradients; a configuration the pair kernels do not cover is refused (-2), nothing written."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    gen = torch.Generator().manual_seed(cfg + 3)
+    N, H, W = 4, 35, 35
+    zb = ops.View.alloc(N, H, W, 240, zero=True)
+    zb.tensor().copy_(torch.randn(N, H, W, 240, generator=gen).to(torch.bfloat16))
+    stream = torch.cuda.current_stream().cuda_stream
+    shapes = [((0, 32), 32, 3, 3, 1), ((32, 32), 48, 5, 5, 2)]           # (input slice, C_out, R, S, pad)
+
+    def descs(transposed):
+        out = []
+        for (c0, ci), co, R, S_, pad in shapes:
+            if transposed:
+                cin, cout = co, ci
+                x = ops.View.alloc(N, H, W, cin, zero=True)
+                x.tensor().copy_(torch.randn(N, H, W, cin, generator=torch.Generator().manual_seed(co)).to(torch.bfloat16))
+            else:
+                cin, cout, x = ci, co, zb.slice(c0, ci)
+            w = (torch.randn(cout, R, S_, cin, generator=torch.Generator().manual_seed(co + R)) / (R * S_ * cin) ** 0.5).to(torch.bfloat16).cuda()
+            ys = [ops.View.alloc(N, H, W, cout + 8, zero=True).slice(8, cout) for _ in range(2)]
+            ds = []
+            for y in ys:
+                d = ops.make_desc(x, w, cout, R, S_, 1, pad, pad, y, transposed=transposed)
+                d.tile_config = cfg
+                stt = None
+                if not transposed:
+                    stt = torch.zeros((ops.conv_stats_rows(d) + 2, cout, 2), device="cuda")
+                    d = ops.make_desc(x, w, cout, R, S_, 1, pad, pad, y, stats=stt)
+                    d.tile_config = cfg
+                ds.append((d, y, stt, x, w))
+            out.append(ds)
+        return out
+    for transposed in (0, 1):
+        (a0, a1), (b0, b1) = descs(transposed)
+        rc = l.mbx_conv_pair(C.byref(a1[0]), C.byref(b1[0]), stream)
+        torch.cuda.synchronize()
+        if cfg == 6:                                                      # tile_config 6 = the eight-wave 256x128 tile: not a pair kernel
+            assert rc == -2 and float(a1[1].tensor().float().abs().max()) == 0
+            continue
+        assert rc == 0
+        assert l.mbx_conv(C.byref(a0[0]), stream) == 0 and l.mbx_conv(C.byref(b0[0]), stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a0[1].tensor(), a1[1].tensor()) and torch.equal(b0[1].tensor(), b1[1].tensor())
+        assert float(a0[1].tensor().float().abs().max()) > 0 and float(b0[1].tensor().float().abs().max()) > 0
+        if not transposed:
+            assert torch.equal(a0[2], a1[2]) and torch.equal(b0[2], b1[2])
+
+
 @pytest.mark.parametrize("g", [("sk1", 16, 8, 8, 1536, 96, 3, 3, 1, (1, 1, 1, 1)), ("sk2", 16, 8, 8, 1536, 256, 3, 3, 2, (0, 0, 1, 1)),
                                ("sk3", 3, 9, 9, 200, 40, 3, 3, 1, (1, 1, 1, 1)), ("sk4", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3))],
                          ids=["head_6x6", "head_s2", "ragged", "1x7"])

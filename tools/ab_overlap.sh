@@ -1,6 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_nnops.py -x -q -m gpu 2>&1 | tail -4
-python -m pytest tests/test_gpu_model.py tests/test_gpu_assembled.py -x -q -m gpu -k "not saturation and not side_stream and not soak" 2>&1 | tail -6
-bash tools/ab_env.sh - "MBX_POOL_FUSE=0" | grep rep
-python tools/step_trace.py gpurun_out/step_trace_r4f.tsv 2>/dev/null | tail -31
+python -m pytest tests/test_gpu_conv.py -x -q -m gpu -k "pair or igemm5 or dgrad" 2>&1 | tail -4
+MBX_DETERMINISTIC=1 python tools/overlap_check.py 96 2 16 2>&1 | tail -2
+bash tools/ab_env.sh - "MBX_CONV_PAIR=0" | grep rep
+python tools/step_trace.py gpurun_out/step_trace_r4g.tsv 2>/dev/null | head -8
