@@ -948,16 +948,32 @@ avgpool_fwd_kernel(const unsigned short* __restrict__ x, long long xs, int ldx, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     int cnt = 0;
-    for (int r = 0; r < k; ++r)
-      for (int s = 0; s < k; ++s) {
-        const int h = oh - pad + r, w = ow - pad + s;
-        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
-        float f[8];
-        unpack8(ld8(x + n * xs + ((long long)h * W + w) * ldx + c), f);
+    // four taps' loads in flight at a time, added in tap order (the 8x8 head pool read its 64 taps one dependent load after
+    // the other: 24 us for 12 MB)
+    for (int r = 0; r < k; ++r) {
+      const int h = oh - pad + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      const unsigned short* row = x + n * xs + (long long)h * W * ldx + c;
+      for (int s0 = 0; s0 < k; s0 += 4) {
+        u32x4 v[4];
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += f[j];
-        ++cnt;
+        for (int q = 0; q < 4; ++q) {
+          const int w = ow - pad + s0 + q;
+          ok[q] = s0 + q < k && (unsigned)w < (unsigned)W;
+          v[q] = ok[q] ? ld8(row + (long long)w * ldx) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!ok[q]) continue;
+          float f[8];
+          unpack8(v[q], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += f[j];
+          ++cnt;
+        }
       }
+    }
     const float inv = 1.0f / (float)cnt;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] *= inv;

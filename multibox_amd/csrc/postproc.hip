@@ -66,8 +66,11 @@ __device__ __forceinline__ Cand cand_shfl_xor(const Cand& c, int o) {
 
 // One workgroup per image.  Rectangular LSAP on the transposed problem (rows = gt boxes,
 // columns = predictions), shortest augmenting path with float64 duals, as scipy's
-// linear_sum_assignment (loss.py:40).  LDS: 36 B per prediction + 16 B per gt.
-__global__ void __launch_bounds__(kThreads)
+// linear_sum_assignment (loss.py:40).  LDS: 36 B per prediction + 16 B per gt.  256 threads per image up to 1536 predictions,
+// 512 beyond (round 4, tools/match_bench.py on random boxes: P = 3199 / G = 100 812 -> 589 us; P = 646 is fastest at 256:
+// 47 us against 84 with one wave -- the column scan, not the barriers, is what an iteration costs; staging the locations in
+// LDS changed nothing: they are L1 hits).
+__global__ void __launch_bounds__(1024)
 match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
              const float4* __restrict__ gt, const int* __restrict__ n_gt, float alpha, int P, int G,
              int* __restrict__ match, int* __restrict__ status) {
@@ -81,11 +84,12 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
   int* SC = row4col + P;                                  // [P]
   int* col4row = SC + P;                                  // [G]
   int* SR = col4row + G;                                  // [G]
-  __shared__ Cand wave_best[kWaves];
+  __shared__ Cand wave_best[16];
   __shared__ int sh_i, sh_sink, sh_bad;
   __shared__ double sh_min;
 
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int nt = (int)blockDim.x, nwaves = nt >> 6;       // 256 or 512 threads (mbx_match)
   const float4* loc = decoded + (size_t)b * P;
   const float* cf = conf + (size_t)b * P;
   const float4* g = gt + (size_t)b * G;
@@ -96,7 +100,7 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
   if (tid == 0) sh_bad = 0;
   __syncthreads();
   int bad = 0;
-  for (int j = tid; j < P; j += kThreads) {
+  for (int j = tid; j < P; j += nt) {
     mt[j] = -1;
     const float c = cf[j];
     const float lc = logf(c);                              // loss.py:21
@@ -110,7 +114,7 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
     const float4 l = loc[j];
     if (!(isfinite(lc) && isfinite(l1c) && isfinite(l.x) && isfinite(l.y) && isfinite(l.z) && isfinite(l.w))) bad = 1;
   }
-  for (int i = tid; i < G; i += kThreads) {
+  for (int i = tid; i < G; i += nt) {
     u[i] = 0.0;
     col4row[i] = -1;
     if (i < n) {
@@ -125,8 +129,8 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
   if (sh_bad) { if (tid == 0) status[b] = 2; return; }
 
   for (int cur = 0; cur < n; ++cur) {
-    for (int j = tid; j < P; j += kThreads) { spc[j] = INFINITY; SC[j] = 0; }
-    for (int i = tid; i < n; i += kThreads) SR[i] = 0;
+    for (int j = tid; j < P; j += nt) { spc[j] = INFINITY; SC[j] = 0; }
+    for (int i = tid; i < n; i += nt) SR[i] = 0;
     if (tid == 0) { sh_i = cur; sh_sink = -1; sh_min = 0.0; }
     __syncthreads();
     while (true) {
@@ -135,7 +139,7 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
       const float4 gi = g[i];
       const double ui = u[i];
       Cand best; best.val = INFINITY; best.j = -1; best.free_ = 0;
-      for (int j = tid; j < P; j += kThreads) {
+      for (int j = tid; j < P; j += nt) {
         if (SC[j]) continue;
         const float2 ll = lcl[j];
         // scipy: r = minVal + cost[i][j] - u[i] - v[j]
@@ -154,7 +158,7 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
       __syncthreads();
       if (tid == 0) {
         Cand bb = wave_best[0];
-        for (int w = 1; w < kWaves; ++w) if (cand_better(wave_best[w], bb)) bb = wave_best[w];
+        for (int w = 1; w < nwaves; ++w) if (cand_better(wave_best[w], bb)) bb = wave_best[w];
         if (bb.j < 0 || !(bb.val < INFINITY)) {
           sh_sink = -2;                                    // infeasible
         } else {
@@ -172,11 +176,11 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
     if (sink == -2) { if (tid == 0) status[b] = 2; return; }
     const double min_val = sh_min;
     // dual updates
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += nt) {
       if (i == cur) u[i] += min_val;
       else if (SR[i]) u[i] += min_val - spc[col4row[i]];
     }
-    for (int j = tid; j < P; j += kThreads)
+    for (int j = tid; j < P; j += nt)
       if (SC[j]) v[j] -= min_val - spc[j];
     __syncthreads();
     if (tid == 0) {                                        // augment along the path
@@ -192,7 +196,7 @@ match_kernel(const float4* __restrict__ decoded, const float* __restrict__ conf,
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += kThreads) mt[col4row[i]] = i;
+  for (int i = tid; i < n; i += nt) mt[col4row[i]] = i;
   if (tid == 0) status[b] = 0;
 }
 
@@ -365,12 +369,14 @@ extern "C" int mbx_match(const float* decoded, const float* conf, const float* g
   if (B == 0) return MBX_OK;
   const size_t lds = match_lds_bytes(P, G);
   if (lds > 150 * 1024) return MBX_ERR_UNSUPPORTED;        // P > ~4200 at G=100
+  static const int force_nt = getenv("MBX_MATCH_THREADS") ? atoi(getenv("MBX_MATCH_THREADS")) : 0;      // (tools/match_bench.py)
+  const int nthreads = force_nt ? force_nt : (P > 1536 ? 512 : kThreads);
   MBX_ENTER();
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return MBX_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(match_kernel, dim3(B), dim3(kThreads), lds, mbx_s(stream),
+  hipLaunchKernelGGL(match_kernel, dim3(B), dim3(nthreads), lds, mbx_s(stream),
                      reinterpret_cast<const float4*>(decoded), conf, reinterpret_cast<const float4*>(gt), n_gt,
                      alpha, P, G, match, status);
   MBX_LAUNCH_CHECK();
