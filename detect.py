@@ -90,7 +90,8 @@ def main():
         from multibox_amd.augment import PatchExtractor
         # the host decodes and lays out the patches (detect.py:183-281); scaling + bilinear resize run on the GPU
         on_device = bool(cfg.get("INPUT_AUGMENT_ON_DEVICE", True))
-        extractor = PatchExtractor(B, S) if on_device else None
+        depth = int(cfg.get("INPUT_PREFETCH_BATCHES", 3))
+        extractor = PatchExtractor(B, S, slots=depth + 2) if on_device else None
         # rank-sharded INPUT: this rank decodes only the records that feed its own batches
         in_stats = {}
         # produced by a background thread a few batches ahead (record parsing, patch planning and batch assembly are host
@@ -98,7 +99,14 @@ def main():
         from multibox_amd.inputs import prefetched
         stream = detect_batches(args.tfrecords, cfg, B, keep_partial=args.keep_partial_batch, device_patches=on_device,
                                 rank=rank, world=world, stats=in_stats)
-        depth = int(cfg.get("INPUT_PREFETCH_BATCHES", 3))
+        if on_device:
+            # the HOST half of the patch extraction (24 MB of pixels per batch into pinned staging, the item table) runs in the
+            # producer thread too; this thread only uploads and launches (PatchExtractor.prepare / launch)
+            def staged(it):
+                for b in it:
+                    b["staged"] = extractor.prepare(b.pop("sources"), b.pop("patches"))
+                    yield b
+            stream = staged(stream)
         batches = ((b["batch_index"], b) for b in (prefetched(stream, depth) if depth > 0 else stream))
     else:
         in_stats, extractor = None, None
@@ -166,8 +174,8 @@ def main():
                                  batch["max_to_keep"], batch["image_hw"], device="cpu")
         meta_host[slot].copy_(meta)                     # slot's previous upload finished before its results were read (finish)
         ev[slot][0].record()
-        if "sources" in batch:
-            extractor(batch["sources"], batch["patches"])                       # -> x_static (its own output buffer)
+        if "staged" in batch:
+            extractor.launch(batch["staged"])                                   # -> x_static (its own output buffer)
         else:
             x_static.copy_(torch.from_numpy(batch["images"]), non_blocking=False)
         meta_static.copy_(meta_host[slot], non_blocking=True)

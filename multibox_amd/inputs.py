@@ -108,10 +108,104 @@ def detect_patches_for_image(image01, image_hw, cfg):
     return patches, offs, dims, flips, rests, keeps
 
 
-def _decoded_ahead(planned, threads, window=32):
+# ---- JPEG decoding in worker PROCESSES (round 4): the decoded pixels come back through one shared-memory block
+_SHM = None                       # worker side: the attached block
+
+
+def _decode_worker_init(shm_name):
+    global _SHM
+    from multiprocessing import shared_memory
+    _SHM = shared_memory.SharedMemory(name=shm_name)
+
+
+def _decode_into_shm(offset, capacity, jpeg_bytes):
+    """Worker: decode one JPEG into the shared block at `offset`; (H, W), or None if it needs more than `capacity` bytes."""
+    u8 = decode_image_u8(jpeg_bytes)
+    if u8.size > capacity:
+        return None
+    np.frombuffer(_SHM.buf, np.uint8, u8.size, offset)[:] = u8.reshape(-1)
+    return int(u8.shape[0]), int(u8.shape[1])
+
+
+class _DecodePool:
+    """`processes` spawned workers (no torch, no GPU) decode JPEGs into slots of one shared-memory block; the parent wraps a
+    finished slot as a numpy view whose finalizer gives the slot back, so a picture lives exactly as long as something
+    (a pending patch, a batch being staged) refers to it.  No free slot, or a picture larger than a slot: decoded in
+    this process instead (never a wait: the consumer of the slots is the caller itself)."""
+
+    def __init__(self, processes, slots=160, slot_bytes=3 << 19):
+        import multiprocessing as mp
+        import queue
+        from concurrent.futures import ProcessPoolExecutor
+        from multiprocessing import shared_memory
+        self.slot_bytes, self.slots, self._closing = int(slot_bytes), int(slots), False
+        self.shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
+        self.free = queue.SimpleQueue()
+        for i in range(int(slots)):
+            self.free.put(i)
+        self.pool = ProcessPoolExecutor(max_workers=int(processes), mp_context=mp.get_context("spawn"),
+                                        initializer=_decode_worker_init, initargs=(self.shm.name,))
+
+    def submit(self, jpeg_bytes):
+        """-> a handle for result()."""
+        try:
+            slot = self.free.get_nowait()
+        except Exception:                                       # (queue.Empty) every slot is referenced: decode here, later
+            return (None, jpeg_bytes)
+        return (slot, self.pool.submit(_decode_into_shm, slot * self.slot_bytes, self.slot_bytes, jpeg_bytes), jpeg_bytes)
+
+    def result(self, handle):
+        import weakref
+        if handle[0] is None:
+            return decode_image_u8(handle[1])
+        slot, fut, jpeg_bytes = handle
+        hw = fut.result()
+        if hw is None:                                          # larger than a slot
+            self.free.put(slot)
+            return decode_image_u8(jpeg_bytes)
+        arr = np.ndarray((hw[0], hw[1], 3), np.uint8, buffer=self.shm.buf, offset=slot * self.slot_bytes)
+        # views of `arr` keep it alive through .base; the bound method keeps THIS object -- and with it the mapping -- alive
+        # as long as a picture is (numpy takes no buffer export: SharedMemory.close() would unmap under a live array)
+        weakref.finalize(arr, self._release, slot)
+        return arr
+
+    def _release(self, slot):
+        self.free.put(slot)
+        if self._closing and self.free.qsize() >= self.slots:
+            self.shm.close()
+
+    def close(self):
+        """Stop the workers and remove the block's name; the mapping itself goes when the last picture does."""
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        try:
+            self.shm.unlink()
+        except FileNotFoundError:
+            pass
+        self._closing = True
+        if self.free.qsize() >= self.slots:
+            self.shm.close()
+
+
+def _decoded_ahead(planned, threads, window=32, processes=0):
     """(example, plan, mine, decoded uint8 image or None) in record order for _planned_examples() items: the JPEGs of the
-    records this rank needs are decoded `threads` at a time ahead of the consumer (PIL releases the GIL while it
-    decodes); the others pass through undecoded."""
+    records this rank needs are decoded ahead of the consumer -- by `threads` threads (PIL releases the GIL while it decodes)
+    or, on request, by `processes` worker processes through shared memory (_DecodePool); the others pass through undecoded."""
+    if processes > 0:
+        from collections import deque
+        pool = _DecodePool(processes)
+        try:
+            pending = deque()
+            for ex, plan, mine in planned:
+                pending.append((ex, plan, mine, pool.submit(ex["image/encoded"][0]) if mine else None))
+                if len(pending) >= window:
+                    e, pl, m, h = pending.popleft()
+                    yield e, pl, m, (pool.result(h) if h is not None else None)
+            while pending:
+                e, pl, m, h = pending.popleft()
+                yield e, pl, m, (pool.result(h) if h is not None else None)
+        finally:
+            pool.close()
+        return
     if threads <= 1:
         for ex, plan, mine in planned:
             yield ex, plan, mine, (decode_image_u8(ex["image/encoded"][0]) if mine else None)
@@ -157,7 +251,7 @@ def _planned_examples(examples, cfg, batch_size, rank, world, stats):
 
 
 def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patches=False, decode_threads=None, rank=0,
-                   world=1, stats=None):
+                   world=1, stats=None, decode_processes=None):
     """Yield dicts of numpy arrays: images [B,S,S,3], offsets [B,2], dims [B,2], is_flipped [B,1],
     restrictions [B,4], max_to_keep [B,1], image_hw [B,2], image_ids [B] -- the fetches of detect.py:398-406 -- plus
     "batch_index", the batch's position in the single-process stream (tf.train.batch order, detect.py:283-292).
@@ -168,7 +262,10 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patche
     device_patches=True leaves the pixels to the GPU (mbx_extract_patches): instead of "images" a batch carries
     "sources" (the decoded uint8 images it touches) and "patches" [(source index, window, flip_source) or None for
     padding]: multibox_amd.augment.PatchExtractor turns them into the [B,S,S,3] tensor on the device.  The JPEGs are
-    then decoded by decode_threads threads (default NUM_INPUT_THREADS) ahead of the consumer, in record order."""
+    then decoded ahead of the consumer, in record order: by decode_threads threads (default NUM_INPUT_THREADS) or, with
+    decode_processes > 0 (NUM_DECODE_PROCESSES, default 0), by that many worker processes through shared memory -- measured
+    SLOWER end to end (8192 VGA records, BATCH_SIZE 256: 4 threads 16 300 patches/s, 4 processes 15 700, 8 processes 15 500,
+    8 threads 13 800): with the pixels' staging copy in the producer thread the decode is not what limits detect.py."""
     buf = {k: [] for k in ("images", "offsets", "dims", "is_flipped", "restrictions", "max_to_keep", "image_hw", "image_ids")}
     S = int(cfg.INPUT_SIZE)
 
@@ -196,11 +293,12 @@ def detect_batches(tfrecords, cfg, batch_size, keep_partial=False, device_patche
             del buf[k][:batch_size]
         return out
     threads = int(decode_threads if decode_threads is not None else cfg.get("NUM_INPUT_THREADS", 4)) if device_patches else 1
+    procs = int(decode_processes if decode_processes is not None else cfg.get("NUM_DECODE_PROCESSES", 0)) if device_patches else 0
     planned = _planned_examples(_records(tfrecords), cfg, batch_size, rank, world, stats)
     if world == 1 and not device_patches:
         decoded = ((ex, plan, True, None) for ex, plan, _ in planned)
     else:
-        decoded = _decoded_ahead(planned, threads)
+        decoded = _decoded_ahead(planned, threads, processes=procs)
     next_index = [0]
 
     def emit_mine():

@@ -321,3 +321,37 @@ def test_detect_patch_geometry_matches_extract_patches(tmp_path):
             src = src[:, ::-1] if fs else src
             assert np.array_equal(I.resize_bilinear_tf(src[y:y + h, x:x + w], 299, 299), hb["images"][i])
     assert any(p is None for p in dev[-1]["patches"])
+
+
+def test_decode_process_pool_matches_thread_path(tmp_path):
+    """NUM_DECODE_PROCESSES > 0 (round 4): JPEGs decoded by worker processes through one shared-memory block give the batches
+    of the thread path, sources included; pictures outlive the pool (the mapping goes with the last picture), slots are
+    recycled, a picture larger than a slot or a full ring falls back to decoding in this process."""
+    path = str(tmp_path / "p.tfrecords")
+    _make_records(path, [(320, 420, []), (300, 300, []), (412, 412, []), (200, 640, []), (480, 640, [])])
+    cfg = Cfg(dict(INPUT_SIZE=299, DETECTION=dict(
+        USE_ORIGINAL_IMAGE=True, ORIGINAL_IMAGE_MAX_TO_KEEP=200, USE_FLIPPED_ORIGINAL_IMAGE=True, FLIPPED_IMAGE_MAX_TO_KEEP=100,
+        CROPS=[dict(HEIGHT=299, WIDTH=299, HEIGHT_STRIDE=113, WIDTH_STRIDE=113, FLIP=False, MAX_TO_KEEP=50)])))
+    a = list(I.detect_batches([path], cfg, 4, keep_partial=True, device_patches=True, decode_processes=0))
+    b = list(I.detect_batches([path], cfg, 4, keep_partial=True, device_patches=True, decode_processes=2))
+    assert len(a) == len(b) > 2
+    for x, y in zip(a, b):
+        assert x["patches"] == y["patches"] and len(x["sources"]) == len(y["sources"])
+        assert all(np.array_equal(s, t) for s, t in zip(x["sources"], y["sources"]))
+    # the pool on its own: three slots of 256 KB for six pictures, the last of them larger than a slot
+    import io
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    shapes = [(120, 160), (121, 160), (122, 160), (123, 160), (124, 160), (400, 400)]
+    jpegs = []
+    for h, w in shapes:
+        buf = io.BytesIO()
+        Image.fromarray(rng.randint(0, 255, (h, w, 3)).astype(np.uint8)).save(buf, format="JPEG", quality=95)
+        jpegs.append(buf.getvalue())
+    pool = I._DecodePool(2, slots=3, slot_bytes=1 << 18)
+    outs = [pool.result(h) for h in [pool.submit(j) for j in jpegs]]
+    assert all(np.array_equal(o, I.decode_image_u8(j)) for o, j in zip(outs, jpegs))
+    pool.close()                                          # pictures stay readable after close()
+    assert all(np.array_equal(o, I.decode_image_u8(j)) for o, j in zip(outs, jpegs))
+    del outs
+    assert pool.free.qsize() == 3

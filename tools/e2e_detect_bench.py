@@ -16,6 +16,7 @@ INPUT_SIZE : 299
 NUM_TRAIN_EXAMPLES : 56945
 NUM_TRAIN_ITERATIONS : 1000000
 NUM_INPUT_THREADS : %(threads)s
+NUM_DECODE_PROCESSES : %(procs)s
 INPUT_AUGMENT_ON_DEVICE : %(on_device)s
 DETECTION :
   USE_ORIGINAL_IMAGE : true
@@ -56,10 +57,10 @@ def main():
     CK.save(logdir, tr)
     del tr, net
     torch.cuda.empty_cache()
-    # E2E_BATCH / E2E_THREADS: BATCH_SIZE and NUM_INPUT_THREADS of the run (64 / 8); E2E_HOST=1 also times the host input path (~60 s)
+    # E2E_BATCH / E2E_THREADS / E2E_PROCS: BATCH_SIZE, NUM_INPUT_THREADS and NUM_DECODE_PROCESSES of the run (64 / 8 / 0); E2E_HOST=1 also times the host input path (~60 s)
     for on_device in (("true", "false") if os.environ.get("E2E_HOST") else ("true",)):
         cfg = os.path.join(tmp, "e2e_det_%s.yaml" % on_device)
-        open(cfg, "w").write(CFG % dict(on_device=on_device, batch=os.environ.get("E2E_BATCH", "64"), threads=os.environ.get("E2E_THREADS", "8")))
+        open(cfg, "w").write(CFG % dict(on_device=on_device, batch=os.environ.get("E2E_BATCH", "64"), threads=os.environ.get("E2E_THREADS", "8"), procs=os.environ.get("E2E_PROCS", "0")))
         prof = ["-m", "cProfile", "-s", "tottime"] if os.environ.get("MBX_E2E_PROFILE") else []      # where the host time goes
         r = subprocess.run([sys.executable] + prof + [os.path.join(ROOT, "detect.py"), "--priors", pri, "--checkpoint_path", logdir,
                             "--config", cfg, "--save_dir", os.path.join(tmp, "e2e_det_out"), "--tfrecords", rec],
