@@ -19,22 +19,50 @@ wg = [r for r in step if "conv_wgrad2" in r["Kernel_Name"]]
 net = Net(batch=B, device="cpu")
 convs = [op for op in net.fwd if isinstance(op, ConvOp)]
 bw = [op for op in reversed(net.fwd) if isinstance(op, ConvOp) and op.trainable]
-n_f = len(convs)
-fwd = ig[:n_f]
-dg = ig[n_f:]
-dgi = iter(dg)
+# Walk the igemm launches in order.  A batch-norm group of two may run as ONE pair launch (conv_igemm3_pair_kernel, issued at
+# the position of the group's last member, forward, and of its first member in backward order): its time is split between
+# the two convolutions by their FLOPs.
+kname = lambda r: ("pair:" if "pair_kernel" in r["Kernel_Name"] else "i5:" if "igemm5" in r["Kernel_Name"] else "i7:" if "igemm7" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1)
+flops = lambda op: 2.0 * op.M * op.K * op.R * op.S * op.Cin
 rec = {}
-for op, r in zip(convs, fwd):
-    rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": ("i5:" if "igemm5" in r["Kernel_Name"] else "i7:" if "igemm7" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1), "fwd_grid": r["Grid_Size_X"]}
+pos = 0
+for op in convs:
+    g = getattr(op, "group", None)
+    r = ig[pos]
+    if g is not None and len(g.members) == 2 and "pair_kernel" in r["Kernel_Name"]:
+        if op is g.members[0]:
+            continue                                   # its launch is the pair at the last member's position
+        a, b = g.members
+        fa, fb = flops(a), flops(b)
+        for m, f in ((a, fa), (b, fb)):
+            rec[id(m)] = {"op": m, "fwd": dur(r) * f / (fa + fb), "fwd_k": kname(r), "fwd_grid": r["Grid_Size_X"]}
+        pos += 1
+        continue
+    rec[id(op)] = {"op": op, "fwd": dur(r), "fwd_k": kname(r), "fwd_grid": r["Grid_Size_X"]}
+    pos += 1
+dg = ig[pos:]
+dgi = iter(dg)
 if len(wg) == len(bw):          # per-layer weight-gradient launches (round 1); the grouped launches have no per-layer time
     for op, r in zip(bw, wg):
         rec[id(op)]["wg"] = dur(r)
         rec[id(op)]["wg_grid"] = "%sx%s" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"])
+paired = set()
 for op in bw:
     if op.need_dx:
+        if id(op) in paired:
+            continue
         d = next(dgi)
+        g = getattr(op, "group", None)
+        if g is not None and len(g.members) == 2 and "pair_kernel" in d["Kernel_Name"]:
+            a, b = g.members
+            fa, fb = flops(a), flops(b)
+            for m, f in ((a, fa), (b, fb)):
+                rec[id(m)]["dg"] = dur(d) * f / (fa + fb)
+                rec[id(m)]["dg_k"] = kname(d)
+                paired.add(id(m))
+            continue
         rec[id(op)]["dg"] = dur(d)
-        rec[id(op)]["dg_k"] = ("i5:" if "igemm5" in d["Kernel_Name"] else "i7:" if "igemm7" in d["Kernel_Name"] else "") + re.search(r"<([^>]*)>", d["Kernel_Name"]).group(1)
+        rec[id(op)]["dg_k"] = kname(d)
 print("%-58s %7s %5s %5s %3s | %7s %7s %7s | TF/s fwd dg wg | %s" % ("layer", "M", "Cin", "K", "RS", "fwd us", "dg us", "wg us", "cfg"))
 agg = {}
 tot = [0, 0, 0]
