@@ -94,12 +94,24 @@ def _conv_flops(d):
 def _work_table():
     W = {}
     W["mbx_conv"] = ("igemm", "mfma", lambda a: _conv_flops(a[0]._obj))
+    W["mbx_conv_pair"] = ("igemm", "mfma", lambda a: _conv_flops(a[0]._obj) + _conv_flops(a[1]._obj))      # two sibling convs, one launch
     W["mbx_conv_wgrad_scaled"] = ("wgrad", "mfma", lambda a: _conv_flops(a[0]._obj))
     W["mbx_conv_wgrad_grouped"] = ("wgrad", "mfma", lambda a: float(a[1]._obj.flops))  # mbx_wgrad_plan_info.flops
     W["mbx_bn_apply_fused"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[6] * a[7])
+    W["mbx_bn_finalize"] = ("bn_fwd", "hbm", lambda a: 0.0)
+    W["mbx_bn_finalize_parts"] = ("bn_fwd", "hbm", lambda a: 0.0)
+    W["mbx_bn_apply_mapped"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[1] * a[2])                  # a batch-norm group: [M, sum K]
+    # normalise + 3x3/2 max-pool in one pass: y read once, pooled tensor + argmax bytes written (a[1..4] = N,H,W,C; a[12], a[13] = Ho, Wo)
+    W["mbx_bn_apply_maxpool"] = ("bn_fwd", "hbm", lambda a: (2.0 * a[1] * a[2] * a[3] + 3.0 * a[1] * a[12] * a[13]) * a[4])
     W["mbx_bn_bwd_onepass"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[4] * a[5])
+    W["mbx_bn_bwd_onepass_mapped"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[4] * a[5])
     W["mbx_bn_bwd_reduce"] = ("bn_bwd", "hbm", lambda a: 4.0 * a[6] * a[7])
     W["mbx_bn_bwd_apply"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[6] * a[7])
+    W["mbx_bn_bwd_reduce_mapped"] = ("bn_bwd", "hbm", lambda a: 4.0 * a[6] * a[7])
+    W["mbx_bn_bwd_apply_mapped"] = ("bn_bwd", "hbm", lambda a: 6.0 * a[6] * a[7])
+    # pooled forms (a[4..8] = N,H,W,Ho,Wo; a[11] = C): y (+ dy) per element, pool gradient + argmax per pooled element
+    W["mbx_bn_bwd_reduce_pooled"] = ("bn_bwd", "hbm", lambda a: (2.0 * a[4] * a[5] * a[6] + 3.0 * a[4] * a[7] * a[8]) * a[11])
+    W["mbx_bn_bwd_apply_pooled"] = ("bn_bwd", "hbm", lambda a: (4.0 * a[4] * a[5] * a[6] + 3.0 * a[4] * a[7] * a[8]) * a[11])
     W["mbx_bn_bwd_finalize"] = ("bn_bwd", "hbm", lambda a: 0.0)
     return W
 
@@ -166,8 +178,11 @@ def timed_eager_pass(run, entry_points=None):
     return out, pair_ms, plain_ms
 
 
-KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel")), ("wgrad", ("conv_wgrad",)),
-                  ("bn_fwd", ("bn_finalize_kernel", "bn_apply_kernel", "bn_apply_fused_kernel")), ("bn_bwd", ("bn_bwd_",)))
+# (the pair launch runs two igemm3 problems in one grid; the split-K reduce launch is the epilogue of its igemm3 slices)
+KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel",
+                             "splitk_reduce_kernel")), ("wgrad", ("conv_wgrad",)),
+                  ("bn_fwd", ("bn_finalize_kernel", "bn_finalize_parts_kernel", "bn_apply_kernel", "bn_apply_fused_kernel",
+                              "bn_apply_maxpool3s2_kernel")), ("bn_bwd", ("bn_bwd_",)))
 
 
 def traced_kernel_times(step_fn, steps=3):
@@ -223,7 +238,7 @@ def committed_traffic():
             if any(j.get(k) != v for k, v in shas.items()):
                 continue
             n = mb = 0.0
-            for kern in ("conv_igemm3_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel"):
+            for kern in ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel"):
                 if kern in j:
                     n += j[kern]["calls"]
                     mb += j[kern]["calls"] * j[kern]["MB_per_launch"]
@@ -259,13 +274,13 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
-    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel (implicit-GEMM convolution: forward + data-gradient launches)",
+    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel (implicit-GEMM convolution: forward + data-gradient launches)",
             "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
             "ms_per_step": round(d["ms"], 3),
             "timing": ("kernel begin/end timestamps of 3 real (graph-replayed) steps, recorded live by the ROCm tracer via "
-                       "torch.profiler: the timestamps of a rocprofv3 kernel trace (profiles/r03_bench_b64_kernel_stats.csv)"
+                       "torch.profiler: the timestamps of a rocprofv3 kernel trace (profiles/r04_bench_b64_kernel_stats.csv)"
                        if traced is not None else
                        "HIP events around every launch of one eager pass minus one measured marker cost per interval "
                        "(tracer unavailable)"),
