@@ -1615,7 +1615,9 @@ static void plan_jobs(const mbx_wgrad_job* jobs, int n_jobs, int flags, std::vec
     total += (double)pj[j].tiles_n * pj[j].tiles_k * pj[j].steps * pj[j].step_cost;
   }
   const double share = total / plan_cus();
-  double wmax = share / 4.0;
+  static double wdiv = 0.0;
+  if (wdiv == 0.0) { const char* e = getenv("MBX_WG_WMAX_DIV"); wdiv = e ? atof(e) : 4.0; if (wdiv <= 0.0) wdiv = 4.0; }   // (A/B knob)
+  double wmax = share / wdiv;
   if (wmax < 16.0) wmax = 16.0;
   for (int j = 0; j < n_jobs; ++j) {
     int splits = (flags & MBX_WGRAD_DETERMINISTIC) ? 1 : (int)((pj[j].steps * pj[j].step_cost + wmax - 1) / wmax);

@@ -6,7 +6,7 @@ for defs in "$@"; do
   d="$defs"; [ "$d" = "-" ] && d=""
   MBX_BUILD_DEFS="$d" python -c "from multibox_amd import build; build.build(force=True, verbose=False)" || exit 1
   for rep in 1 2; do
-    python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-detect --no-roofline 2>/dev/null | python -c "
+    python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-detect --no-roofline --no-configs 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('defs [%s] rep $rep: %.3f ms/step %.1f img/s' % ('$defs', j['ms_per_step'], j['value']))"

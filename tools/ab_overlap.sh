@@ -1,5 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_postproc.py tests/test_gpu_nnops.py tests/test_gpu_conv.py -x -q -m gpu 2>&1 | tail -4
-python tools/step_trace.py gpurun_out/step_trace_r4h.tsv 2>/dev/null | grep -i "match\|avgpool\|step wall"
-bash tools/ab_env.sh - | grep rep
+python -m pytest tests/test_gpu_conv.py -x -q -m gpu -k "igemm5" 2>&1 | tail -3
+bash tools/ab_builds.sh "-" "-DMBX_I5_NO_EARLY_REM" "-" "-DMBX_I5_NO_EARLY_REM" 2>&1 | grep "defs"
