@@ -591,7 +591,11 @@ def main():
                           "skipped_steps": int(tr.skipped_steps), "error": verdict["error"], "events": list(tr.events)},
                # the kernel mix of THIS run (data-parallel runs cap the BN-backward grid; both use the same conv kernels)
                "kernels": {"igemm5_launches": sum(1 for _, d_, _ in net.tune_registry if 32 < d_.tile_config < 64),
-                           "igemm7_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 64),
+                           "igemm7_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config == 65),
+                           "split_k_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 128),
+                           "bn_groups": len(net.bn_groups), "pair_launches": sum(int(g_.pair_fwd) + int(g_.pair_bwd) for g_ in net.bn_groups),
+                           "fused_stem_pools": sum(1 for c_ in net.convs if getattr(c_, "fused_pool", None) is not None),
+                           "backward_segments": len(tr._segments), "graphs": len(tr.graphs or []),
                            "bn_backward": "three-launch" if net.no_onepass else "one-launch (grid barrier, max %s workgroups)" % (net.bn_max_wg or "all"),
                            "skipped_steps_events": tr.events},
                "algorithmic_tflop_per_step": round(per_image_gflop * 1e-3 * B * world, 3)}

@@ -30,9 +30,10 @@ elif [ "$part" = "b" ]; then
   rm -rf $out/sq1 $out/sq2
 elif [ "$part" = "w" ]; then
   # the grouped weight-gradient launches of the step: SQ counters, then L2 (TCC) counters, eager steps of the real network
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --output-format csv -d $out/wg1 -o s -- python3 bench.py $B > $out/wg1.log 2>&1 || exit 8
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --output-format csv -d $out/wg1 -o s -- python3 bench.py $B > $out/wg1.log 2>&1 || exit 8
   python tools/pmc_summary.py $out/wg1/s_counter_collection.csv | grep -A 9 "conv_wgrad_grouped" > $out/wgrad_sq_counters.txt 2>&1
-  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $out/wg2 -o s -- python3 bench.py $B > $out/wg2.log 2>&1 || exit 9
+  # (the counter set of r03_conv_l2_counters.txt; under its own timeout: a TCC pass has hung inside rocprofv3 on this pool before)
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_avr --output-format csv -d $out/wg2 -o s -- python3 bench.py $B > $out/wg2.log 2>&1 || exit 9
   python tools/pmc_summary.py $out/wg2/s_counter_collection.csv | grep -A 6 "conv_wgrad_grouped" > $out/wgrad_l2_counters.txt 2>&1
   rm -rf $out/wg1 $out/wg2
 elif [ "$part" = "c" ]; then
