@@ -190,7 +190,11 @@ typedef struct {
 /* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
    POINTWISE launch with the filter panel resident in LDS (1x1, unit stride, unpadded, 64 < K <= 384, no statistics; its
    work_counter, if given, is an array of one zeroed int32 per 128-channel column tile, at most 32).  A configuration that
-   does not apply returns MBX_ERR_UNSUPPORTED. */
+   does not apply returns MBX_ERR_UNSUPPORTED.
+   tile_config 96: the DIRECT 3x3 launch (stride 1, forward or data gradient, C_in 32 / 64, C_out <= 64, bf16 store with or
+   without statistics) for few channels on large maps: a persistent workgroup per CU stages a pixel patch with its halo
+   once and multiplies the nine taps out of LDS instead of gathering the input nine times.  Same accumulation order as
+   the implicit-GEMM tiles: bit-identical outputs; mbx_conv_stats_rows() = one row per workgroup. */
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);

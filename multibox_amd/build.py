@@ -23,6 +23,7 @@ SOURCES = {
     "conv.hip": ["-munsafe-fp-atomics"],
     "conv5.hip": [],
     "conv7.hip": [],
+    "convd.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
     "augment.hip": ["-ffp-contract=off"],
 }

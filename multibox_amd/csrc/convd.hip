@@ -1,0 +1,309 @@
+// libmbx: conv_direct3_kernel -- 3x3, stride-1 convolutions with FEW channels (C_in 32 / 64, C_out 32 / 48 / 64) on LARGE maps
+// (the stem layers Conv2d_2a / 2b of model.py:93-100 at 147 x 147 x BATCH_SIZE 64: 1.4 M pixels, forward and data gradient).
+//
+// The implicit-GEMM kernels gather the input NINE times through the L2 -> LDS path (once per filter tap: 800 MB per launch
+// for 88 MB of activations) and ran these launches at 2-3x their HBM time (134 / 141 / 86 / 129 us against 36 / 53 / 36 / 53).
+// Here a workgroup stages a (8 + 2) x (32 + 2) pixel PATCH of the input once (halo included, zero padding by
+// buffer-descriptor range misses), keeps the whole filter in LDS for its lifetime, and multiplies the nine taps out of LDS:
+// tap (r, s) of output row `oh` reads the patch row oh + r at columns shifted by s.  Round 1 tried the one-shot form of
+// this (load a patch, 0.5 us of MFMA, store: a block waited on latency for most of its life) and dropped it; this one is
+// PERSISTENT: one 512-thread workgroup per CU walks tiles first, first + grid, ... with the NEXT tile's patch in flight
+// (LDS-DMA into the other of two patch buffers) while the current one is multiplied and stored.
+//
+// Same arithmetic as the implicit GEMM: K order (r, s, c), one v_mfma_f32_16x16x32_bf16 per 32 input channels of a tap,
+// filter rows as the A operand (D[row = channel][col = pixel]) -- the accumulation sequence of every output element is
+// the igemm kernels', so the results are bit-identical to them (tests/test_gpu_conv.py::test_conv_direct3).
+// Epilogues: bf16 store (EV = 0), store + batch-norm statistics (EV = 1: ONE partial row per workgroup, summed over its
+// tiles in a fixed order: mbx_conv_stats_rows = the grid size).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kDTH = 8, kDTW = 32;                        // output tile: 8 rows x 32 columns = one row per wave
+constexpr int kDPH = kDTH + 2, kDPW = kDTW + 2;           // input patch with halo
+constexpr int kDThreads = 512;
+
+struct DirK { int N, H_out, tiles_h, tiles_w, ntiles; };
+
+// conflict-free ds_read_b128 of 16 consecutive pixels (or filter rows) of CI channels: a pixel is CI / 8 chunks of 16 B;
+// 256 / (2 CI) pixels cover the 64 banks once, so the chunk is XOR-ed with the pixel index divided by that count
+template <int CI>
+__device__ __forceinline__ int dkey(int pix) { return CI == 32 ? ((pix >> 2) & 3) : ((pix >> 1) & 7); }
+
+// Filter rows are fed to the MFMA in a PERMUTED order (as in conv_igemm3_kernel): LDS row 16 a + f of a tap holds output
+// channel dperm(a, f), so that blocks 2A and 2A + 1 leave a lane EIGHT consecutive channels of one pixel = one 16-byte store
+// (four lanes cover 64 contiguous bytes; with the plain order a 128-byte pixel row went out as four 32-byte pieces and the
+// 32 -> 64 layer ran at 2.4x its HBM time).  A trailing unpaired block (C_out 48: channels 32..47) keeps the plain order.
+template <int CO>
+__device__ __forceinline__ int dperm(int a, int f) {
+  return (a < (CO / 32) * 2) ? 32 * (a >> 1) + 8 * (f >> 2) + 4 * (a & 1) + (f & 3) : 16 * a + f;
+}
+
+template <int CI, int CO, int EV>
+__global__ void __launch_bounds__(kDThreads)
+conv_direct3_kernel(const ConvK p, const DirK q) {
+  constexpr int C8 = CI / 8, KC = CI / 32, NA = CO / 16;
+  constexpr int PCH = kDPH * kDPW * C8;                   // 16-byte chunks of a patch
+  constexpr int PROUNDS = (PCH + kDThreads - 1) / kDThreads;
+  constexpr int PBUF = PROUNDS * kDThreads;               // chunks per patch buffer (the tail is zero fill)
+  constexpr int WCH = 9 * CO * C8;                        // chunks of the filter image [tap][co][c8]
+  constexpr int WROUNDS = (WCH + kDThreads - 1) / kDThreads;
+  // patch ring: NBUF buffers, the loads run D = NBUF - 1 tiles ahead (three buffers where 160 KB hold them: C_in 32).  One
+  // workgroup per CU has nothing else to cover the ~2 us of a patch's HBM latency with: at D = 1 every tile waited for it.
+  constexpr int NBUF = CI == 32 ? 3 : 2, D = NBUF - 1;
+  constexpr int NS = 2 * (CO / 32 + (CO % 32 ? 1 : 0));   // store instructions of a tile's epilogue, per wave
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* const wimg = smem;                               // [9][CO][C8] (swizzled)
+  u32x4* const pbuf = smem + WROUNDS * kDThreads;         // the patch ring
+  float* const red = reinterpret_cast<float*>(pbuf + NBUF * PBUF);  // [8 waves][CO][2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+
+  // this thread's patch chunks (the same positions for every tile): patch row / column, source chunk
+  int prow[PROUNDS], pcol[PROUNDS], pc8[PROUNDS];
+#pragma unroll
+  for (int i = 0; i < PROUNDS; ++i) {
+    const int ch = i * kDThreads + tid;
+    const int pix = ch / C8, c8p = ch - pix * C8;
+    prow[i] = pix / kDPW;
+    pcol[i] = pix - prow[i] * kDPW;
+    pc8[i] = c8p ^ dkey<CI>(pcol[i]);                     // the DMA destination is lane-linear: swizzle the SOURCE chunk
+    if (ch >= PCH) prow[i] = -1;
+  }
+  auto issue_patch = [&](int t, int buf) {
+    const int tw = t % q.tiles_w, r_ = t / q.tiles_w, th = r_ % q.tiles_h, img = r_ / q.tiles_h;
+    const int h_in0 = th * kDTH - p.pad_t, w_in0 = tw * kDTW - p.pad_l;
+    u32x4* dst = pbuf + buf * PBUF + wave * 64;
+#pragma unroll
+    for (int i = 0; i < PROUNDS; ++i) {
+      const int h = h_in0 + prow[i], w = w_in0 + pcol[i];
+      const bool ok = prow[i] >= 0 && (unsigned)h < (unsigned)p.H_in && (unsigned)w < (unsigned)p.W_in;
+      glds16(xr, dst + i * kDThreads, ok ? (img * p.x_img_stride + (h * p.W_in + w) * p.ldx + pc8[i] * 8) * 2 : (int)kOOB);
+    }
+  };
+
+  // ---- prologue: the filter image (once) and the first patch
+#pragma unroll
+  for (int i = 0; i < WROUNDS; ++i) {
+    const int ch = i * kDThreads + tid;
+    const int row = ch / C8, c8p = ch - row * C8;         // row = tap * CO + LDS row (16 a + f)
+    const int tap = row / CO, lr = row - tap * CO;
+    const int co = dperm<CO>(lr >> 4, lr & 15);           // the output channel that LDS row holds
+    const int c8 = c8p ^ dkey<CI>(lr);
+    const bool ok = ch < WCH && co < p.C_out;
+    glds16(wr, wimg + i * kDThreads + wave * 64, ok ? ((co * 9 + tap) * CI + c8 * 8) * 2 : (int)kOOB);   // KRSC: [co][r][s][c]
+  }
+  const int first = (int)blockIdx.x, G = (int)gridDim.x;
+  if (first < q.ntiles) issue_patch(first, 0);
+  if (D > 1 && first + G < q.ntiles) { issue_patch(first + G, 1); wait_vmcnt<PROUNDS>(); } else wait_vmcnt<0>();
+  lds_readback_wait(lds_readback_issue(pbuf + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+  raw_barrier();
+
+  // ---- fragment addresses (16-byte slots)
+  const int frow = lane & 15, fch = lane >> 4;
+  float s1[NA][4], s2[NA][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+
+  int buf = 0;
+  for (int t = first; t < q.ntiles; t += G) {
+    const bool more = t + G < q.ntiles;                   // a next tile exists (its patch must be published below)
+    const bool ahead = t + D * G < q.ntiles;              // ... and one D tiles ahead, whose patch is issued now
+    const int buf_next = buf == NBUF - 1 ? 0 : buf + 1;
+    {
+      int bi = buf + D;
+      if (bi >= NBUF) bi -= NBUF;                         // the buffer tile t - 1 was multiplied out of (free: barrier below)
+      if (ahead) issue_patch(t + D * G, bi);
+    }
+    const u32x4* pb = pbuf + buf * PBUF;
+    f32x4 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tap = r * 3 + s;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          bf16x8 wf[NA], pf[2];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            const int lr = a * 16 + frow;
+            wf[a] = __builtin_bit_cast(bf16x8, wimg[(tap * CO + lr) * C8 + ((4 * j + fch) ^ dkey<CI>(lr))]);
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int pc = b * 16 + s + frow;
+            pf[b] = __builtin_bit_cast(bf16x8, pb[((wave + r) * kDPW + pc) * C8 + ((4 * j + fch) ^ dkey<CI>(pc))]);
+          }
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    // ---- epilogue: blocks 2A, 2A + 1 -> 8 consecutive channels (32 A + 8 fch ..) of pixel (wave, 16 b + frow): 16-byte stores;
+    // an unpaired last block: 4 consecutive channels, 8-byte stores
+    {
+      const int tw = t % q.tiles_w, r_ = t / q.tiles_w, th = r_ % q.tiles_h, img = r_ / q.tiles_h;
+      const int oh = th * kDTH + wave;
+      constexpr int NP = CO / 32;                           // paired blocks
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ow = tw * kDTW + b * 16 + frow;
+        const bool pv = oh < q.H_out && ow < p.W_out;
+        const int pix_off = img * p.y_img_stride + (oh * p.W_out + ow) * p.ldy;
+#pragma unroll
+        for (int A = 0; A < NP; ++A) {
+          const int c0 = 32 * A + 8 * fch;
+          const bool ok = pv && c0 < p.C_out;               // C_out % 8 == 0: a group of eight is all in or all out
+          unsigned h8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { h8[r] = f2bf(acc[2 * A][b][r]); h8[4 + r] = f2bf(acc[2 * A + 1][b][r]); }
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+                                                 yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
+          if constexpr (EV == 1) {
+            if (ok) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float f0 = bf2f((unsigned short)h8[r]), f1 = bf2f((unsigned short)h8[4 + r]);
+                s1[2 * A][r] += f0; s2[2 * A][r] += f0 * f0;
+                s1[2 * A + 1][r] += f1; s2[2 * A + 1][r] += f1 * f1;
+              }
+            }
+          }
+        }
+        if constexpr (NA > 2 * NP) {                        // C_out 48: channels 32 .. 47 in the plain order
+          constexpr int a = 2 * NP;
+          const int c0 = a * 16 + 4 * fch;
+          const bool ok = pv && c0 < p.C_out;
+          unsigned h4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h4[r] = f2bf(acc[a][b][r]);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)}, yr,
+                                                ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
+          if constexpr (EV == 1) {
+            if (ok) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float f = bf2f((unsigned short)h4[r]); s1[a][r] += f; s2[a][r] += f * f; }
+            }
+          }
+        }
+      }
+    }
+    if (more) {
+      // the NEXT tile's patch: retired, then visible (landing read-back).  Behind its DMA this wave has issued D - 1 newer
+      // patches and D tiles' stores (memory operations retire in order): a counted wait leaves those in flight -- except in
+      // the tail, where fewer were issued and the count would let the patch itself through
+      if (ahead) wait_vmcnt<(D - 1) * PROUNDS + D * NS>(); else wait_vmcnt<0>();
+      lds_readback_wait(lds_readback_issue(pbuf + buf_next * PBUF + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the current patch are done
+    raw_barrier();                                        // everyone is: the buffer may be refilled, the next one read
+    buf = buf_next;
+  }
+  if constexpr (EV == 1) {
+    // ONE statistics row per workgroup: lane sums -> the 16 lanes that share its channels -> the eight waves, fixed order
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
+        if (frow == 0) {
+          const int ch = dperm<CO>(a, 4 * fch + r);           // the channel MFMA row 4 fch + r of block a holds
+          red[(wave * CO + ch) * 2] = x1;
+          red[(wave * CO + ch) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < CO && tid < p.C_out) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { x1 += red[(w * CO + tid) * 2]; x2 += red[(w * CO + tid) * 2 + 1]; }
+      float* o = p.stats + ((size_t)blockIdx.x * p.C_out + tid) * 2;
+      o[0] = x1;
+      o[1] = x2;
+    }
+  }
+}
+
+template <int CI, int CO>
+constexpr int direct3_lds() {
+  constexpr int C8 = CI / 8;
+  constexpr int PCH = kDPH * kDPW * C8, PBUF = (PCH + kDThreads - 1) / kDThreads * kDThreads;
+  constexpr int WCH = 9 * CO * C8, WB = (WCH + kDThreads - 1) / kDThreads * kDThreads;
+  return (WB + (CI == 32 ? 3 : 2) * PBUF) * 16 + 8 * CO * 2 * 4;
+}
+
+template <int CI, int CO>
+int launch_direct3(const ConvK& k, const DirK& q, int grid, hipStream_t s) {
+  constexpr int lds = direct3_lds<CI, CO>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr[2] = {false, false};
+  const int ev = k.stats ? 1 : 0;
+  if (!attr[ev]) {
+    if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr[ev] = true;
+  }
+  if (ev) hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 1>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 0>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+int direct3_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return ncu;
+}
+
+}  // namespace
+
+// workgroups (= statistics rows) of the direct launch for an N x H_out x W_out output
+int mbx_direct3_grid(int N, int H_out, int W_out) {
+  const long nt = (long)N * ((H_out + kDTH - 1) / kDTH) * ((W_out + kDTW - 1) / kDTW);
+  const int ncu = direct3_cus();
+  return nt < ncu ? (int)nt : ncu;
+}
+
+// mbx_conv_desc.tile_config = 96: the direct 3x3 launch.  MBX_ERR_UNSUPPORTED for anything but a 3x3 / stride-1 convolution
+// (forward, or the data gradient of one) with C_in in {32, 64}, C_out <= 64 (a multiple of 8) and a bf16 store epilogue
+// with or without statistics.
+int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
+  ConvK& k = *reinterpret_cast<ConvK*>(convk);
+  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || k.epi != MBX_EPI_STORE || k.accumulate || k.skip || k.rscale != 0.f)
+    return MBX_ERR_UNSUPPORTED;
+  if ((k.C_in != 32 && k.C_in != 64) || k.C_out > 64 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2 ||
+      (k.C_in == 64 && k.C_out > 48))
+    return MBX_ERR_UNSUPPORTED;
+  DirK q;
+  q.N = N; q.H_out = H_out;
+  q.tiles_h = (H_out + kDTH - 1) / kDTH;
+  q.tiles_w = (k.W_out + kDTW - 1) / kDTW;
+  const long nt = (long)N * q.tiles_h * q.tiles_w;
+  if (nt >= (1L << 30)) return MBX_ERR_UNSUPPORTED;
+  q.ntiles = (int)nt;
+  const int grid = mbx_direct3_grid(N, H_out, k.W_out);
+  if (k.dry) return MBX_OK;
+  const int co = k.C_out <= 32 ? 32 : k.C_out <= 48 ? 48 : 64;
+  if (k.C_in == 32) {
+    if (co == 32) return launch_direct3<32, 32>(k, q, grid, s);
+    if (co == 48) return launch_direct3<32, 48>(k, q, grid, s);
+    return launch_direct3<32, 64>(k, q, grid, s);
+  }
+  if (co == 32) return launch_direct3<64, 32>(k, q, grid, s);
+  if (co == 48) return launch_direct3<64, 48>(k, q, grid, s);
+  return MBX_ERR_UNSUPPORTED;                             // 64 -> 64: filter image + two patches do not fit 160 KB of LDS
+}

@@ -598,6 +598,11 @@ class Net:
                 self._i5_used += n
             if os.environ.get("MBX_NO_2STAGE") == "1":                     # bisecting aid: 3-deep-ring twins of the 2-deep tiles
                 d.tile_config = {9: 7, 10: 2, 11: 5, 12: 2, 13: 8, 14: 1}.get(d.tile_config, d.tile_config)
+            # few channels on a large map (the stem's 3x3 layers, forward and data gradient): the direct launch stages each
+            # pixel patch once instead of gathering it nine times (by rule, not by the table; bit-identical outputs)
+            if ops.direct3_applies(d):
+                d.tile_config, d.work_counter = ops.DIRECT3_TILE_CONFIG, None
+                _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 " + op.name)
         return d
 
     def _build_forward_launches(self):

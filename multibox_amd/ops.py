@@ -151,6 +151,20 @@ I5_TILE_CONFIGS = (33, 34, 35, 36, 37)         # 128x64, 128x128, 192x128, 256x1
 I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
 I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
 SPLITK_FLAG = 128                              # tile_config 128 + S: split-K in S slices (float32 partials + reduce launch)
+DIRECT3_TILE_CONFIG = 96                       # the direct 3x3 launch for few channels on large maps (csrc/convd.hip)
+
+
+def direct3_applies(desc: ConvDesc, min_pixels=300000):
+    """The direct 3x3 launch by rule: 3x3 / stride 1 (forward or data gradient), C_in 32 / 64, C_out <= 64, plain bf16 store
+    (+ statistics), and a map large enough that the nine-fold gather of the implicit GEMM is what the launch spends its
+    time on (the stem's 147 x 147 layers at BATCH_SIZE 64: 1.4 M pixels).  MBX_DIRECT3=0 turns it off (A/B); MBX_DIRECT3_MIN_PIXELS."""
+    if os.environ.get("MBX_DIRECT3", "1") == "0":
+        return False
+    if desc.R != 3 or desc.S != 3 or desc.stride != 1 or desc.epilogue != EPI_STORE or desc.accumulate or desc.skip or desc.rscale != 0.0:
+        return False
+    if desc.C_in not in (32, 64) or desc.C_out > 64 or desc.C_out % 8 or (desc.C_in == 64 and desc.C_out > 48):
+        return False
+    return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_DIRECT3_MIN_PIXELS", min_pixels))
 
 
 def splitk_slices(desc: ConvDesc, n_cus=256):

@@ -139,6 +139,68 @@ def test_conv_epilogues(T):
     assert ok, "accumulate: " + msg
 
 
+@pytest.mark.parametrize("g", [("d1", 2, 37, 45, 32, 32, 3, 3, 1, (0, 0, 0, 0)), ("d2", 3, 41, 33, 32, 64, 3, 3, 1, (1, 1, 1, 1)),
+                               ("d3", 2, 35, 35, 32, 48, 3, 3, 1, (1, 1, 1, 1)), ("d4", 2, 29, 50, 64, 32, 3, 3, 1, (1, 1, 1, 1)),
+                               ("d5", 1, 20, 70, 64, 48, 3, 3, 1, (1, 1, 1, 1)), ("d6", 2, 24, 24, 32, 40, 3, 3, 1, (1, 1, 1, 1)),
+                               ("d7", 4, 147, 147, 32, 64, 3, 3, 1, (1, 1, 1, 1))],
+                         ids=["valid_32_32", "same_32_64", "same_32_48", "same_64_32", "same_64_48", "cout_40", "stem_2b"])
+def test_conv_direct3_bit_identical(T, g):
+    """tile_config 96 (round 4, csrc/convd.hip): the direct 3x3 launch -- a persistent workgroup per CU stages each pixel
+    patch with its halo once and multiplies the nine taps out of LDS -- against the implicit-GEMM launch of the same
+    descriptor: forward with statistics and as a data gradient ("full" padding 2 for a VALID forward), ragged tile edges,
+    more tiles than workgroups.  Same accumulation order: outputs bit-identical, statistics = sums of the stored values (one
+    row per workgroup); slices of wider buffers untouched outside; what it does not cover is refused."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=11)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    stream = torch.cuda.current_stream().cuda_stream
+    xb = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    outs = []
+    for cfg in (0, ops.DIRECT3_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb)
+        d.tile_config = cfg
+        rows = ops.conv_stats_rows(d)
+        stats = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=stats)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        full = yb.buf.reshape(N, Ho, Wo, Co + 24)
+        assert float(full[..., :16].abs().max()) == 0 and float(full[..., 16 + Co:].abs().max()) == 0
+        outs.append((yb.tensor().clone(), stats.double().sum(0).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0].float() - outs[1][0].float()).abs().max())
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-3)
+    ok, msg = close(torch, outs[1][0], ref_conv(torch, x, w, st, pads))
+    assert ok, msg
+    # data gradient of the same convolution: input = dy [N,Ho,Wo,Co], flipped / transposed filter, "full" padding R - 1 - pad
+    gen = torch.Generator().manual_seed(5)
+    if Co in (32, 64) and Ci <= 64 and not (Co == 64 and Ci > 48):
+        dy = ops.View.alloc(N, Ho, Wo, Co)
+        dy.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+        wt = w.to(torch.bfloat16).flip(1, 2).permute(3, 1, 2, 0).contiguous().cuda()          # [Ci][R][S][Co]
+        res = []
+        for cfg in (0, ops.DIRECT3_TILE_CONFIG):
+            gx = ops.View.alloc(N, H, W, Ci, zero=True)
+            dd = ops.make_desc(dy, wt, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], gx, transposed=1)
+            dd.tile_config = cfg
+            assert l.mbx_conv(C.byref(dd), stream) == 0
+            torch.cuda.synchronize()
+            res.append(gx.tensor().clone())
+        assert torch.equal(res[0], res[1]) and float(res[0].float().abs().max()) > 0
+    # refused: a 1x1, a stride-2, an accumulate epilogue, 64 -> 64 channels
+    bad = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, accumulate=1)
+    bad.tile_config = ops.DIRECT3_TILE_CONFIG
+    assert l.mbx_conv_supported(C.byref(bad)) == -2
+
+
 @pytest.mark.parametrize("cfg", [0, 10, 11, 5, 6])
 def test_conv_pair_bit_identical(T, cfg):
     """mbx_conv_pair (round 4): two independent convolutions of different shape (block35's sibling 3x3 branches: 32 -> 32 and
