@@ -185,6 +185,14 @@ typedef struct {
      (deterministic), rounds, stores y and writes the statistics partials (a row per 16 pixels).  The float32 sum is
      grouped differently from the one-pass kernels: results agree with them to 1 bf16 ulp, not bit for bit.          */
   void* splitk_ws; int64_t splitk_ws_bytes;
+  /* stats_rows_mod = R > 0 (round 4): the statistics of a tile are ADDED (float32 atomics) into row (tile index mod R) of
+     stats_partial = [R][stats_ld][2], which must be ZERO at launch -- R rows whatever the tile shape (mbx_conv_stats_rows()
+     = R), few enough for the consumer to reduce them itself (mbx_bn_apply_fused_mapped: no finalize launch), many enough
+     that the adders of one address stay few.  The order of the additions is not fixed: sums differ from run to run in the
+     last float32 bits (callers that need bit-reproducible statistics leave it 0: a plain row per tile).
+     stats_ld (0: C_out): channels per row -- sibling convolutions of a batch-norm group add into channel slices of one
+     table (stats_partial then points at the member's first channel).                                              */
+  int32_t stats_rows_mod, stats_ld;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
@@ -287,6 +295,15 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
                        const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
                        float* mean, float* rstd, float* moving_mean, float* moving_var,
                        mbx_stream_t stream);
+/* The same in one launch WHATEVER `rows` is, with the activation view addressed through a group's channel map (NULL: the
+ * identity; see BATCH-NORM GROUPS below) -- the consumer of a convolution that ADDED its statistics into few rows
+ * (mbx_conv_desc.stats_rows_mod = 16: every workgroup re-reduces 16 rows of its 64 channels; no finalize launch).
+ * relu_thr ([C], may be NULL): the ReLU threshold on y, mean - beta / rstd (-inf without relu): (y - mean) rstd + beta > 0
+ * <=> y > relu_thr -- what mbx_conv's BN-backward statistics epilogue masks with.                                      */
+int mbx_bn_apply_fused_mapped(const float* stats_partial, int rows, int64_t count, float eps, float decay,
+                              const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
+                              const struct mbx_chan_map_s* a_map /*HOST*/, float* mean, float* rstd, float* moving_mean,
+                              float* moving_var, float* relu_thr, mbx_stream_t stream);
 /* moving -= (1-decay)*(moving - batch) for n channels (every batch-norm layer of a step in one launch; batch_mean /
  * batch_var as written by the store mode above: the same float32 expressions, bit-identical to the in-place update).
  * skip_ctl (DEVICE, two float32, may be NULL): the step control block of mbx_rmsprop_ema_step -- if either word is
@@ -306,7 +323,7 @@ int mbx_bn_moving_update(float* moving_mean, float* moving_var, const float* bat
  * i = the last entry with c_begin[i] <= c.  c_begin ascending from 0, everything a multiple of 8, offsets >= 0 (the
  * view pointer is that of the lowest member).  map = NULL: the identity.  A kernel costs >= 4.4 us in the replayed
  * step whatever it does; a group of two saves a finalize, an apply and a backward launch per step and block.          */
-typedef struct { int32_t n; int32_t c_begin[4]; int32_t offset[4]; } mbx_chan_map;
+typedef struct mbx_chan_map_s { int32_t n; int32_t c_begin[4]; int32_t offset[4]; } mbx_chan_map;
 /* mbx_bn_finalize over up to 4 members: member p's convolution wrote parts[p] = [rows[p]][Cs[p]][2]. */
 int mbx_bn_finalize_parts(const float* const* parts /*HOST array of DEVICE pointers*/, const int32_t* rows /*HOST*/,
                           const int32_t* Cs /*HOST*/, int n_parts, int64_t count, float eps, float decay, float* mean,

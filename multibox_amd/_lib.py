@@ -67,6 +67,7 @@ _SIGS = {
     "mbx_bn_bwd_onepass_mapped": (I, [P, I, I, P, C.c_int64, I, P, P, P, P, P, P, I, P, P, P]),
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
+    "mbx_bn_apply_fused_mapped": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
     "mbx_bn_bwd_onepass_workspace_bytes": (C.c_size_t, [I]),
     "mbx_bn_bwd_onepass_supported": (I, [C.c_int64, I, I]),

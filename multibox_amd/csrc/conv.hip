@@ -272,9 +272,7 @@ __device__ __forceinline__ void conv_igemm3_body(const ConvK& p, const int bid_,
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-        float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
-        o[0] = x1;
-        o[1] = x2;
+        stats_write(p, tile_m, n0 + tid, x1, x2);
       }
     }
   }
@@ -1056,7 +1054,8 @@ conv_wgrad_grouped_kernel(const WgradLayer* __restrict__ layers, const WgradItem
 constexpr int kSplitRows = 16;                        // pixels per workgroup of the reduce launch = per statistics row
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice_stride, int M, int C, int ldp,
-                     unsigned short* __restrict__ y, int HW_out, long long y_img_stride, int ldy, float* __restrict__ stats) {
+                     unsigned short* __restrict__ y, int HW_out, long long y_img_stride, int ldy, float* __restrict__ stats,
+                     int stats_mod, int stats_ld) {
   __shared__ float red[kSplitRows][256][2];             // [row][channel][value | value^2] of the STORED values (C <= 256 per pass)
   const int m0 = blockIdx.x * kSplitRows, tid = threadIdx.x;
   for (int cb = 0; cb < C; cb += 256) {
@@ -1103,9 +1102,15 @@ splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int r = 0; r < kSplitRows; ++r) { x1 += red[r][tid][0]; x2 += red[r][tid][1]; }
-        float* o = stats + ((size_t)blockIdx.x * C + cb + tid) * 2;
-        o[0] = x1;
-        o[1] = x2;
+        if (stats_mod) {
+          float* o = stats + ((size_t)((int)blockIdx.x % stats_mod) * stats_ld + cb + tid) * 2;
+          unsafeAtomicAdd(o, x1);
+          unsafeAtomicAdd(o + 1, x2);
+        } else {
+          float* o = stats + ((size_t)blockIdx.x * stats_ld + cb + tid) * 2;
+          o[0] = x1;
+          o[1] = x2;
+        }
       }
     }
   }
@@ -1274,6 +1279,7 @@ int check_desc(const mbx_conv_desc* d) {
 
 extern "C" int mbx_conv_stats_rows(const mbx_conv_desc* d) {
   if (!d) return MBX_ERR_INVALID_ARG;
+  if (d->stats_rows_mod > 0) return d->stats_rows_mod;                 // atomic mode: R rows whatever the tiles
   const long M = (long)d->N * d->H_out * d->W_out;
   if (d->tile_config > kSplitFlag) return (int)((M + kSplitRows - 1) / kSplitRows);   // split-K: the reduce launch writes a row per 16 pixels
   if (d->tile_config == kDirectCfg) return mbx_direct3_grid(d->N, d->H_out, d->W_out);        // a row per workgroup
@@ -1353,6 +1359,8 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   k.skip = reinterpret_cast<const unsigned short*>(d->skip);
   k.skip_img_stride = (int)d->skip_img_stride; k.ld_skip = d->ld_skip; k.rscale = d->rscale;
   k.stats = d->stats_partial;
+  if (d->stats_rows_mod < 0 || d->stats_rows_mod > 1024 || d->stats_ld < 0 || (d->stats_ld && d->stats_ld < d->C_out)) return MBX_ERR_INVALID_ARG;
+  k.stats_mod = d->stats_rows_mod; k.stats_ld = d->stats_ld ? d->stats_ld : d->C_out;
   if (d->accumulate && d->acc_src) {
     if (d->ld_acc % 8 || (reinterpret_cast<uintptr_t>(d->acc_src) & 15) || (long long)d->N * d->acc_img_stride >= (1LL << 31))
       return MBX_ERR_INVALID_ARG;
@@ -1421,7 +1429,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     if (st != MBX_OK || dry) return st;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((k.M + kSplitRows - 1) / kSplitRows), dim3(256), 0, s, reinterpret_cast<const float*>(d->splitk_ws),
                        ksplit, slice, k.M, k.C_out, ldp, reinterpret_cast<unsigned short*>(k.y), k.HW_out,
-                       (long long)k.y_img_stride, k.ldy, k.stats);
+                       (long long)k.y_img_stride, k.ldy, k.stats, k.stats_mod, k.stats_ld);
     MBX_LAUNCH_CHECK();
     return MBX_OK;
   }

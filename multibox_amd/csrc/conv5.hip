@@ -296,9 +296,7 @@ conv_igemm5_kernel(const ConvK p) {
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int w = 0; w < G::WM; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-        float* o = p.stats + ((size_t)tile_m * p.C_out + n0 + tid) * 2;
-        o[0] = x1;
-        o[1] = x2;
+        stats_write(p, tile_m, n0 + tid, x1, x2);
       }
       // (no second barrier: `red` is rewritten only after the next tile's K loop, nk >= 1 barriers away)
     }

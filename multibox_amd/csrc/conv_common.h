@@ -27,6 +27,7 @@ struct ConvK {
   const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
   const unsigned short* acc_src; int acc_img_stride, ld_acc;      // accumulate: OLD value read from here (may alias y)
   float* stats;
+  int stats_mod, stats_ld;               // stats_mod = R > 0: tile sums ADDED atomically into row (tile % R) of [R][stats_ld][2] (zero at launch); 0: a plain row per tile
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
   int pw;                              // pointwise: R = S = 1, no padding, unit stride
@@ -61,6 +62,20 @@ __device__ __forceinline__ float row_sum16(float v) {
 // exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
 __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
   return (unsigned)(((unsigned long long)m * magic) >> shift);
+}
+// one channel's statistics sums of one tile (or of one workgroup) into the partial table: a plain row per tile, or --
+// stats_mod rows whatever the tile count -- float32 atomics into row (tile mod stats_mod) of a table that is zero at launch
+// (hardware float atomics, fire and forget: performed at the memory side, nothing returns)
+__device__ __forceinline__ void stats_write(const ConvK& p, const int tile_row, const int ch, const float x1, const float x2) {
+  if (p.stats_mod) {
+    float* o = p.stats + ((size_t)(tile_row % p.stats_mod) * p.stats_ld + ch) * 2;
+    unsafeAtomicAdd(o, x1);
+    unsafeAtomicAdd(o + 1, x2);
+  } else {
+    float* o = p.stats + ((size_t)tile_row * p.stats_ld + ch) * 2;
+    o[0] = x1;
+    o[1] = x2;
+  }
 }
 // pixel index m -> (image, output row, output column)
 __device__ __forceinline__ void decode_pixel(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {

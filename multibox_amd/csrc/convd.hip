@@ -228,9 +228,7 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
       float x1 = 0.f, x2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) { x1 += red[(w * CO + tid) * 2]; x2 += red[(w * CO + tid) * 2 + 1]; }
-      float* o = p.stats + ((size_t)blockIdx.x * p.C_out + tid) * 2;
-      o[0] = x1;
-      o[1] = x2;
+      stats_write(p, (int)blockIdx.x, tid, x1, x2);
     }
   }
 }

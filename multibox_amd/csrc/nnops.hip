@@ -300,11 +300,29 @@ __global__ void __launch_bounds__(kT)
 bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count, float eps, float decay,
                       const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ beta, int relu,
                       unsigned short* __restrict__ a, int ld_a, float* __restrict__ mean, float* __restrict__ rstd,
-                      float* __restrict__ mmean, float* __restrict__ mvar, int rows_per_chunk) {
+                      float* __restrict__ mmean, float* __restrict__ mvar, int rows_per_chunk, const ChanMap map,
+                      float* __restrict__ thr) {
   __shared__ double red[8][kBnGroup][2];
   __shared__ float s_mean[kBnGroup], s_rstd[kBnGroup], s_beta[kBnGroup];
   const int c0 = blockIdx.x * kBnGroup;
   const int cw = min(kBnGroup, C - c0);
+  const int V = cw >> 3;                                  // 16-byte vectors per row in this group
+  const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+  long long r_end = r_begin + rows_per_chunk;
+  if (r_end > M) r_end = M;
+  const int total = (int)(r_end - r_begin) * V;
+  // The first kPre vectors of every lane are loaded BEFORE the statistics are reduced: the reads of y do not depend on
+  // them, and with the partial rows just written by another kernel's atomics (memory side: an L2 miss) the two round
+  // trips would otherwise sit back to back in front of the first store -- 9.7 us per launch against 6.5 for the plain
+  // apply kernel, which ate what the removed finalize launch had saved.
+  constexpr int kPre = 4;
+  u32x4 pre[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int i = threadIdx.x + u * kT;
+    pre[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < total) pre[u] = ld8(y + (r_begin + i / V) * C + c0 + ((i % V) << 3));
+  }
   {
     // lane = (channel pair, one of 8 row lanes): 16-byte loads of {sum, sumsq} x 2 channels, SIXTEEN partial rows in
     // flight per lane (one L2 round trip per batch instead of one per row).  The order of the additions is fixed, so
@@ -320,6 +338,13 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
         for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 8 * u) * C * 2);
 #pragma unroll
         for (int u = 0; u < 16; ++u) { s1a += v[u].x; s2a += v[u].y; s1b += v[u].z; s2b += v[u].w; }
+      }
+      if (r + 8 < rows) {                                  // (the 16-row tables of the atomic mode: both loads in flight)
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)r * C * 2);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(r + 8) * C * 2);
+        s1a += v0.x; s2a += v0.y; s1b += v0.z; s2b += v0.w;
+        s1a += v1.x; s2a += v1.y; s1b += v1.z; s2b += v1.w;
+        r += 16;
       }
       for (; r < rows; r += 8) {
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * C * 2);
@@ -339,6 +364,8 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
       s_mean[ch] = fm; s_rstd[ch] = fr; s_beta[ch] = beta[c0 + ch];
       if (blockIdx.y == 0) {
         mean[c0 + ch] = fm; rstd[c0 + ch] = fr;
+        // relu threshold on y for the backward pass's statistics epilogue: (y - mean) rstd + beta > 0  <=>  y > mean - beta / rstd
+        if (thr) thr[c0 + ch] = relu ? fm - s_beta[ch] / fr : -__builtin_inff();
         if (decay < 0.f) {                                                 // store mode (bn_finalize_kernel)
           if (mmean) mmean[c0 + ch] = fm;
           if (mvar) mvar[c0 + ch] = (float)var;
@@ -350,22 +377,104 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
     }
     __syncthreads();
   }
-  const int V = cw >> 3;                                  // 16-byte vectors per row in this group
-  const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
-  long long r_end = r_begin + rows_per_chunk;
-  if (r_end > M) r_end = M;
-  const long long total = (r_end - r_begin) * V;
-  for (long long i = threadIdx.x; i < total; i += kT) {
+  auto finish = [&](const int i, const u32x4 raw) {
     const long long m = r_begin + i / V;
-    const int vc = (int)(i % V) << 3;
+    const int vc = (i % V) << 3;
     float f[8];
-    unpack8(ld8(y + m * C + c0 + vc), f);
+    unpack8(raw, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = (f[j] - s_mean[vc + j]) * s_rstd[vc + j] + s_beta[vc + j];
       f[j] = relu ? fmaxf(v, 0.f) : v;
     }
-    st8(a + m * ld_a + c0 + vc, pack8(f));
+    st8(a + m * ld_a + c0 + vc + chan_off(map, c0 + vc), pack8(f));
+  };
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int i = threadIdx.x + u * kT;
+    if (i < total) finish(i, pre[u]);
+  }
+  for (int i = threadIdx.x + kPre * kT; i < total; i += kT)
+    finish(i, ld8(y + (r_begin + i / V) * C + c0 + ((i % V) << 3)));
+}
+
+// ------------------------------------------- batch norm: apply straight from FEW statistics rows (round 4)
+// The consumer of a convolution that ADDED its tile sums into R <= 16 rows (mbx_conv_desc.stats_rows_mod).  bn_apply_kernel's
+// walk -- a lane owns one 8-channel group, a workgroup sweeps whole rows: every wave access is a contiguous run of the
+// tensor -- behind a prologue in which the workgroup reduces the R rows of ALL C channels itself (lane t: channels t,
+// t + 256, ...; consecutive lanes read consecutive 8-byte {sum, sumsq} pairs) into LDS.  The 64-channel-group kernel above
+// re-reduces only its own channels but reads 128-byte pieces of rows C * 2 bytes apart: 9.7-10.3 us per launch on the
+// block17 / block35 layers against 6.5 for bn_apply_kernel, more than the finalize launch it replaces.  The first vector
+// of y is loaded before the prologue (it does not depend on the statistics).  Workgroup 0 publishes mean / rstd / relu
+// threshold and the moving statistics.  C <= 2048.
+constexpr int kRowsMaxC = 2048;
+__global__ void __launch_bounds__(kT)
+bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count, float eps, float decay,
+                     const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ beta, int relu,
+                     unsigned short* __restrict__ a, int ld_a, float* __restrict__ mean, float* __restrict__ rstd,
+                     float* __restrict__ mmean, float* __restrict__ mvar, const ChanMap map, float* __restrict__ thr) {
+  extern __shared__ __attribute__((aligned(16))) float s_par[];          // [3][C]: mean, rstd, beta
+  const int C8 = C >> 3;
+  const int rpi = kT / C8 > 0 ? kT / C8 : 1;              // rows per sweep of the workgroup (C8 <= 256)
+  const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+  const bool active = rr < rpi;
+  const int c = vc << 3;
+  const long long step = (long long)gridDim.x * rpi;
+  long long m = (long long)blockIdx.x * rpi + rr;
+  u32x4 first = u32x4{0u, 0u, 0u, 0u};
+  if (active && m < M) first = ld8(y + m * C + c);
+  for (int ch = threadIdx.x; ch < C; ch += kT) {
+    const float* src = part + (size_t)ch * 2;
+    double s1 = 0.0, s2 = 0.0;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {                        // four rows' loads in flight
+      const float2 v0 = *reinterpret_cast<const float2*>(src + (size_t)(r + 0) * C * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(src + (size_t)(r + 1) * C * 2);
+      const float2 v2 = *reinterpret_cast<const float2*>(src + (size_t)(r + 2) * C * 2);
+      const float2 v3 = *reinterpret_cast<const float2*>(src + (size_t)(r + 3) * C * 2);
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; r < rows; ++r) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)r * C * 2);
+      s1 += v.x; s2 += v.y;
+    }
+    const double mu = s1 * inv_count;
+    double var = s2 * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)mu, fr = (float)(1.0 / sqrt(var + (double)eps)), be = beta[ch];
+    s_par[ch] = fm; s_par[C + ch] = fr; s_par[2 * C + ch] = be;
+    if (blockIdx.x == 0) {
+      mean[ch] = fm; rstd[ch] = fr;
+      if (thr) thr[ch] = relu ? fm - be / fr : -__builtin_inff();
+      if (decay < 0.f) {                                                   // store mode (bn_finalize_kernel)
+        if (mmean) mmean[ch] = fm;
+        if (mvar) mvar[ch] = (float)var;
+      } else {
+        if (mmean) mmean[ch] -= (1.0f - decay) * (mmean[ch] - fm);
+        if (mvar) mvar[ch] -= (1.0f - decay) * (mvar[ch] - (float)var);
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  a += chan_off(map, c);
+  float mu[8], rs[8], be[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mu[j] = s_par[c + j]; rs[j] = s_par[C + c + j]; be[j] = s_par[2 * C + c + j]; }
+  u32x4 cur = first;
+  for (; m < M; m += step) {
+    u32x4 nxt = u32x4{0u, 0u, 0u, 0u};
+    if (m + step < M) nxt = ld8(y + (m + step) * C + c);      // next row's load in flight behind this row's arithmetic
+    float f[8];
+    unpack8(cur, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (f[j] - mu[j]) * rs[j] + be[j];
+      f[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+    st8(a + m * ld_a + c, pack8(f));
+    cur = nxt;
   }
 }
 
@@ -1756,6 +1865,37 @@ extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float e
   return MBX_OK;
 }
 
+extern "C" int mbx_bn_apply_fused_mapped(const float* stats_partial, int rows, int64_t count, float eps, float decay,
+                                         const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
+                                         const mbx_chan_map* a_map, float* mean, float* rstd, float* mmean, float* mvar,
+                                         float* relu_thr, mbx_stream_t stream) {
+  if (!stats_partial || !y || !a || !beta || !mean || !rstd || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_a % 8 ||
+      count <= 0 || !al16(y) || !al16(a) || !al16(stats_partial))
+    return MBX_ERR_INVALID_ARG;
+  ChanMap cm;
+  if (to_chan_map(a_map, C, cm) != MBX_OK) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  static const int rows_kernel = env_int("MBX_BN_ROWS_KERNEL", 1), rows_blocks = env_int("MBX_BN_ROWS_BLOCKS", 1024);
+  if (rows_kernel && rows <= 16 && C <= kRowsMaxC) {
+    // whole-row sweeps; every workgroup reduces the few rows of all C channels itself (bn_apply_rows_kernel)
+    const int C8 = C / 8, rpi = kT / C8 > 0 ? kT / C8 : 1;
+    long long g = (M + rpi - 1) / rpi;
+    if (g > rows_blocks) g = rows_blocks;
+    hipLaunchKernelGGL(bn_apply_rows_kernel, dim3((unsigned)g), dim3(kT), (size_t)3 * C * sizeof(float), mbx_s(stream), stats_partial,
+                       rows, 1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd,
+                       mmean, mvar, cm, relu_thr);
+    MBX_LAUNCH_CHECK();
+    return MBX_OK;
+  }
+  int groups, chunks, rpc;
+  bn_fused_grid(M, C, rows, groups, chunks, rpc);
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
+                     1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
+                     mvar, rpc, cm, relu_thr);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 extern "C" int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, float eps, float decay, const void* y,
                                   int64_t M, int C, const float* beta, int relu, void* a, int ld_a, float* mean,
                                   float* rstd, float* mmean, float* mvar, mbx_stream_t stream) {
@@ -1778,7 +1918,7 @@ extern "C" int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t 
   bn_fused_grid(M, C, rows, groups, chunks, rpc);
   hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
                      1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
-                     mvar, rpc);
+                     mvar, rpc, ChanMap{}, nullptr);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

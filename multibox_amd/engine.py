@@ -28,6 +28,7 @@ from . import _lib, ops
 from .ops import View
 
 BN_EPS = 0.001           # train.py:96
+STATS_ROWS = int(os.environ.get("MBX_STATS_ROWS", "16"))          # replica rows of the atomically added batch-norm statistics (mbx_conv_desc.stats_rows_mod)
 WEIGHT_DECAY = 0.00004   # train.py:104-105
 
 
@@ -109,6 +110,10 @@ class Net:
         # (no atomics) and un-split weight-gradient tiles (one adder per element); slower, same mathematics
         self.deterministic = bool(int(os.environ.get("MBX_DETERMINISTIC", "0")))
         self.no_onepass = self.deterministic or bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
+        # forward batch-norm statistics ADDED by the convolution epilogues into STATS_ROWS replica rows per layer (float32
+        # atomics; cleared with the work counters at the start of forward()), reduced by the apply launch itself: no finalize
+        # launch (>= 4.4 us each, 130 per step).  Off in deterministic mode (plain row per tile + finalize); MBX_ATOMIC_STATS=0: A/B
+        self.atomic_stats = mode == "train" and not self.deterministic and os.environ.get("MBX_ATOMIC_STATS", "1") != "0"
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
@@ -490,7 +495,7 @@ class Net:
 
     def _alloc_scratch(self):
         dev = self.dev
-        max_y = max_stats = max_bwd = 0
+        max_y = max_stats = max_bwd = n_stats16 = 0
         self.y_tmp = {}
         l = _lib.lib()
         # batch-norm groups that apply: training-mode BN on every member, same pixels / relu / trainability, consecutive in
@@ -524,6 +529,10 @@ class Net:
                     ybuf = g.y
                 ko = 0 if g is None else g.koff[g.members.index(op)]
                 op.y_view = View(ybuf, N_, H_, W_, op.K, K_all, ko)
+                if lead:
+                    op.stats16_base = n_stats16                 # [STATS_ROWS][K_all][2] floats of the layer / group
+                    n_stats16 += STATS_ROWS * K_all * 2
+                op.stats16_off = (op.stats16_base if g is None else g.members[0].stats16_base) + 2 * ko
                 d = self._desc(op, op.y_view)
                 rows = max(ops.conv_stats_rows(d), (op.M + 63) // 64)                                   # any tile height
                 if g is None and ops.splitk_slices(d, self.n_cus):
@@ -562,6 +571,12 @@ class Net:
                 op.bn_ws_off = ws_floats
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(K_all) // 4 + 7) // 8 * 8
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
+        # ONE buffer cleared by one fill at the start of forward(): [work counters of the persistent launches | statistics rows]
+        n_ctr = self.i5_counters.numel()
+        self._fwd_clear = torch.zeros(n_ctr + max(n_stats16, 4), dtype=torch.int32, device=dev)
+        self.i5_counters = self._fwd_clear[:n_ctr]
+        self.stats16 = self._fwd_clear[n_ctr:].view(torch.float32)
+        self.bn_thr = torch.zeros(max(self.nBt, 8), dtype=torch.float32, device=dev)    # relu threshold on y per channel (mbx_bn_apply_fused_mapped)
         self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)    # workgroups that gave up on a grid barrier, ever
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
@@ -620,9 +635,14 @@ class Net:
                 # own statistics partials; the LAST member's launch is followed by ONE finalize and ONE apply for the group
                 g = op.group
                 i = g.members.index(op)
-                d = self._tune(op, self._desc(op, op.y_view, stats=self.stats_scratch[op.stats_off:]), "fwd")
+                use16 = self.atomic_stats
+                if use16:
+                    d = self._tune(op, self._desc(op, op.y_view, stats=self.stats16[op.stats16_off:], stats_rows_mod=STATS_ROWS,
+                                                  stats_ld=g.K), "fwd")
+                else:
+                    d = self._tune(op, self._desc(op, op.y_view, stats=self.stats_scratch[op.stats_off:]), "fwd")
                 g.rows[i] = ops.conv_stats_rows(d)
-                assert g.rows[i] * op.K * 2 <= (g.stats_off[i + 1] - g.stats_off[i] if i + 1 < len(g.members) else 1 << 62)
+                assert use16 or g.rows[i] * op.K * 2 <= (g.stats_off[i + 1] - g.stats_off[i] if i + 1 < len(g.members) else 1 << 62)
                 g.fwd_desc[i] = d
                 if i + 1 < len(g.members):
                     # (a group of two whose convolutions resolve to the same small-tile kernel run as ONE launch, issued with the
@@ -639,9 +659,11 @@ class Net:
                 mean, rstd = self._sl(self.bn_mean, lead.beta_off, g.K), self._sl(self.bn_rstd, lead.beta_off, g.K)
                 mm, mv = self._sl(self.MM, lead.beta_off, g.K), self._sl(self.MV, lead.beta_off, g.K)
                 var, beta = self._sl(self.bn_var, lead.beta_off, g.K), self._sl(self.Bt, lead.beta_off, g.K)
+                thr = self._sl(self.bn_thr, lead.beta_off, g.K)
+                s16 = self.stats16[lead.stats16_base:]
 
                 def run(d=d, op=op, g=g, parts=parts, rows_a=rows_a, cs_a=cs_a, amap=amap, a_ptr=a_ptr, mean=mean, rstd=rstd,
-                        mm=mm, mv=mv, var=var, beta=beta, n=n):
+                        mm=mm, mv=mv, var=var, beta=beta, n=n, use16=use16, thr=thr, s16=s16):
                     s = st()
                     if g.pair_fwd:
                         _lib.check(l.mbx_conv_pair(C.byref(g.fwd_desc[0]), C.byref(d), s), "pair " + op.name)
@@ -650,6 +672,13 @@ class Net:
                     decay = self.bn_decay
                     if self.defer_moving:
                         mm, mv, decay = None, var, -1.0
+                    if use16:
+                        # every member ADDED its tile sums into the group's 16 rows: the apply launch reduces them itself
+                        _lib.check(l.mbx_bn_apply_fused_mapped(s16.data_ptr(), STATS_ROWS, op.M, BN_EPS, decay, g.y.data_ptr(), op.M,
+                                                               g.K, beta.data_ptr(), int(op.relu), a_ptr, op.out.ld, C.byref(amap),
+                                                               mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv),
+                                                               thr.data_ptr(), s), "bn_apply_fused_mapped")
+                        return
                     _lib.check(l.mbx_bn_finalize_parts(parts, rows_a, cs_a, n, op.M, BN_EPS, decay, mean.data_ptr(), rstd.data_ptr(),
                                                        ops._p(mm), ops._p(mv), s), "bn_finalize_parts")
                     _lib.check(l.mbx_bn_apply_mapped(g.y.data_ptr(), op.M, g.K, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
@@ -657,7 +686,12 @@ class Net:
                 L.append(run)
             elif op.kind == "bn":
                 yv = op.y_view
-                d = self._tune(op, self._desc(op, yv, stats=self.stats_scratch), "fwd")
+                fpool = getattr(op, "fused_pool", None)
+                use16 = self.atomic_stats and fpool is None          # (the fused apply + max-pool launch reads finalized statistics)
+                if use16:
+                    d = self._tune(op, self._desc(op, yv, stats=self.stats16[op.stats16_off:], stats_rows_mod=STATS_ROWS), "fwd")
+                else:
+                    d = self._tune(op, self._desc(op, yv, stats=self.stats_scratch), "fwd")
                 S_ = ops.splitk_slices(d, self.n_cus) if torch.device(self.dev).type == "cuda" else 0
                 if S_:
                     # long K, few tiles (the 3x3 head convolutions on the 1536-channel map): K slices + a reduce launch
@@ -677,17 +711,25 @@ class Net:
                 out = op.out
 
                 var = self._sl(self.bn_var, op.beta_off, op.K)
+                thr = self._sl(self.bn_thr, op.beta_off, op.K)
+                s16 = self.stats16[op.stats16_off:]
 
-                fpool = getattr(op, "fused_pool", None)
                 if fpool is not None:
                     fpool.fused_fwd = True
 
-                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var, fpool=fpool):
+                def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var, fpool=fpool,
+                        use16=use16, thr=thr, s16=s16):
                     s = st()
                     _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     decay = self.bn_decay
                     if self.defer_moving:                    # store mode: batch variance -> bn_var, moving statistics untouched
                         mm, mv, decay = None, var, -1.0
+                    if use16:
+                        _lib.check(l.mbx_bn_apply_fused_mapped(s16.data_ptr(), STATS_ROWS, op.M, BN_EPS, decay, op.y_view.ptr, op.M,
+                                                               op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld, None,
+                                                               mean.data_ptr(), rstd.data_ptr(), ops._p(mm), ops._p(mv),
+                                                               thr.data_ptr(), s), "bn_apply_fused_mapped")
+                        return
                     if fpool is not None:
                         # the activation feeds only a 3x3 / 2 max-pool: normalise and pool in one pass, never store it
                         po = fpool.out
@@ -908,6 +950,14 @@ class Net:
                     # graphs) when a grid barrier has timed out -- e.g. RCCL kernels holding more CUs than bn_max_wg allows for
                     def pre(s, one=pre_onepass, three=pre):
                         (three if self.no_onepass else one)(s)
+                    if os.environ.get("MBX_PROBE_BN_APPLY_ONLY") == "1":
+                        # timing probe (WRONG results): what a batch-norm backward that is ONE streaming launch would cost --
+                        # the apply launch of the three-launch form on stale totals
+                        def pre(s, op=op, da=da, da_ptr=da_ptr, dmap=dmap, mean=mean, rstd=rstd, beta=beta, Kb=Kb, M=M, y_ptr=y_ptr,
+                                dy_ptr=dy_ptr):
+                            _lib.check(l.mbx_bn_bwd_apply_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
+                                                                 mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
+                                                                 dy_ptr, dmap, s), "bn_bwd_apply")
             ddesc = None
             if op.need_dx:
                 gx = self._gview(op.x)
@@ -1015,8 +1065,8 @@ class Net:
                                              self.images.buf.data_ptr(), torch.cuda.current_stream().cuda_stream), "pack_input")
 
     def forward(self):
-        if self._i5_used:
-            self.i5_counters.zero_()               # (forward AND backward launches of this pass)
+        if self._i5_used or self.atomic_stats:
+            self._fwd_clear.zero_()                # work counters (forward AND backward launches of this pass) + statistics rows
         for f in self.fwd_launches:
             f()
         return self.locs, self.logits

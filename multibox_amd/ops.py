@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("work_counter", C.c_void_p),
         ("max_workgroups", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("stats_rows_mod", C.c_int32), ("stats_ld", C.c_int32),
     ]
 
 
@@ -99,7 +100,8 @@ def _p(t):
 
 
 def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed=0, epilogue=EPI_STORE, relu=0,
-              accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None, acc_src: View = None):
+              accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None, acc_src: View = None,
+              stats_rows_mod=0, stats_ld=0):
     d = ConvDesc()
     d.x, d.x_img_stride, d.ldx = x.ptr, x.img_stride, x.ld
     d.N, d.H_in, d.W_in, d.C_in = x.N, x.H, x.W, x.C
@@ -113,6 +115,7 @@ def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed
         d.skip, d.skip_img_stride, d.ld_skip = skip.ptr, skip.img_stride, skip.ld
     d.rscale = float(rscale)
     d.stats_partial = _p(stats)
+    d.stats_rows_mod, d.stats_ld = int(stats_rows_mod), int(stats_ld)
     if acc_src is not None:
         d.acc_src, d.acc_img_stride, d.ld_acc = acc_src.ptr, acc_src.img_stride, acc_src.ld
     return d

@@ -201,6 +201,94 @@ def test_conv_direct3_bit_identical(T, g):
     assert l.mbx_conv_supported(C.byref(bad)) == -2
 
 
+@pytest.mark.parametrize("g,cfg", [(("a1", 3, 35, 35, 64, 96, 3, 3, 1, (1, 1, 1, 1)), 0), (("a2", 2, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), 10),
+                                   (("a3", 3, 17, 17, 384, 320, 1, 1, 1, (0, 0, 0, 0)), 34), (("a4", 4, 35, 35, 320, 96, 1, 1, 1, (0, 0, 0, 0)), 35),
+                                   (("a5", 2, 60, 60, 32, 32, 3, 3, 1, (0, 0, 0, 0)), 96), (("a6", 8, 8, 8, 1536, 96, 3, 3, 1, (1, 1, 1, 1)), 128 + 6)] +
+                         [(("b%d" % c, 2, 8, 8, 96, 96, 3, 3, 1, (0, 0, 0, 0)), c) for c in list(range(1, 15)) + [33, 34, 35, 36, 37]] +
+                         [(("c%d" % c, 5, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)), c) for c in list(range(1, 15)) + [33, 34, 35, 36, 37]],
+                         ids=["igemm3", "igemm3_2deep", "igemm5_128x128", "igemm5_192x128", "direct3", "split_k"] +
+                         ["small_cfg%d" % c for c in list(range(1, 15)) + [33, 34, 35, 36, 37]] +
+                         ["mid_cfg%d" % c for c in list(range(1, 15)) + [33, 34, 35, 36, 37]])
+def test_conv_stats_atomic_rows(T, g, cfg):
+    """mbx_conv_desc.stats_rows_mod = 16 (round 4): the tiles ADD their statistics sums into 16 rows of a zeroed table
+    (float32 atomics) instead of writing a row each -- for every kernel family with a statistics epilogue.  Outputs
+    bit-identical to the plain launch; the 16 rows sum to the plain rows' sums (float32 rounding of a different grouping:
+    rtol 1e-5); with stats_ld the sums land in a channel slice of a wider table, the rest of which stays zero; and
+    mbx_bn_apply_fused_mapped on the 16 rows gives mean / rstd / activation of finalize + apply on the plain rows."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=3)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    stream = torch.cuda.current_stream().cuda_stream
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    M = N * Ho * Wo
+    ws = None
+
+    def run(stats, mod, ld):
+        nonlocal ws
+        yb = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=stats, stats_rows_mod=mod, stats_ld=ld)
+        d.tile_config = cfg
+        if cfg > 128:
+            ws = torch.empty(int(l.mbx_conv_splitk_workspace_bytes(C.byref(d))) // 4, dtype=torch.float32, device="cuda")
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        assert mod == 0 or ops.conv_stats_rows(d) == mod
+        ops.conv(d)
+        torch.cuda.synchronize()
+        return yb, d
+
+    d0 = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], ops.View.alloc(N, Ho, Wo, Co))
+    d0.tile_config = cfg
+    rows = ops.conv_stats_rows(d0)
+    plain = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
+    y0, _ = run(plain, 0, 0)
+    ld = Co + 24
+    table = torch.zeros((16, ld, 2), dtype=torch.float32, device="cuda")
+    y1, _ = run(table[:, 8:], 16, ld)                 # the member's first channel = channel 8 of the table
+    assert torch.equal(y0.tensor(), y1.tensor())
+    assert float(table[:, :8].abs().max()) == 0 and float(table[:, 8 + Co:].abs().max()) == 0
+    want, got = plain.double().sum(0).cpu(), table[:, 8:8 + Co].double().sum(0).cpu()
+    assert torch.allclose(want, got, rtol=1e-5, atol=1e-3), float((want - got).abs().max())
+    assert int((table[:, 8:8 + Co, 1].abs().sum(1) > 0).sum()) == min(16, rows)       # spread over the rows, not piled on one
+    # the consumer: finalize + apply on the plain rows against the one-launch form on the 16 rows
+    dense = table[:, 8:8 + Co].contiguous()
+    beta = (torch.randn(Co, generator=torch.Generator().manual_seed(1)) * 0.3).cuda()
+    outs = []
+    for fused in (False, True):
+        mean, rstd = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        mm, mv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        a = ops.View.alloc(N, Ho, Wo, Co + 16, zero=True)
+        thr = torch.zeros(Co, device="cuda")
+        if fused:
+            cm = _lib.ChanMap()
+            cm.n, cm.c_begin[0], cm.offset[0], cm.c_begin[1], cm.offset[1] = 2, 0, 0, 8, 16      # channels >= 8 shifted by 16
+            assert l.mbx_bn_apply_fused_mapped(dense.data_ptr(), 16, M, 0.001, -1.0, y1.ptr, M, Co, beta.data_ptr(), 1, a.ptr, a.ld,
+                                               C.byref(cm), mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                               thr.data_ptr(), stream) == 0
+        else:
+            assert l.mbx_bn_finalize(plain.data_ptr(), rows, Co, M, 0.001, -1.0, mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(),
+                                     mv.data_ptr(), stream) == 0
+            cm = _lib.ChanMap()
+            cm.n, cm.c_begin[0], cm.offset[0], cm.c_begin[1], cm.offset[1] = 2, 0, 0, 8, 16
+            assert l.mbx_bn_apply_mapped(y0.ptr, M, Co, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1, a.ptr, a.ld,
+                                         C.byref(cm), stream) == 0
+        torch.cuda.synchronize()
+        outs.append((mean.cpu(), rstd.cpu(), mm.cpu(), mv.cpu(), a.buf.float().cpu().reshape(-1, Co + 16), thr.cpu()))
+    for i in range(4):
+        assert torch.allclose(outs[0][i], outs[1][i], rtol=2e-5, atol=1e-6), i
+    ok, msg = close(torch, outs[1][4], outs[0][4])
+    assert ok, msg
+    assert float(outs[1][4][:, 8:24].abs().max()) == 0                                  # the hole the map leaves
+    thr_ref = outs[1][0] - beta.cpu() / outs[1][1]
+    assert torch.allclose(outs[1][5], thr_ref, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("cfg", [0, 10, 11, 5, 6])
 def test_conv_pair_bit_identical(T, cfg):
     """mbx_conv_pair (round 4): two independent convolutions of different shape (block35's sibling 3x3 branches: 32 -> 32 and
