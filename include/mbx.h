@@ -140,6 +140,26 @@ typedef enum {
   MBX_EPI_STORE_F32 = 3 /* y = acc as float32            (head outputs, model.py:213-293)     */
 } mbx_epilogue;
 
+/* BATCH-NORM BACKWARD STATISTICS FROM THE DATA GRADIENT THAT WRITES THE ACTIVATION GRADIENT (round 4).  The backward pass of
+ * slim.batch_norm + relu (train.py:94-99) needs, per channel, sum g and sum g xhat over all pixels before it can write one
+ * element -- with g = da (a > 0): a grid-wide dependency that cost a grid barrier per layer (mbx_bn_bwd_onepass) or three
+ * launches.  The convolution whose data gradient WRITES da already holds every element of it in registers: with this table
+ * attached to its descriptor (mbx_conv_desc.bn_bwd_stats) its epilogue also reads y at the same positions and ADDS
+ *   sum g  and  sum g y,   g = (y > relu_thr[c]) ? bf16(da) : 0
+ * (float32 atomics) into row (tile index mod rows_mod) of stats[i] = [rows_mod][stats_ld[i]][2], ZERO at launch.  Output
+ * channels [c_begin[i], c_begin[i+1]) of the launch belong to entry i (at most 4: the gradient of a concat buffer slice
+ * feeds several layers): y[i] = that layer's pre-BN output [M, ld_y[i]] at the entry's first channel, relu_thr[i] / stats[i]
+ * likewise.  c_begin ascending from 0 in multiples of 32.  mbx_bn_bwd_apply_rows then is ONE streaming launch.
+ * (sum g xhat = rstd (sum g y - mean sum g); the mask y > mean - beta / rstd is the forward's (y - mean) rstd + beta > 0.)
+ * Plain bf16 STORE data gradients only (no accumulate, no mask, stride 1); anything else: MBX_ERR_INVALID_ARG / UNSUPPORTED. */
+typedef struct {
+  int32_t n, rows_mod;
+  int32_t c_begin[4];
+  const void* y[4]; int32_t ld_y[4];
+  const float* relu_thr[4];
+  float* stats[4]; int32_t stats_ld[4];
+} mbx_bn_bwd_stats;
+
 typedef struct {
   /* input view */
   const void* x; int64_t x_img_stride; int32_t ldx;
@@ -193,6 +213,7 @@ typedef struct {
      stats_ld (0: C_out): channels per row -- sibling convolutions of a batch-norm group add into channel slices of one
      table (stats_partial then points at the member's first channel).                                              */
   int32_t stats_rows_mod, stats_ld;
+  const mbx_bn_bwd_stats* bn_bwd_stats;   /* HOST, may be NULL: see above */
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
@@ -364,6 +385,16 @@ int mbx_bn_bwd_reduce_mapped(const void* da, int ld_da, const void* a, int ld_a,
 int mbx_bn_bwd_apply_mapped(const void* da, int ld_da, const void* a, int ld_a, int relu, const void* y, int64_t M, int C,
                             const float* mean, const float* rstd, const float* beta, const float* m12, void* dy,
                             const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
+
+/* Backward through relu + batch norm as ONE STREAMING launch, for a layer whose sums {sum g, sum g y} were ADDED into
+ * `rows` rows of stats = [rows][C][2] by the data gradient(s) that wrote da (mbx_bn_bwd_stats above): every workgroup
+ * reduces the rows of all C channels itself, then dy = rstd (g - m1 - xhat m2) with g = (y > relu_thr) ? da : 0,
+ * m1 = sum g / M, m2 = rstd (sum g y - mean sum g) / M; dbeta [C] += sum g (may be NULL).  No grid barrier, no
+ * workspace to time out on: the same launch with and without a concurrent stream.  da through a group's channel map
+ * (NULL: identity).  C <= 2048, rows <= 16.                                                                       */
+int mbx_bn_bwd_apply_rows(const float* stats, int rows, const void* da, int ld_da, const void* y, int64_t M, int C,
+                          const float* mean, const float* rstd, const float* relu_thr, float* dbeta, void* dy,
+                          const mbx_chan_map* da_map /*HOST*/, mbx_stream_t stream);
 
 /* The same backward pass in ONE launch (relu mask recomputed from y): every workgroup keeps its slice of
  * (da, y) in registers across a grid barrier, so da and y are read once.  Available when the layer fits

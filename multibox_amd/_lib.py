@@ -68,6 +68,7 @@ _SIGS = {
     "mbx_bn_fold": (I, [P, P, P, F, I, P, P, P]),
     "mbx_bn_apply_fused": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P]),
     "mbx_bn_apply_fused_mapped": (I, [P, I, C.c_int64, F, F, P, C.c_int64, I, P, I, P, I, P, P, P, P, P, P, P]),
+    "mbx_bn_bwd_apply_rows": (I, [P, I, P, I, P, C.c_int64, I, P, P, P, P, P, P, P]),
     "mbx_bn_bwd_rows": (I, [C.c_int64, I]),
     "mbx_bn_bwd_onepass_workspace_bytes": (C.c_size_t, [I]),
     "mbx_bn_bwd_onepass_supported": (I, [C.c_int64, I, I]),
@@ -101,6 +102,12 @@ class MbxError(RuntimeError):
 class ChanMap(C.Structure):
     """mbx_chan_map (include/mbx.h)."""
     _fields_ = [("n", C.c_int32), ("c_begin", C.c_int32 * 4), ("offset", C.c_int32 * 4)]
+
+
+class BnBwdStats(C.Structure):
+    """mbx_bn_bwd_stats (include/mbx.h)."""
+    _fields_ = [("n", C.c_int32), ("rows_mod", C.c_int32), ("c_begin", C.c_int32 * 4), ("y", C.c_void_p * 4), ("ld_y", C.c_int32 * 4),
+                ("relu_thr", C.c_void_p * 4), ("stats", C.c_void_p * 4), ("stats_ld", C.c_int32 * 4)]
 
 
 class Head(C.Structure):

@@ -31,7 +31,7 @@ namespace {
 
 // EV: epilogue variant fixed at compile time (no per-element branching):
 //   0 store, 1 store + BN statistics partials, 2 accumulate into y (+ optional relu mask from `skip`),
-//   3 affine (+relu), 4 residual (+relu), 5 float32 store.
+//   3 affine (+relu), 4 residual (+relu), 5 float32 store, 6 store + batch-norm BACKWARD statistics (data gradients).
 // SH: the stride-2 data gradient (input dilated by 2).  Its own instantiation, so that the parity walk below costs
 // the other 400 launches per step nothing (as a run-time branch in one kernel it cost them 0.6 ms per step).
 // MODE 1: pointwise (1x1, unit stride, no padding) -- the two-instruction address path, no tap walk: 60 % of the launches.
@@ -251,8 +251,8 @@ __device__ __forceinline__ void conv_igemm3_body(const ConvK& p, const int bid_,
   } else {
     float s1[NA][8], s2[NA][8];
     // (reads in flight per lane: all of the tile's, or two pixel blocks at a time where that would take > 64 registers)
-    conv_epilogue_direct<EV, SH, NI, MI, (EV == 2 && MI * NA >= 8 && MI % 2 == 0) ? 2 : MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
-    if constexpr (EV == 1) {
+    conv_epilogue_direct<EV, SH, NI, MI, ((EV == 2 || EV == 6) && MI * NA >= 8 && MI % 2 == 0) ? 2 : MI>(p, acc, m0 + wm * TM + frow, n0 + cl0, s1, s2);
+    if constexpr (EV == 1 || EV == 6) {
       // batch-norm statistics partials of this tile (of the STORED, bf16-rounded values), in a fixed order: the lane's
       // MI pixels (above) -> the 16 lanes that share its channels (DPP row sums) -> the WMW waves along the pixel
       // dimension through LDS (the ring is idle: every wave is past the last barrier of the K loop)
@@ -272,7 +272,7 @@ __device__ __forceinline__ void conv_igemm3_body(const ConvK& p, const int bid_,
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WMW; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-        stats_write(p, tile_m, n0 + tid, x1, x2);
+        if constexpr (EV == 6) bw_stats_write(p, tile_m, n0 + tid, x1, x2); else stats_write(p, tile_m, n0 + tid, x1, x2);
       }
     }
   }
@@ -1204,7 +1204,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
   if (k.dry == 2) {
     g_capture.k = k; g_capture.bm = BM; g_capture.bn = BN; g_capture.wnw = WNW; g_capture.wmw = WMW; g_capture.nstg = NSTG;
     g_capture.ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
-                   : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
     g_capture.mode = k.shift ? 2 : k.pw ? 1 : 0;
     g_capture.valid = 1;
     return MBX_OK;
@@ -1212,8 +1212,8 @@ int launch_igemm(ConvK& k, hipStream_t s) {
   {
     const size_t lds = NSTG * (size_t)(BM + BN) * 128;          // the ring; the epilogue works out of the accumulators
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
-                   : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
-    static bool attr_set3[6] = {false, false, false, false, false, false};
+                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+    static bool attr_set3[7] = {false, false, false, false, false, false, false};
 #define MBX_LAUNCH_EV(EV)                                                                                     \
     case EV:                                                                                                  \
       if (!attr_set3[EV]) {                                                                                   \
@@ -1241,14 +1241,14 @@ int launch_igemm(ConvK& k, hipStream_t s) {
       hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WNW, WMW, EV, 2, NSTG>), dim3(k.tiles_m * k.tiles_n),      \
                          dim3(64 * WNW * WMW), lds, s, k);                                                    \
     } while (0)
-    if (k.dry) return (k.shift && ev != 0 && ev != 2) ? MBX_ERR_UNSUPPORTED : MBX_OK;
+    if (k.dry) return (k.shift && ev != 0 && ev != 2) ? MBX_ERR_UNSUPPORTED : MBX_OK;       // (the stride-2 walk: store / accumulate only)
     if (k.shift) {                               // stride-2 data gradient: its own instantiations (store / accumulate)
       if (ev == 0) MBX_LAUNCH_SH(0, 0);
       else if (ev == 2) MBX_LAUNCH_SH(2, 1);
       else return MBX_ERR_UNSUPPORTED;
     } else
     switch (ev) {
-      MBX_LAUNCH_EV(0) MBX_LAUNCH_EV(1) MBX_LAUNCH_EV(2) MBX_LAUNCH_EV(3) MBX_LAUNCH_EV(4) MBX_LAUNCH_EV(5)
+      MBX_LAUNCH_EV(0) MBX_LAUNCH_EV(1) MBX_LAUNCH_EV(2) MBX_LAUNCH_EV(3) MBX_LAUNCH_EV(4) MBX_LAUNCH_EV(5) MBX_LAUNCH_EV(6)
     }
 #undef MBX_LAUNCH_SH
 #undef MBX_LAUNCH_EV
@@ -1311,13 +1311,14 @@ extern "C" int mbx_conv_pair(const mbx_conv_desc* a, const mbx_conv_desc* b, mbx
   if (!g_capture.valid) return MBX_ERR_UNSUPPORTED;
   cb = g_capture;
   if (ca.bm != cb.bm || ca.bn != cb.bn || ca.wnw != cb.wnw || ca.wmw != cb.wmw || ca.nstg != cb.nstg || ca.ev != cb.ev ||
-      ca.mode != 0 || cb.mode != 0 || (ca.ev != 0 && ca.ev != 1) || ca.wnw != 2 || ca.wmw != 2 || ca.bn != 64)
+      ca.mode != 0 || cb.mode != 0 || (ca.ev != 0 && ca.ev != 1 && ca.ev != 6) || ca.wnw != 2 || ca.wmw != 2 || ca.bn != 64)
     return MBX_ERR_UNSUPPORTED;
   ca.k.dry = cb.k.dry = 0;
   hipStream_t s = mbx_s(stream);
 #define MBX_PAIR(BM_, NSTG_)                                                                                      \
   if (ca.bm == BM_ && ca.nstg == NSTG_)                                                                           \
-    return ca.ev ? launch_pair_inst<BM_, 64, 2, 2, 1, NSTG_>(ca.k, cb.k, s) : launch_pair_inst<BM_, 64, 2, 2, 0, NSTG_>(ca.k, cb.k, s);
+    return ca.ev == 6 ? launch_pair_inst<BM_, 64, 2, 2, 6, NSTG_>(ca.k, cb.k, s)                                    \
+           : ca.ev ? launch_pair_inst<BM_, 64, 2, 2, 1, NSTG_>(ca.k, cb.k, s) : launch_pair_inst<BM_, 64, 2, 2, 0, NSTG_>(ca.k, cb.k, s);
   MBX_PAIR(128, 2) MBX_PAIR(128, 3) MBX_PAIR(64, 2) MBX_PAIR(64, 3)
 #undef MBX_PAIR
   return MBX_ERR_UNSUPPORTED;
@@ -1361,6 +1362,23 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   k.stats = d->stats_partial;
   if (d->stats_rows_mod < 0 || d->stats_rows_mod > 1024 || d->stats_ld < 0 || (d->stats_ld && d->stats_ld < d->C_out)) return MBX_ERR_INVALID_ARG;
   k.stats_mod = d->stats_rows_mod; k.stats_ld = d->stats_ld ? d->stats_ld : d->C_out;
+  k.bw_n = 0; k.bw_mod = 1;
+  for (int i = 0; i < 4; ++i) { k.bw_cb[i] = 1 << 30; k.bw_ldy[i] = 0; k.bw_sld[i] = 0; k.bw_y[i] = nullptr; k.bw_thr[i] = nullptr; k.bw_stats[i] = nullptr; }
+  if (d->bn_bwd_stats) {
+    // BN-backward statistics epilogue: plain bf16 store only (a scale is fine), never with the forward statistics
+    const mbx_bn_bwd_stats* b = d->bn_bwd_stats;
+    if (d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->stats_partial || b->n < 1 || b->n > 4 || b->rows_mod < 1 ||
+        b->rows_mod > 1024 || b->c_begin[0] != 0)
+      return MBX_ERR_INVALID_ARG;
+    for (int i = 0; i < b->n; ++i) {
+      if (!b->y[i] || !b->relu_thr[i] || !b->stats[i] || (reinterpret_cast<uintptr_t>(b->y[i]) & 15) || b->ld_y[i] % 8 || b->c_begin[i] % 32 ||
+          b->c_begin[i] >= d->C_out || (i && b->c_begin[i] <= b->c_begin[i - 1]) || b->stats_ld[i] <= 0)
+        return MBX_ERR_INVALID_ARG;
+      k.bw_cb[i] = b->c_begin[i]; k.bw_ldy[i] = b->ld_y[i]; k.bw_sld[i] = b->stats_ld[i];
+      k.bw_y[i] = reinterpret_cast<const unsigned short*>(b->y[i]); k.bw_thr[i] = b->relu_thr[i]; k.bw_stats[i] = b->stats[i];
+    }
+    k.bw_n = b->n; k.bw_mod = b->rows_mod;
+  }
   if (d->accumulate && d->acc_src) {
     if (d->ld_acc % 8 || (reinterpret_cast<uintptr_t>(d->acc_src) & 15) || (long long)d->N * d->acc_img_stride >= (1LL << 31))
       return MBX_ERR_INVALID_ARG;
@@ -1412,7 +1430,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   if (d->tile_config > kSplitFlag) {
     // split-K: forward convolutions with a bf16 store (+ statistics) epilogue only; partials in the caller's workspace
     const int S = d->tile_config - kSplitFlag;
-    if (S < 2 || S > kSplitMax || d->transposed || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->rscale != 0.f)
+    if (S < 2 || S > kSplitMax || d->transposed || d->bn_bwd_stats || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->rscale != 0.f)
       return MBX_ERR_UNSUPPORTED;
     const int ldp = ((d->C_out + 7) / 8) * 8;
     int ksplit, kps;

@@ -50,7 +50,7 @@ conv_igemm5_kernel(const ConvK p) {
   constexpr bool PW = MODE == 1;
   constexpr int BM = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, MI = G::MI, NI = G::NI, STAGE = G::STAGE, NST = G::NST;
   constexpr int NL = MY + NW;                                       // LDS-DMA instructions per loader wave and K step
-  constexpr int NBAR = EV == 1 ? 1 : 0;                             // barriers of one tile's epilogue (statistics reduce)
+  constexpr int NBAR = (EV == 1 || EV == 6) ? 1 : 0;                             // barriers of one tile's epilogue (statistics reduce)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   float* const red = reinterpret_cast<float*>(smem + NST * STAGE);  // [WM][BN][2]
   // QUEUED tile assignment (p.work_counter): tile sequence of this workgroup = its first tile by position, then
@@ -229,7 +229,7 @@ conv_igemm5_kernel(const ConvK p) {
     // 128x64 / 128x128 / 256x64 residual tiles, half of it for 256x128; the rest is read in the epilogue.)
     constexpr int NA = NI / 2;
     // pixel blocks whose reads are issued ahead: 16 registers' worth (four 16-byte reads per lane)
-    constexpr int PRE_RAW = (EV == 4 || EV == 2) ? 4 / (NA * (EV == 2 ? 2 : 1)) : 0;
+    constexpr int PRE_RAW = (EV == 4 || EV == 2 || EV == 6) ? 4 / (NA * (EV == 2 ? 2 : 1)) : 0;
     constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
     u32x4 pla[PREB > 0 ? PREB : 1][NA], plb[PREB > 0 ? PREB : 1][NA];
@@ -278,8 +278,8 @@ conv_igemm5_kernel(const ConvK p) {
       conv_epilogue_range<EV, false, NI, MI, PREB, MI, CH>(p, acc, mlane, clane, sh, sc, s1, s2);
     }
     MBX5_STAMP(2);                                                  // rows written
-    if constexpr (EV == 1) {
-      // batch-norm statistics partials of this tile: lane's pixels -> the 16 lanes sharing its channels (DPP row sums)
+    if constexpr (EV == 1 || EV == 6) {
+      // batch-norm statistics partials of this tile (EV = 6: the backward sums of the layers this data gradient feeds): lane's pixels -> the 16 lanes sharing its channels (DPP row sums)
       // -> the WM waves along the pixel dimension through `red` (its own LDS area: the ring is being refilled)
 #pragma unroll
       for (int A = 0; A < NA; ++A)
@@ -296,7 +296,7 @@ conv_igemm5_kernel(const ConvK p) {
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int w = 0; w < G::WM; ++w) { x1 += red[(w * BN + tid) * 2]; x2 += red[(w * BN + tid) * 2 + 1]; }
-        stats_write(p, tile_m, n0 + tid, x1, x2);
+        if constexpr (EV == 6) bw_stats_write(p, tile_m, n0 + tid, x1, x2); else stats_write(p, tile_m, n0 + tid, x1, x2);
       }
       // (no second barrier: `red` is rewritten only after the next tile's K loop, nk >= 1 barriers away)
     }
@@ -318,9 +318,13 @@ int launch5(ConvK& k, hipStream_t s) {
   }
   int grid = ntiles < ncu ? ntiles : ncu;                           // one persistent block per CU
   if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;             // ... or fewer: CUs left to a kernel on another stream
-  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+  // the BN-backward statistics epilogue (EV = 6) on the 256 x 128 tile: 64 accumulator + 48 sum / threshold registers + the
+  // reads in flight do not fit the 128-register budget of a 16-wave block (33 spilled): not built, the caller takes 192 x 128
+  constexpr bool kNo6 = MY == 4 && NW == 2;
+  if (ev == 6 && kNo6) return MBX_ERR_UNSUPPORTED;
   if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
-  static bool attr[5][2] = {};
+  static bool attr[7][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \
   do {                                                                                                        \
     if (!attr[EV][MODE]) {                                                                                    \
@@ -331,7 +335,12 @@ int launch5(ConvK& k, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, MODE>), dim3(grid), dim3(1024), G::LDS_BYTES, s, k);   \
   } while (0)
 #define MBX5_EV(EV) case EV: if (k.pw) MBX5_LAUNCH(EV, 1); else MBX5_LAUNCH(EV, 0); break;
-  switch (ev) { MBX5_EV(0) MBX5_EV(1) MBX5_EV(2) MBX5_EV(3) MBX5_EV(4) }
+  switch (ev) {
+    MBX5_EV(0) MBX5_EV(1) MBX5_EV(2) MBX5_EV(3) MBX5_EV(4)
+    case 6:
+      if constexpr (!kNo6) { if (k.pw) MBX5_LAUNCH(6, 1); else MBX5_LAUNCH(6, 0); }
+      break;
+  }
 #undef MBX5_EV
 #undef MBX5_LAUNCH
   MBX_LAUNCH_CHECK();

@@ -209,7 +209,7 @@ conv_igemm7_kernel(const ConvK p) {
 int mbx_launch_igemm7(void* convk, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
   const int nk = (k.Ktot + 63) >> 6;
-  if (!k.pw || k.shift || k.stats || k.epi == MBX_EPI_STORE_F32 || nk < 2 || nk > k7MaxNk || (k.C_in % 8)) return MBX_ERR_UNSUPPORTED;
+  if (!k.pw || k.shift || k.stats || k.bw_n || k.epi == MBX_EPI_STORE_F32 || nk < 2 || nk > k7MaxNk || (k.C_in % 8)) return MBX_ERR_UNSUPPORTED;
   k.tiles_m = (k.M + k7BM - 1) / k7BM;
   k.tiles_n = (k.C_out + k7BN - 1) / k7BN;
   static int ncu = 0;

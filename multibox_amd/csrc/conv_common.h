@@ -28,6 +28,15 @@ struct ConvK {
   const unsigned short* acc_src; int acc_img_stride, ld_acc;      // accumulate: OLD value read from here (may alias y)
   float* stats;
   int stats_mod, stats_ld;               // stats_mod = R > 0: tile sums ADDED atomically into row (tile % R) of [R][stats_ld][2] (zero at launch); 0: a plain row per tile
+  // EV = 6 (data gradients): BATCH-NORM BACKWARD statistics of the layers whose activation gradient this launch writes.
+  // Output channels [bw_cb[i], bw_cb[i + 1]) belong to segment i: y = that layer's pre-BN output [M][bw_ldy] (pointer at the
+  // segment's first channel), thr = its relu threshold on y, sums {sum g, sum g y} with g = (y > thr) ? stored gradient : 0
+  // ADDED into row (tile % bw_mod) of bw_stats[i] = [bw_mod][bw_sld][2].  Segment boundaries are multiples of 32 channels.
+  int bw_n, bw_mod;
+  int bw_cb[4], bw_ldy[4], bw_sld[4];
+  const unsigned short* bw_y[4];
+  const float* bw_thr[4];
+  float* bw_stats[4];
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
   int pw;                              // pointwise: R = S = 1, no padding, unit stride
@@ -76,6 +85,19 @@ __device__ __forceinline__ void stats_write(const ConvK& p, const int tile_row, 
     o[0] = x1;
     o[1] = x2;
   }
+}
+// segment of output channel c in the BN-backward statistics table (EV = 6)
+__device__ __forceinline__ int bw_seg(const ConvK& p, const int c) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < p.bw_n && c >= p.bw_cb[i]) s = i;
+  return s;
+}
+__device__ __forceinline__ void bw_stats_write(const ConvK& p, const int tile_row, const int ch, const float x1, const float x2) {
+  const int s = bw_seg(p, ch);
+  float* o = p.bw_stats[s] + ((size_t)(tile_row % p.bw_mod) * p.bw_sld[s] + (ch - p.bw_cb[s])) * 2;
+  unsafeAtomicAdd(o, x1);
+  unsafeAtomicAdd(o + 1, x2);
 }
 // pixel index m -> (image, output row, output column)
 __device__ __forceinline__ void decode_pixel(const ConvK& p, unsigned m, int& img, int& oh, int& ow) {
@@ -212,6 +234,22 @@ __device__ __forceinline__ void epi_pixel(const ConvK& p, const int m, int& img,
 template <int EV, bool SH, int NA, int BCH>
 __device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const int mlane, const int clane, const int b0,
                                                           u32x4 (&la)[BCH][NA], u32x4 (&lb)[BCH][NA]) {
+  if constexpr (EV == 6) {
+    // y of the layer that owns the lane's 8 channels at the lane's pixel (linear pixel index: never the stride-2 walk).
+    // Out-of-tile lanes read the segment's first row (valid, finite): their gradient is an exact zero and adds nothing.
+#pragma unroll
+    for (int A = 0; A < NA; ++A) {
+      const int c0 = clane + 32 * A;
+      const int sg = bw_seg(p, c0 < p.C_out ? c0 : 0);
+      const unsigned short* yb = p.bw_y[sg] + (c0 < p.C_out ? c0 - p.bw_cb[sg] : 0);
+      const long long ld = p.bw_ldy[sg];
+#pragma unroll
+      for (int bb = 0; bb < BCH; ++bb) {
+        const int m = mlane + (b0 + bb) * 16;
+        la[bb][A] = *reinterpret_cast<const u32x4*>(yb + ((m < p.M && c0 < p.C_out) ? m * ld : 0ll));
+      }
+    }
+  }
   if constexpr (EV == 2 || EV == 4) {
     const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
     const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.acc_src, p.acc_bytes);
@@ -306,6 +344,17 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[A][j] += f; s2[A][j] += f * f; }
       }
+      if constexpr (EV == 6) {
+        // batch-norm backward sums of the STORED gradient: g = relu mask (y > thr; sh holds thr) ? da : 0; sum g, sum g y
+        const unsigned w[4] = {la[bb][A].x, la[bb][A].y, la[bb][A].z, la[bb][A].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yv = bf2f((unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu)));
+          const float g = yv > sh[A][j] ? bf2f(q8[j]) : 0.f;
+          s1[A][j] += g;
+          s2[A][j] += g * yv;
+        }
+      }
     }
   }
 }
@@ -318,6 +367,18 @@ __device__ __forceinline__ void conv_epilogue_channels(const ConvK& p, const int
   for (int A = 0; A < NA; ++A)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[A][j] = 1.f; sh[A][j] = 0.f; s1[A][j] = 0.f; s2[A][j] = 0.f; }
+  if constexpr (EV == 6) {
+#pragma unroll
+    for (int A = 0; A < NA; ++A) {
+      const int c0 = clane + 32 * A;
+      if (c0 < p.C_out) {
+        const int sg = bw_seg(p, c0);
+        const float* t = p.bw_thr[sg] + (c0 - p.bw_cb[sg]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[A][j] = t[j];
+      }
+    }
+  }
   if constexpr (EV == 3 || EV == 4) {
 #pragma unroll
     for (int A = 0; A < NA; ++A) {

@@ -478,6 +478,74 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
   }
 }
 
+// ------------------------------------------- batch norm backward from FEW statistics rows (round 4)
+// The sums {sum g, sum g y} were added by the data gradient(s) that wrote da (conv EV = 6) into `rows` rows: this launch is
+// bn_apply_rows_kernel's shape -- prologue: the workgroup reduces the rows of all C channels into LDS (m1, m2 per channel),
+// the first (da, y) pair of every lane in flight meanwhile; then whole-row sweeps, a lane owning one 8-channel group.
+__global__ void __launch_bounds__(kT)
+bn_bwd_rows_kernel(const float* __restrict__ part, int rows, double inv_M, const unsigned short* __restrict__ da, int ld_da,
+                   const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ thr, float* __restrict__ dbeta,
+                   unsigned short* __restrict__ dy, const ChanMap map) {
+  extern __shared__ __attribute__((aligned(16))) float s_par[];          // [5][C]: mean, rstd, thr, m1, m2
+  const int C8 = C >> 3;
+  const int rpi = kT / C8 > 0 ? kT / C8 : 1;
+  const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
+  const bool active = rr < rpi;
+  const int c = vc << 3;
+  const long long step = (long long)gridDim.x * rpi;
+  long long m = (long long)blockIdx.x * rpi + rr;
+  const unsigned short* dap = da + c + chan_off(map, c);
+  u32x4 g0 = u32x4{0u, 0u, 0u, 0u}, y0 = u32x4{0u, 0u, 0u, 0u};
+  if (active && m < M) { g0 = ld8(dap + m * ld_da); y0 = ld8(y + m * C + c); }
+  for (int ch = threadIdx.x; ch < C; ch += kT) {
+    const float* src = part + (size_t)ch * 2;
+    double s1 = 0.0, s2 = 0.0;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+      const float2 v0 = *reinterpret_cast<const float2*>(src + (size_t)(r + 0) * C * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(src + (size_t)(r + 1) * C * 2);
+      const float2 v2 = *reinterpret_cast<const float2*>(src + (size_t)(r + 2) * C * 2);
+      const float2 v3 = *reinterpret_cast<const float2*>(src + (size_t)(r + 3) * C * 2);
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; r < rows; ++r) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)r * C * 2);
+      s1 += v.x; s2 += v.y;
+    }
+    const float mu = mean[ch], rs = rstd[ch];
+    // sum g xhat = rstd (sum g y - mean sum g), in double: the two terms nearly cancel when |mean| >> 1 / rstd
+    const double sgx = (double)rs * (s2 - (double)mu * s1);
+    s_par[ch] = mu; s_par[C + ch] = rs; s_par[2 * C + ch] = thr[ch];
+    s_par[3 * C + ch] = (float)(s1 * inv_M); s_par[4 * C + ch] = (float)(sgx * inv_M);
+    if (blockIdx.x == 0 && dbeta) dbeta[ch] += (float)s1;
+  }
+  __syncthreads();
+  if (!active) return;
+  float mu[8], rs[8], th[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = s_par[c + j]; rs[j] = s_par[C + c + j]; th[j] = s_par[2 * C + c + j]; m1[j] = s_par[3 * C + c + j]; m2[j] = s_par[4 * C + c + j];
+  }
+  u32x4 gc = g0, yc = y0;
+  for (; m < M; m += step) {
+    u32x4 gn = u32x4{0u, 0u, 0u, 0u}, yn = u32x4{0u, 0u, 0u, 0u};
+    if (m + step < M) { gn = ld8(dap + (m + step) * ld_da); yn = ld8(y + (m + step) * C + c); }
+    float g[8], yy[8], o[8];
+    unpack8(gc, g);
+    unpack8(yc, yy);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yy[j] - mu[j]) * rs[j];
+      const float gj = yy[j] > th[j] ? g[j] : 0.f;
+      o[j] = rs[j] * (gj - m1[j] - xh * m2[j]);
+    }
+    st8(dy + m * C + c, pack8(o));
+    gc = gn; yc = yn;
+  }
+}
+
 inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 inline void bn_fused_grid(long long M, int C, int rows, int& groups, int& chunks, int& rpc) {
   groups = (C + kBnGroup - 1) / kBnGroup;
@@ -1536,6 +1604,26 @@ static int ob_cus() {
     ncu = n;
   }
   return ncu;
+}
+
+extern "C" int mbx_bn_bwd_apply_rows(const float* stats, int rows, const void* da, int ld_da, const void* y, int64_t M, int C,
+                                     const float* mean, const float* rstd, const float* relu_thr, float* dbeta, void* dy,
+                                     const mbx_chan_map* da_map, mbx_stream_t stream) {
+  if (!stats || rows <= 0 || rows > 16 || !da || !y || !mean || !rstd || !relu_thr || !dy || M <= 0 || C <= 0 || C % 8 ||
+      ld_da % 8 || !al16(da) || !al16(y) || !al16(dy) || !al16(stats))
+    return MBX_ERR_INVALID_ARG;
+  if (C > kRowsMaxC) return MBX_ERR_UNSUPPORTED;
+  ChanMap cm;
+  if (to_chan_map(da_map, C, cm) != MBX_OK) return MBX_ERR_INVALID_ARG;
+  MBX_ENTER();
+  static const int rows_blocks = env_int("MBX_BN_ROWS_BLOCKS", 1024);
+  const int C8 = C / 8, rpi = kT / C8 > 0 ? kT / C8 : 1;
+  long long g = (M + rpi - 1) / rpi;
+  if (g > rows_blocks) g = rows_blocks;
+  hipLaunchKernelGGL(bn_bwd_rows_kernel, dim3((unsigned)g), dim3(kT), (size_t)5 * C * sizeof(float), mbx_s(stream), stats, rows,
+                     1.0 / (double)M, (cus)da, ld_da, (cus)y, (long long)M, C, mean, rstd, relu_thr, dbeta, (us)dy, cm);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
 }
 
 extern "C" size_t mbx_bn_bwd_onepass_workspace_bytes(int C) {

@@ -110,10 +110,22 @@ class Net:
         # (no atomics) and un-split weight-gradient tiles (one adder per element); slower, same mathematics
         self.deterministic = bool(int(os.environ.get("MBX_DETERMINISTIC", "0")))
         self.no_onepass = self.deterministic or bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
-        # forward batch-norm statistics ADDED by the convolution epilogues into STATS_ROWS replica rows per layer (float32
-        # atomics; cleared with the work counters at the start of forward()), reduced by the apply launch itself: no finalize
-        # launch (>= 4.4 us each, 130 per step).  Off in deterministic mode (plain row per tile + finalize); MBX_ATOMIC_STATS=0: A/B
-        self.atomic_stats = mode == "train" and not self.deterministic and os.environ.get("MBX_ATOMIC_STATS", "1") != "0"
+        # OPTION, off (MBX_ATOMIC_STATS=1): forward batch-norm statistics ADDED by the convolution epilogues into STATS_ROWS
+        # replica rows per layer (float32 atomics; cleared with the work counters at the start of forward()), reduced by the
+        # apply launch itself: no finalize launch.  Measured (round 4, LAB_NOTES): 130 launches of 4.5 us go, the apply launch
+        # grows by 2.2 us (the rows prologue) and every statistics convolution by 0.3-0.5 us (the atomics' acknowledgement at
+        # the end of the kernel): -0.06..-0.14 ms per step -- and the forward pass stops being run-to-run reproducible (the
+        # order of the adds), which at batch 2 / random init moves the losses by percents.  Not worth its price.
+        self.atomic_stats = mode == "train" and not self.deterministic and os.environ.get("MBX_ATOMIC_STATS", "0") == "1"
+        # batch-norm BACKWARD statistics produced by the data gradient that writes the activation gradient (mbx_bn_bwd_stats):
+        # the layer's backward then is ONE streaming launch (mbx_bn_bwd_apply_rows) instead of the grid-barrier launch --
+        # wherever every channel of the layer's activation has exactly one consumer and that is a stride-1 convolution
+        # (_plan_bw_stats: the branch layers of block35 / block17 / block8, 121 of 141 launches).  Needs the relu
+        # thresholds the atomic-statistics forward writes.  OPTION, off (MBX_ATOMIC_STATS=1 MBX_BW_STATS=1).  Measured (round
+        # 4): the backward launch drops from 14.2 to 8.9 us, but the statistics epilogue costs its data gradient 3.3-5.5 us
+        # (threshold loads, sums, cross-wave reduce, the atomics' acknowledgement -- all on the tail of a launch that has one
+        # tile per CU) and 17 us where the 256 x 128 tile has no room for it: 15.98 -> 16.5 ms per step.
+        self.bw_stats = self.atomic_stats and os.environ.get("MBX_BW_STATS", "0") == "1"
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
@@ -570,6 +582,17 @@ class Net:
             if op.kind == "bn" and op.trainable and torch.device(dev).type == "cuda" and l.mbx_bn_bwd_onepass_supported(op.M, K_all, self.chain_cap or self.bn_max_wg):
                 op.bn_ws_off = ws_floats
                 ws_floats += (l.mbx_bn_bwd_onepass_workspace_bytes(K_all) // 4 + 7) // 8 * 8
+        self._plan_bw_stats()
+        for op in self.convs:
+            op.bw_rows_off = -1
+            u = getattr(op, "bw_unit", None)
+            if u is not None:
+                lead = u[0]
+                if op is lead:
+                    op.bw_rows_off = ws_floats                       # [STATS_ROWS][K_all][2], cleared with the workspace every step
+                    ws_floats += STATS_ROWS * sum(m.K for m in u) * 2
+                else:
+                    op.bw_rows_off = lead.bw_rows_off
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
         # ONE buffer cleared by one fill at the start of forward(): [work counters of the persistent launches | statistics rows]
         n_ctr = self.i5_counters.numel()
@@ -582,6 +605,113 @@ class Net:
         self.bwd_scratch = torch.zeros(max(max_bwd, 2), dtype=torch.float32, device=dev)
         self.m12 = torch.zeros(2 * 2048, dtype=torch.float32, device=dev)
         self.reg_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _plan_bw_stats(self):
+        """Which batch-norm layers (groups) get their backward statistics from the data gradient(s) that write their
+        activation gradient, and which data gradients carry the statistics epilogue.  A consumer convolution X is CONVERTIBLE
+        when it is a trainable stride-1 convolution with a data gradient whose input view is tiled exactly by outputs of
+        eligible batch-norm members (segments at multiples of 32 channels, at most 4) and nothing else reads those channels;
+        a unit is ELIGIBLE when every channel of every member has exactly one consumer and that one is convertible.  Fixed point
+        of the two.  Sets op.bw_unit (tuple of the unit's members) on eligible layers and op.bw_segments on convertible consumers:
+        [(first channel relative to X's input view, member, first channel inside the member's output, channels)]."""
+        for op in self.convs:
+            op.bw_unit, op.bw_segments = None, None
+        if not self.bw_stats or torch.device(self.dev).type != "cuda":
+            return
+        units = []
+        for op in self.convs:
+            if op.kind != "bn" or not op.trainable:
+                continue
+            g = op.group
+            if g is not None and op is not g.members[0]:
+                continue
+            mem = tuple([op] if g is None else g.members)
+            if sum(m.K for m in mem) <= 2048:
+                units.append(mem)
+        unit_of = {id(m): u for u in units for m in u}
+
+        def member_at(buf, c):
+            for u in units:
+                for m in u:
+                    if m.out.buf is buf and m.out.ch_off <= c < m.out.ch_off + m.K:
+                        return m
+            return None
+
+        def readers(buf, lo, hi):
+            """forward ops that read channels [lo, hi) of buf: as their input, or as a residual block's skip (trunk) tensor"""
+            r = [o for o in self.fwd if o.x.buf is buf and o.x.ch_off < hi and o.x.ch_off + o.x.C > lo]
+            r += [o for o in self.fwd if isinstance(o, ConvOp) and o.skip is not None and o.skip.buf is buf and
+                  o.skip.ch_off < hi and o.skip.ch_off + o.skip.C > lo]
+            return r
+
+        def segments(X):
+            """tiling of X's input view by batch-norm member outputs, or None"""
+            segs, c, end = [], X.x.ch_off, X.x.ch_off + X.x.C
+            while c < end:
+                m = member_at(X.x.buf, c)
+                if m is None:
+                    return None
+                n = min(end, m.out.ch_off + m.K) - c
+                segs.append((c - X.x.ch_off, m, c - m.out.ch_off, n))
+                c += n
+            if len(segs) > 4 or any(sg[0] % 32 for sg in segs):
+                return None
+            return segs
+
+        eligible = set(id(u) for u in units)
+        while True:
+            conv_ok = {}
+            for X in self.fwd:
+                if not isinstance(X, ConvOp) or not X.need_dx or not X.trainable or X.stride != 1:
+                    continue
+                segs = segments(X)
+                if segs is None or any(id(unit_of[id(sg[1])]) not in eligible for sg in segs):
+                    continue
+                if len(readers(X.x.buf, X.x.ch_off, X.x.ch_off + X.x.C)) != 1:
+                    continue                                   # someone else reads (part of) these channels: accumulated gradient
+                # (the direct 3x3 launch has no statistics epilogue: the stem's layers stay on the grid-barrier form)
+                dd = ops.ConvDesc()                               # (the fields ops.direct3_applies looks at, of X's data gradient)
+                dd.R, dd.S, dd.stride, dd.epilogue, dd.C_in, dd.C_out = X.R, X.S, 1, ops.EPI_STORE, X.K, X.Cin
+                dd.N, dd.H_out, dd.W_out, dd.rscale = X.x.N, X.x.H, X.x.W, (X.rscale if X.kind == "residual" else 0.0)
+                if ops.direct3_applies(dd):
+                    continue
+                conv_ok[id(X)] = segs
+            drop = set()
+            for u in units:
+                if id(u) not in eligible:
+                    continue
+                for m in u:
+                    rd = readers(m.out.buf, m.out.ch_off, m.out.ch_off + m.K)
+                    covered = sorted((max(o.x.ch_off, m.out.ch_off), min(o.x.ch_off + o.x.C, m.out.ch_off + m.K)) for o in rd)
+                    tiled = bool(covered) and covered[0][0] == m.out.ch_off and covered[-1][1] == m.out.ch_off + m.K and \
+                        all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+                    if not tiled or any(id(o) not in conv_ok for o in rd):
+                        drop.add(id(u))
+            if not drop:
+                break
+            eligible -= drop
+        for u in units:
+            if id(u) in eligible:
+                for m in u:
+                    m.bw_unit = u
+        for X in self.fwd:
+            if isinstance(X, ConvOp) and id(X) in conv_ok:
+                X.bw_segments = conv_ok[id(X)]
+
+    def _bw_table(self, X):
+        """mbx_bn_bwd_stats of consumer X's data gradient (kept alive in self._keep_bw)."""
+        t = _lib.BnBwdStats()
+        t.n, t.rows_mod = len(X.bw_segments), STATS_ROWS
+        for i, (c_rel, m, c_in, n) in enumerate(X.bw_segments):
+            lead = m.bw_unit[0]
+            K_all = sum(q.K for q in m.bw_unit)
+            ko = m.y_view.ch_off                                         # the member's first channel inside the unit's [M, K_all] tensors
+            t.c_begin[i] = c_rel
+            t.y[i], t.ld_y[i] = m.y_view.buf.data_ptr() + 2 * (ko + c_in), K_all
+            t.relu_thr[i] = self.bn_thr.data_ptr() + 4 * (m.beta_off + c_in)
+            t.stats[i], t.stats_ld[i] = self.bn_ws.data_ptr() + 4 * (lead.bw_rows_off + 2 * (ko + c_in)), K_all
+        self._keep_bw = getattr(self, "_keep_bw", []) + [t]
+        return t
 
     # ------------------------------------------------------------------ descriptors
     def _w(self, op):
@@ -932,6 +1062,16 @@ class Net:
                         _lib.check(l.mbx_bn_bwd_apply_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
                                                              mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                              dy_ptr, dmap, s), "bn_bwd_apply")
+                    if op.bw_unit is not None:
+                        # the sums were ADDED by the data gradient(s) that wrote da (their launches ran earlier in this pass)
+                        thr = self._sl(self.bn_thr, lead.beta_off, Kb)
+                        rows_off = lead.bw_rows_off
+
+                        def pre(s, da=da, da_ptr=da_ptr, dmap=dmap, mean=mean, rstd=rstd, thr=thr, dbeta=dbeta, Kb=Kb, M=M,
+                                y_ptr=y_ptr, dy_ptr=dy_ptr, rows_off=rows_off):
+                            _lib.check(l.mbx_bn_bwd_apply_rows(self.bn_ws.data_ptr() + 4 * rows_off, STATS_ROWS, da_ptr, da.ld, y_ptr, M, Kb,
+                                                               mean.data_ptr(), rstd.data_ptr(), thr.data_ptr(), dbeta.data_ptr(),
+                                                               dy_ptr, dmap, s), "bn_bwd_apply_rows")
                     if fpool is not None:
                         gy = self._gview(fpool.out)
                         rows = l.mbx_bn_bwd_rows_pooled(fpool.x.N, fpool.x.H, fpool.x.W, Kb)     # (<= the plain form's: bwd_scratch fits)
@@ -945,7 +1085,7 @@ class Net:
                             _lib.check(l.mbx_bn_bwd_finalize(self.bwd_scratch.data_ptr(), rows, Kb, M, dbeta.data_ptr(),
                                                              self.m12.data_ptr(), s), "bn_bwd_finalize")
                             _lib.check(l.mbx_bn_bwd_apply_pooled(*geo, self.m12.data_ptr(), dy_ptr, s), "bn_bwd_apply_pooled")
-                if pre is not None and (op.bn_ws_off if g is None else g.members[0].bn_ws_off) >= 0:
+                if pre is not None and op.bw_unit is None and (op.bn_ws_off if g is None else g.members[0].bn_ws_off) >= 0:
                     # chosen at CALL time: Trainer.check_health() falls back to the three launches (and re-captures its
                     # graphs) when a grid barrier has timed out -- e.g. RCCL kernels holding more CUs than bn_max_wg allows for
                     def pre(s, one=pre_onepass, three=pre):
@@ -969,6 +1109,20 @@ class Net:
                                       rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None),
                                       acc_src=acc_src)
                 self._tune(op, ddesc, "dgrad")
+                if op.bw_segments is not None:
+                    # this data gradient writes the activation gradient of batch-norm layers on the streaming backward: its
+                    # epilogue adds their sums (a plain store by construction: _plan_bw_stats)
+                    assert acc == 0 and acc_src is None and mr is None, op.name
+                    ddesc.bn_bwd_stats = C.addressof(self._bw_table(op))
+                    if l.mbx_conv_supported(C.byref(ddesc)) != 0:
+                        # (the 256 x 128 persistent tile and the panel-resident launch have no statistics epilogue)
+                        for alt in (ops.I5_TILE_CONFIGS[2], ops.I5_TILE_CONFIGS[1], 0):
+                            ddesc.tile_config = alt
+                            if alt == 0:
+                                ddesc.work_counter = None
+                            if l.mbx_conv_supported(C.byref(ddesc)) == 0:
+                                break
+                        _lib.check(l.mbx_conv_supported(C.byref(ddesc)), "statistics epilogue " + op.name)
 
             # the weight gradient is DEFERRED: one grouped launch per backward segment (make_wgrad_groups)
             job = ops.WgradJob()

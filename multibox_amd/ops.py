@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("max_workgroups", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("stats_rows_mod", C.c_int32), ("stats_ld", C.c_int32),
+        ("bn_bwd_stats", C.c_void_p),
     ]
 
 

@@ -289,6 +289,120 @@ def test_conv_stats_atomic_rows(T, g, cfg):
     assert torch.allclose(outs[1][5], thr_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [0, 2, 5, 6, 10, 12, 14, 33, 34, 35, 37, "pair"])
+def test_conv_bn_bwd_stats_epilogue(T, cfg):
+    """mbx_conv_desc.bn_bwd_stats (round 4): the data gradient that writes an activation gradient also adds the batch-norm
+    backward sums {sum g, sum g y}, g = (y > thr) ? stored gradient : 0, of the layers that own its output channels -- two
+    table entries here (channels [0, 64) -> columns 16.. of a 96-wide y, [64, 96) -> a 32-wide y), 8 rows.  Outputs
+    bit-identical to the plain launch; sums = float64 sums of the same expression (rtol 1e-4); the rest of the tables
+    untouched; mbx_bn_bwd_apply_rows on them = the three-launch backward (reduce / finalize / apply) on the same tensors to
+    1 bf16 ulp, dbeta to 1e-4.  The 256 x 128 persistent tile refuses the table (no such instantiation: registers)."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    g = ("bw", 3, 17, 17, 160, 96, 7, 1, 1, (3, 0, 3, 0))
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=9)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    M = N * Ho * Wo
+    stream = torch.cuda.current_stream().cuda_stream
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    gen = torch.Generator().manual_seed(4)
+    Y0 = (torch.randn(M, 96, generator=gen) * 1.5 + 0.3).to(torch.bfloat16).cuda()
+    Y1 = (torch.randn(M, 32, generator=gen) * 0.7 - 0.2).to(torch.bfloat16).cuda()
+    thr0 = (torch.randn(96, generator=gen) * 0.5).cuda()
+    thr1 = (torch.randn(32, generator=gen) * 0.5).cuda()
+    thr1[:8] = float("-inf")                                           # (a layer without relu: everything passes)
+    st0 = torch.zeros((8, 96, 2), dtype=torch.float32, device="cuda")
+    st1 = torch.zeros((8, 48, 2), dtype=torch.float32, device="cuda")
+    tab = _lib.BnBwdStats()
+    tab.n, tab.rows_mod = 2, 8
+    tab.c_begin[0], tab.c_begin[1] = 0, 64
+    tab.y[0], tab.ld_y[0], tab.relu_thr[0], tab.stats[0], tab.stats_ld[0] = Y0.data_ptr() + 2 * 16, 96, thr0.data_ptr() + 4 * 16, st0.data_ptr() + 8 * 16, 96
+    tab.y[1], tab.ld_y[1], tab.relu_thr[1], tab.stats[1], tab.stats_ld[1] = Y1.data_ptr(), 32, thr1.data_ptr(), st1.data_ptr() + 8 * 8, 48
+
+    def desc(yb, table):
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, rscale=0.17)
+        d.tile_config = 0 if cfg == "pair" else cfg
+        if table:
+            d.bn_bwd_stats = C.addressof(tab)
+        return d
+
+    ya, yb_ = ops.View.alloc(N, Ho, Wo, Co, zero=True), ops.View.alloc(N, Ho, Wo, Co, zero=True)
+    ops.conv(desc(ya, False))
+    if cfg == "pair":
+        # two problems in one grid: the second one a plain copy of the first into another buffer (its own table: rows of st0 / st1 too)
+        yc = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+        d1, d2 = desc(yb_, True), desc(yc, True)
+        d1.tile_config = d2.tile_config = 10
+        assert l.mbx_conv_pair(C.byref(d1), C.byref(d2), stream) == 0
+        scale = 2.0
+    else:
+        assert l.mbx_conv_supported(C.byref(desc(yb_, True))) == 0
+        ops.conv(desc(yb_, True))
+        scale = 1.0
+    torch.cuda.synchronize()
+    assert torch.equal(ya.tensor(), yb_.tensor())
+    da = yb_.tensor().reshape(M, Co).float().cpu().double()
+    for (Y, thr, tb, c_lo, c_n, y_lo, s_lo) in ((Y0, thr0, st0, 0, 64, 16, 16), (Y1, thr1, st1, 64, 32, 0, 8)):
+        yy = Y[:, y_lo:y_lo + c_n].float().cpu().double()
+        gg = torch.where(yy > thr[y_lo:y_lo + c_n].cpu().double(), da[:, c_lo:c_lo + c_n], torch.zeros(()).double())
+        want = torch.stack([gg.sum(0), (gg * yy).sum(0)], 1) * scale
+        got = tb[:, s_lo:s_lo + c_n].double().sum(0).cpu()
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-3 * float(want.abs().max())), (c_lo, float((got - want).abs().max()))
+        assert float(tb[:, :s_lo].abs().max()) == 0 and float(tb[:, s_lo + c_n:].abs().max()) == 0
+    # unsupported: the 256 x 128 persistent tile; an accumulate epilogue with the table is an argument error
+    bad = desc(yb_, True)
+    bad.tile_config = 36
+    assert l.mbx_conv_supported(C.byref(bad)) == -2
+    bad = desc(yb_, True)
+    bad.accumulate = 1
+    assert l.mbx_conv_supported(C.byref(bad)) == -1
+    if cfg != 0:
+        return
+    # ---- the consumer: one streaming launch against the three-launch form, layer 0's 64 channels (y columns 16..80)
+    Kc = 64
+    yv = Y0[:, 16:16 + Kc].contiguous()
+    yf = yv.float()
+    mean = yf.mean(0).contiguous()
+    rstd = torch.rsqrt(yf.var(0, unbiased=False) + 0.001).contiguous()
+    beta = (torch.randn(Kc, generator=gen) * 0.3).cuda()
+    thr = (mean - beta / rstd).contiguous()
+    table = torch.zeros((8, Kc, 2), dtype=torch.float32, device="cuda")
+    tab1 = _lib.BnBwdStats()
+    tab1.n, tab1.rows_mod = 2, 8
+    tab1.c_begin[0], tab1.c_begin[1] = 0, 64
+    tab1.y[0], tab1.ld_y[0], tab1.relu_thr[0], tab1.stats[0], tab1.stats_ld[0] = yv.data_ptr(), Kc, thr.data_ptr(), table.data_ptr(), Kc
+    tab1.y[1], tab1.ld_y[1], tab1.relu_thr[1], tab1.stats[1], tab1.stats_ld[1] = Y1.data_ptr(), 32, thr1.data_ptr(), st1.data_ptr() + 8 * 8, 48
+    d = desc(yb_, False)
+    d.bn_bwd_stats = C.addressof(tab1)
+    ops.conv(d)
+    dav = yb_.slice(0, Kc)                                             # the gradient view: channels [0, 64) of the 96-wide output
+    outs = []
+    for rows_form in (False, True):
+        dbeta = torch.full((Kc,), 0.5, dtype=torch.float32, device="cuda")
+        dy = torch.zeros((M, Kc), dtype=torch.bfloat16, device="cuda")
+        if rows_form:
+            assert l.mbx_bn_bwd_apply_rows(table.data_ptr(), 8, dav.ptr, dav.ld, yv.data_ptr(), M, Kc, mean.data_ptr(), rstd.data_ptr(),
+                                           thr.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), None, stream) == 0
+        else:
+            rows = l.mbx_bn_bwd_rows(M, Kc)
+            part = torch.zeros((rows, Kc, 2), dtype=torch.float32, device="cuda")
+            m12 = torch.zeros(2 * Kc, dtype=torch.float32, device="cuda")
+            a = (dav.ptr, dav.ld, None, 0, 1, yv.data_ptr(), M, Kc, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr())
+            assert l.mbx_bn_bwd_reduce(*a, part.data_ptr(), stream) == 0
+            assert l.mbx_bn_bwd_finalize(part.data_ptr(), rows, Kc, M, dbeta.data_ptr(), m12.data_ptr(), stream) == 0
+            assert l.mbx_bn_bwd_apply(*a, m12.data_ptr(), dy.data_ptr(), stream) == 0
+        torch.cuda.synchronize()
+        outs.append((dy.float().cpu(), dbeta.cpu()))
+    ok, msg = close(torch, outs[1][0], outs[0][0])
+    assert ok, msg
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-4 * float(outs[0][1].abs().max()))
+
+
 @pytest.mark.parametrize("cfg", [0, 10, 11, 5, 6])
 def test_conv_pair_bit_identical(T, cfg):
     """mbx_conv_pair (round 4): two independent convolutions of different shape (block35's sibling 3x3 branches: 32 -> 32 and

@@ -315,11 +315,10 @@ def test_train_steps_graph_equals_eager(env):
         assert not torch.equal(w0, net.W)
         assert losses[0][2] > 0 and abs(losses[0][3] - sum(losses[0][:3])) < 1e-3 * abs(losses[0][3])
         res.append((losses, net.W.clone(), tr.Wema.clone()))
-    # graph replay runs the same kernels on the same data: the first step's losses agree to the rounding noise of the
-    # forward pass's statistics atomics (round 4: the batch-norm sums are ADDED by the convolution epilogues in no fixed
-    # order -- a last-bit difference in a mean moves a few bf16 roundings; bit-identical under MBX_DETERMINISTIC=1, see
-    # test_gpu_assembled.py); later steps differ through the order of fp32 atomics in wgrad as well (chaotic at batch 2).
-    assert np.allclose(res[0][0][0][:2], res[1][0][0][:2], rtol=1e-3), (res[0][0][0], res[1][0][0])
+    # graph replay runs the same kernels on the same data: the first step's losses are identical (the forward pass is
+    # bit-reproducible: statistics rows are written, not added; the MBX_ATOMIC_STATS=1 option gives that up);
+    # later steps differ only through the order of fp32 atomics in wgrad (chaotic at batch 2).
+    assert np.allclose(res[0][0][0][:2], res[1][0][0][:2], rtol=1e-6), (res[0][0][0], res[1][0][0])
     assert np.isclose(res[0][0][0][2], res[1][0][0][2], rtol=1e-4)          # regulariser: float atomics order
     assert res[0][0][2][3] < res[0][0][0][3] and res[1][0][2][3] < res[1][0][0][3]      # loss goes down
 
