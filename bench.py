@@ -179,10 +179,11 @@ def timed_eager_pass(run, entry_points=None):
 
 
 # (the pair launch runs two igemm3 problems in one grid; the split-K reduce launch is the epilogue of its igemm3 slices)
+# (... and conv_direct3_kernel is the same convolution -- forward + data gradient of the stem's 3x3 layers -- as a direct launch)
 KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel",
-                             "splitk_reduce_kernel")), ("wgrad", ("conv_wgrad",)),
+                             "conv_direct3_kernel", "splitk_reduce_kernel")), ("wgrad", ("conv_wgrad",)),
                   ("bn_fwd", ("bn_finalize_kernel", "bn_finalize_parts_kernel", "bn_apply_kernel", "bn_apply_fused_kernel",
-                              "bn_apply_maxpool3s2_kernel")), ("bn_bwd", ("bn_bwd_",)))
+                              "bn_apply_rows_kernel", "bn_apply_maxpool3s2_kernel")), ("bn_bwd", ("bn_bwd_",)))
 
 
 def traced_kernel_times(step_fn, steps=3):
@@ -231,25 +232,26 @@ def committed_traffic():
     weighted by their launch counts) from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- only if that profile was
     taken on THESE kernel sources (the file stamps the sha256 of csrc/conv.hip, conv5.hip and conv7.hip); a stale profile prints null."""
     import glob
-    shas = {k: _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", f)) for k, f in (("conv_hip_sha", "conv.hip"), ("conv5_hip_sha", "conv5.hip"), ("conv7_hip_sha", "conv7.hip"))}
+    shas = {k: _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", f)) for k, f in (("conv_hip_sha", "conv.hip"), ("conv5_hip_sha", "conv5.hip"), ("conv7_hip_sha", "conv7.hip"),
+                                                                                  ("convd_hip_sha", "convd.hip"), ("conv_common_h_sha", "conv_common.h"))}
     for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
         try:
             j = json.load(open(pj))
             if any(j.get(k) != v for k, v in shas.items()):
                 continue
             n = mb = 0.0
-            for kern in ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel"):
+            for kern in ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel", "conv_direct3_kernel"):
                 if kern in j:
                     n += j[kern]["calls"]
                     mb += j[kern]["calls"] * j[kern]["MB_per_launch"]
             if n <= 0:
                 continue
             return mb / n * 1e6, os.path.relpath(pj, ROOT) + \
-                " (launch-weighted mean over conv_igemm3_kernel, conv_igemm5_kernel and conv_igemm7_kernel; FETCH_SIZE x2 gfx950 correction + " \
+                " (launch-weighted mean over conv_igemm3 / pair / igemm5 / igemm7 / direct3 launches; FETCH_SIZE x2 gfx950 correction + " \
                 "WRITE_SIZE, separate --pmc passes; source shas match)"
         except Exception:
             continue
-    return None, "no committed PMC profile matches the current csrc/conv.hip + conv5.hip + conv7.hip (%s)" % shas
+    return None, "no committed PMC profile matches the current csrc/conv*.hip + conv_common.h (%s)" % shas
 
 
 def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominant="igemm", traced=None):
@@ -274,7 +276,7 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
-    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel (implicit-GEMM convolution: forward + data-gradient launches)",
+    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel (convolution on MFMA: forward + data-gradient launches)",
             "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
@@ -356,7 +358,7 @@ def detect_leg(args, world, rank, pg):
             classes, pair_ms, _ = timed_eager_pass(one, ["mbx_conv"])
             d = classes["igemm"]
             ach = d["work"] / (d["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                                "traffic": None, "launches_per_batch": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2)}
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

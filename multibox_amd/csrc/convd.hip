@@ -110,6 +110,26 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+  // EV = 3 (folded batch norm of the inference / --fine_tune forward, detect.py:313-326): y = act(acc * scale[c] + shift[c]),
+  // the expression of the implicit-GEMM kernels' affine epilogue; the lane's channels are the same for every tile
+  constexpr int NPq = CO / 32;
+  float sc8[NPq > 0 ? NPq : 1][8], sh8[NPq > 0 ? NPq : 1][8], sc4[4], sh4[4];
+  if constexpr (EV == 3) {
+#pragma unroll
+    for (int A = 0; A < NPq; ++A)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 32 * A + 8 * fch + j;
+        sc8[A][j] = (p.scale && c < p.C_out) ? p.scale[c] : 1.f;
+        sh8[A][j] = (p.shiftv && c < p.C_out) ? p.shiftv[c] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 2 * NPq * 16 + 4 * fch + j;
+      sc4[j] = (p.scale && c < p.C_out) ? p.scale[c] : 1.f;
+      sh4[j] = (p.shiftv && c < p.C_out) ? p.shiftv[c] : 0.f;
+    }
+  }
 
   int buf = 0;
   for (int t = first; t < q.ntiles; t += G) {
@@ -166,8 +186,15 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
           const int c0 = 32 * A + 8 * fch;
           const bool ok = pv && c0 < p.C_out;               // C_out % 8 == 0: a group of eight is all in or all out
           unsigned h8[8];
+          float v8[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { h8[r] = f2bf(acc[2 * A][b][r]); h8[4 + r] = f2bf(acc[2 * A + 1][b][r]); }
+          for (int r = 0; r < 4; ++r) { v8[r] = acc[2 * A][b][r]; v8[4 + r] = acc[2 * A + 1][b][r]; }
+          if constexpr (EV == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[A][j] + sh8[A][j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
                                                  yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
@@ -187,7 +214,11 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
           const bool ok = pv && c0 < p.C_out;
           unsigned h4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h4[r] = f2bf(acc[a][b][r]);
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[a][b][r];
+            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = fmaxf(v, 0.f); }
+            h4[r] = f2bf(v);
+          }
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)}, yr,
                                                 ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
@@ -250,14 +281,16 @@ template <int CI, int CO>
 int launch_direct3(const ConvK& k, const DirK& q, int grid, hipStream_t s) {
   constexpr int lds = direct3_lds<CI, CO>();
   static_assert(lds <= 160 * 1024, "LDS");
-  static bool attr[2] = {false, false};
-  const int ev = k.stats ? 1 : 0;
+  static bool attr[3] = {false, false, false};
+  const int ev = k.epi == MBX_EPI_AFFINE ? 2 : k.stats ? 1 : 0;
   if (!attr[ev]) {
-    if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (ev == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3_kernel<CI, CO, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr[ev] = true;
   }
-  if (ev) hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 1>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  if (ev == 2) hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 3>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else if (ev) hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 1>), dim3(grid), dim3(kDThreads), lds, s, k, q);
   else hipLaunchKernelGGL((conv_direct3_kernel<CI, CO, 0>), dim3(grid), dim3(kDThreads), lds, s, k, q);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
@@ -283,10 +316,11 @@ int mbx_direct3_grid(int N, int H_out, int W_out) {
 
 // mbx_conv_desc.tile_config = 96: the direct 3x3 launch.  MBX_ERR_UNSUPPORTED for anything but a 3x3 / stride-1 convolution
 // (forward, or the data gradient of one) with C_in in {32, 64}, C_out <= 64 (a multiple of 8) and a bf16 store epilogue
-// with or without statistics.
+// with or without statistics, or the affine (+ relu) epilogue of a folded batch norm.
 int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
-  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || k.epi != MBX_EPI_STORE || k.accumulate || k.skip || k.rscale != 0.f || k.bw_n)
+  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip ||
+      k.rscale != 0.f || k.bw_n || (k.epi == MBX_EPI_AFFINE && k.stats))
     return MBX_ERR_UNSUPPORTED;
   if ((k.C_in != 32 && k.C_in != 64) || k.C_out > 64 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2 ||
       (k.C_in == 64 && k.C_out > 48))

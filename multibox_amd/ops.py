@@ -160,13 +160,18 @@ DIRECT3_TILE_CONFIG = 96                       # the direct 3x3 launch for few c
 
 def direct3_applies(desc: ConvDesc, min_pixels=300000):
     """The direct 3x3 launch by rule: 3x3 / stride 1 (forward or data gradient), C_in 32 / 64, C_out <= 64, plain bf16 store
-    (+ statistics), and a map large enough that the nine-fold gather of the implicit GEMM is what the launch spends its
+    (+ statistics) or the affine epilogue of a folded batch norm, and a map large enough that the nine-fold gather of the implicit GEMM is what the launch spends its
     time on (the stem's 147 x 147 layers at BATCH_SIZE 64: 1.4 M pixels).  MBX_DIRECT3=0 turns it off (A/B); MBX_DIRECT3_MIN_PIXELS."""
     if os.environ.get("MBX_DIRECT3", "1") == "0":
         return False
-    if desc.R != 3 or desc.S != 3 or desc.stride != 1 or desc.epilogue != EPI_STORE or desc.accumulate or desc.skip or desc.rscale != 0.0:
+    if desc.R != 3 or desc.S != 3 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
+            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial):
         return False
     if desc.C_in not in (32, 64) or desc.C_out > 64 or desc.C_out % 8 or (desc.C_in == 64 and desc.C_out > 48):
+        return False
+    # its tiles are 8 rows x 32 columns: a map whose width fills the last column tile badly (35 -> 64: 1.8x the pixels) is
+    # better off on the implicit GEMM (measured on block35's 3x3 layers, MBX_DIRECT3_MIN_PIXELS=70000: +0.06 ms per step)
+    if -(-desc.W_out // 32) * 32 > 1.15 * desc.W_out:
         return False
     return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_DIRECT3_MIN_PIXELS", min_pixels))
 

@@ -180,6 +180,19 @@ def test_conv_direct3_bit_identical(T, g):
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-3)
     ok, msg = close(torch, outs[1][0], ref_conv(torch, x, w, st, pads))
     assert ok, msg
+    # the affine (+ relu) epilogue of a folded batch norm (inference / --fine_tune forward): bit-identical to the implicit GEMM's
+    gen = torch.Generator().manual_seed(7)
+    scale, shift = (torch.rand(Co, generator=gen) + 0.5).cuda(), (torch.randn(Co, generator=gen) * 0.2).cuda()
+    aff = []
+    for cfg in (0, ops.DIRECT3_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, epilogue=ops.EPI_AFFINE, relu=1, scale=scale, shift=shift)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        aff.append(yb.tensor().clone())
+    assert torch.equal(aff[0], aff[1]) and float(aff[1].float().min()) == 0.0 and float(aff[1].float().max()) > 0
     # data gradient of the same convolution: input = dy [N,Ho,Wo,Co], flipped / transposed filter, "full" padding R - 1 - pad
     gen = torch.Generator().manual_seed(5)
     if Co in (32, 64) and Ci <= 64 and not (Co == 64 and Ci > 48):
