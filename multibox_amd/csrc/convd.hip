@@ -269,6 +269,209 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ the network's first layer
+// conv_stem_kernel: 3x3, STRIDE 2, C_in = 8 (the packed RGB input: three real channels), C_out <= 32 -- Conv2d_1a_3x3 of
+// model.py:90 (299 x 299 -> 149 x 149).  As an implicit GEMM its K is 72 (two 64-deep K tiles, the second 7/8 padding) and
+// every output pixel gathers nine 16-byte taps through the L2 -> LDS path: 105 us per step at BATCH_SIZE 64 against 36 us of
+// HBM time (59 TFLOP/s), 282 us at the detect batch.  Same scheme as conv_direct3_kernel: a persistent workgroup stages the
+// (2 * 8 + 1) x (2 * 32 + 1) input pixels of an 8 x 32 output tile once (one 16-byte chunk per pixel), keeps the filter in LDS
+// and multiplies out of LDS: one v_mfma_f32_16x16x32_bf16 per FOUR taps (lane group fch holds tap 4 j + fch of its pixel) --
+// K elements in the implicit GEMM's order and grouping (taps 0-3, 4-7, 8 + zeros), so the results are bit-identical to it.
+constexpr int kSPH = 2 * kDTH + 1, kSPW = 2 * kDTW + 1;   // input patch of an output tile (stride 2, 3 x 3)
+constexpr int kSWRow = 13;                                // filter image row: 12 chunks of K (9 taps + 3 of zeros) padded to 13 (conflict-free reads)
+
+template <int EV>
+__global__ void __launch_bounds__(kDThreads)
+conv_stem_kernel(const ConvK p, const DirK q) {
+  constexpr int CO = 32, NA = 2;
+  constexpr int PCH = kSPH * kSPW;                        // 16-byte chunks of a patch (one per pixel)
+  constexpr int PROUNDS = (PCH + kDThreads - 1) / kDThreads;
+  constexpr int PBUF = PROUNDS * kDThreads;
+  constexpr int WCH = CO * kSWRow;
+  static_assert(WCH <= kDThreads, "filter image in one round");
+  constexpr int NBUF = 3, D = NBUF - 1;
+  constexpr int NS = 2;                                   // store instructions of a tile's epilogue, per wave
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* const wimg = smem;                               // [CO][kSWRow]
+  u32x4* const pbuf = smem + kDThreads;                   // the patch ring
+  float* const red = reinterpret_cast<float*>(pbuf + NBUF * PBUF);  // [8 waves][CO][2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  int prow[PROUNDS], pcol[PROUNDS];
+#pragma unroll
+  for (int i = 0; i < PROUNDS; ++i) {
+    const int ch = i * kDThreads + tid;
+    prow[i] = ch / kSPW;
+    pcol[i] = ch - prow[i] * kSPW;
+    if (ch >= PCH) prow[i] = -1;
+  }
+  auto issue_patch = [&](int t, int buf) {
+    const int tw = t % q.tiles_w, r_ = t / q.tiles_w, th = r_ % q.tiles_h, img = r_ / q.tiles_h;
+    const int h_in0 = 2 * th * kDTH - p.pad_t, w_in0 = 2 * tw * kDTW - p.pad_l;
+    u32x4* dst = pbuf + buf * PBUF + wave * 64;
+#pragma unroll
+    for (int i = 0; i < PROUNDS; ++i) {
+      const int h = h_in0 + prow[i], w = w_in0 + pcol[i];
+      const bool ok = prow[i] >= 0 && (unsigned)h < (unsigned)p.H_in && (unsigned)w < (unsigned)p.W_in;
+      glds16(xr, dst + i * kDThreads, ok ? (img * p.x_img_stride + (h * p.W_in + w) * p.ldx) * 2 : (int)kOOB);
+    }
+  };
+  {  // the filter image: LDS row 16 a + f holds output channel dperm(a, f); chunk c of a row = tap c (KRSC with C = 8), 9.. zeros
+    const int row = tid / kSWRow, c = tid - row * kSWRow;
+    const int co = dperm<CO>(row >> 4, row & 15);
+    const bool ok = tid < WCH && c < 9 && co < p.C_out;
+    glds16(wr, wimg + wave * 64, ok ? (co * 9 + c) * 16 : (int)kOOB);
+  }
+  const int first = (int)blockIdx.x, G = (int)gridDim.x;
+  if (first < q.ntiles) issue_patch(first, 0);
+  if (first + G < q.ntiles) { issue_patch(first + G, 1); wait_vmcnt<PROUNDS>(); } else wait_vmcnt<0>();
+  lds_readback_wait(lds_readback_issue(pbuf + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+  raw_barrier();
+
+  const int frow = lane & 15, fch = lane >> 4;
+  float s1[NA][4], s2[NA][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+  float sc8[8], sh8[8];
+  if constexpr (EV == 3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * fch + j;
+      sc8[j] = (p.scale && c < p.C_out) ? p.scale[c] : 1.f;
+      sh8[j] = (p.shiftv && c < p.C_out) ? p.shiftv[c] : 0.f;
+    }
+  }
+  // this lane's patch slots: K step j multiplies tap min(4 j + fch, 8) (taps past 8 meet the filter image's zero chunks) of
+  // output pixels (wave, 16 b + frow): input pixel (2 wave + r, 2 (16 b + frow) + s)
+  int poff[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = min(4 * j + fch, 8), r = tap / 3, sx = tap - 3 * r;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) poff[j][b] = (2 * wave + r) * kSPW + 2 * (16 * b + frow) + sx;
+  }
+  int buf = 0;
+  for (int t = first; t < q.ntiles; t += G) {
+    const bool more = t + G < q.ntiles;
+    const bool ahead = t + D * G < q.ntiles;
+    const int buf_next = buf == NBUF - 1 ? 0 : buf + 1;
+    {
+      int bi = buf + D;
+      if (bi >= NBUF) bi -= NBUF;
+      if (ahead) issue_patch(t + D * G, bi);
+    }
+    const u32x4* pb = pbuf + buf * PBUF;
+    f32x4 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bf16x8 wf[NA], pf[2];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) wf[a] = __builtin_bit_cast(bf16x8, wimg[(a * 16 + frow) * kSWRow + 4 * j + fch]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) pf[b] = __builtin_bit_cast(bf16x8, pb[poff[j][b]]);
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+    }
+    {
+      const int tw = t % q.tiles_w, r_ = t / q.tiles_w, th = r_ % q.tiles_h, img = r_ / q.tiles_h;
+      const int oh = th * kDTH + wave;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ow = tw * kDTW + b * 16 + frow;
+        const int c0 = 8 * fch;
+        const bool ok = oh < q.H_out && ow < p.W_out && c0 < p.C_out;
+        const int pix_off = img * p.y_img_stride + (oh * p.W_out + ow) * p.ldy;
+        unsigned h8[8];
+        float v8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v8[r] = acc[0][b][r]; v8[4 + r] = acc[1][b][r]; }
+        if constexpr (EV == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[j] + sh8[j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+                                               yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
+        if constexpr (EV == 1) {
+          if (ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float f0 = bf2f((unsigned short)h8[r]), f1 = bf2f((unsigned short)h8[4 + r]);
+              s1[0][r] += f0; s2[0][r] += f0 * f0;
+              s1[1][r] += f1; s2[1][r] += f1 * f1;
+            }
+          }
+        }
+      }
+    }
+    if (more) {
+      // (the counted waits of conv_direct3_kernel: D - 1 newer patches and D tiles' stores behind the next patch -- one tile's
+      // stores fewer in the workgroup's first tile, whose next patch the prologue issued)
+      if (ahead && t == first) wait_vmcnt<(D - 1) * PROUNDS + (D - 1) * NS>();
+      else if (ahead) wait_vmcnt<(D - 1) * PROUNDS + D * NS>();
+      else wait_vmcnt<0>();
+      lds_readback_wait(lds_readback_issue(pbuf + buf_next * PBUF + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+    buf = buf_next;
+  }
+  if constexpr (EV == 1) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
+        if (frow == 0) {
+          const int ch = dperm<CO>(a, 4 * fch + r);
+          red[(wave * CO + ch) * 2] = x1;
+          red[(wave * CO + ch) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < CO && tid < p.C_out) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { x1 += red[(w * CO + tid) * 2]; x2 += red[(w * CO + tid) * 2 + 1]; }
+      stats_write(p, (int)blockIdx.x, tid, x1, x2);
+    }
+  }
+}
+
+constexpr int stem_lds() {
+  constexpr int PCH = kSPH * kSPW, PBUF = (PCH + kDThreads - 1) / kDThreads * kDThreads;
+  return (kDThreads + 3 * PBUF) * 16 + 8 * 32 * 2 * 4;
+}
+
+int launch_stem(const ConvK& k, const DirK& q, int grid, hipStream_t s) {
+  constexpr int lds = stem_lds();
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr[3] = {false, false, false};
+  const int ev = k.epi == MBX_EPI_AFFINE ? 2 : k.stats ? 1 : 0;
+  if (!attr[ev]) {
+    if (ev == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr[ev] = true;
+  }
+  if (ev == 2) hipLaunchKernelGGL((conv_stem_kernel<3>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else if (ev) hipLaunchKernelGGL((conv_stem_kernel<1>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else hipLaunchKernelGGL((conv_stem_kernel<0>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 template <int CI, int CO>
 constexpr int direct3_lds() {
   constexpr int C8 = CI / 8;
@@ -319,6 +522,22 @@ int mbx_direct3_grid(int N, int H_out, int W_out) {
 // with or without statistics, or the affine (+ relu) epilogue of a folded batch norm.
 int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
+  if (k.mul == 2 && !k.shift && k.C_in == 8) {
+    // the network's first layer (forward only: stride 2, packed RGB input): conv_stem_kernel
+    if (k.R != 3 || k.S != 3 || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.rscale != 0.f || k.bw_n ||
+        (k.epi == MBX_EPI_AFFINE && k.stats) || k.C_out > 32 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2 ||
+        k.Ktot != 72)
+      return MBX_ERR_UNSUPPORTED;
+    DirK q;
+    q.N = N; q.H_out = H_out;
+    q.tiles_h = (H_out + kDTH - 1) / kDTH;
+    q.tiles_w = (k.W_out + kDTW - 1) / kDTW;
+    const long nt = (long)N * q.tiles_h * q.tiles_w;
+    if (nt >= (1L << 30)) return MBX_ERR_UNSUPPORTED;
+    q.ntiles = (int)nt;
+    if (k.dry) return MBX_OK;
+    return launch_stem(k, q, mbx_direct3_grid(N, H_out, k.W_out), s);
+  }
   if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip ||
       k.rscale != 0.f || k.bw_n || (k.epi == MBX_EPI_AFFINE && k.stats))
     return MBX_ERR_UNSUPPORTED;

@@ -164,10 +164,12 @@ def direct3_applies(desc: ConvDesc, min_pixels=300000):
     time on (the stem's 147 x 147 layers at BATCH_SIZE 64: 1.4 M pixels).  MBX_DIRECT3=0 turns it off (A/B); MBX_DIRECT3_MIN_PIXELS."""
     if os.environ.get("MBX_DIRECT3", "1") == "0":
         return False
-    if desc.R != 3 or desc.S != 3 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
-            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial):
+    if desc.R != 3 or desc.S != 3 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
+            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial) or desc.bn_bwd_stats:
         return False
-    if desc.C_in not in (32, 64) or desc.C_out > 64 or desc.C_out % 8 or (desc.C_in == 64 and desc.C_out > 48):
+    if desc.stride == 2 and not desc.transposed and desc.C_in == 8 and desc.C_out <= 32 and desc.C_out % 8 == 0:
+        pass                                       # the network's first layer (model.py:90): conv_stem_kernel, same tile_config
+    elif desc.stride != 1 or desc.C_in not in (32, 64) or desc.C_out > 64 or desc.C_out % 8 or (desc.C_in == 64 and desc.C_out > 48):
         return False
     # its tiles are 8 rows x 32 columns: a map whose width fills the last column tile badly (35 -> 64: 1.8x the pixels) is
     # better off on the implicit GEMM (measured on block35's 3x3 layers, MBX_DIRECT3_MIN_PIXELS=70000: +0.06 ms per step)
