@@ -131,6 +131,21 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
     }
   }
 
+  // The filter fragments are the same for every tile: where they fit the register file (a 512-thread workgroup alone on its
+  // CU may use 256 registers per lane) they are read from LDS ONCE -- per tile that leaves the two pixel fragments of a tap,
+  // a third to a half of the LDS reads (the tile loop was LDS-read bound: ~3k of its ~6k cycles).
+  // (as many taps as ~112 registers hold: all nine for 32 -> 32 / 48, seven for 32 -> 64 and 64 -> 32, four for 64 -> 48)
+  constexpr int WT = (112 / (KC * NA * 4)) < 9 ? (112 / (KC * NA * 4)) : 9;
+  bf16x8 wreg[WT][KC][NA];
+#pragma unroll
+  for (int tap = 0; tap < WT; ++tap)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int lr = a * 16 + frow;
+        wreg[tap][j][a] = __builtin_bit_cast(bf16x8, wimg[(tap * CO + lr) * C8 + ((4 * j + fch) ^ dkey<CI>(lr))]);
+      }
   int buf = 0;
   for (int t = first; t < q.ntiles; t += G) {
     const bool more = t + G < q.ntiles;                   // a next tile exists (its patch must be published below)
@@ -155,8 +170,12 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
           bf16x8 wf[NA], pf[2];
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
-            const int lr = a * 16 + frow;
-            wf[a] = __builtin_bit_cast(bf16x8, wimg[(tap * CO + lr) * C8 + ((4 * j + fch) ^ dkey<CI>(lr))]);
+            if (tap < WT) {                             // (folded: the tap loops are unrolled)
+              wf[a] = wreg[tap < WT ? tap : 0][j][a];
+            } else {
+              const int lr = a * 16 + frow;
+              wf[a] = __builtin_bit_cast(bf16x8, wimg[(tap * CO + lr) * C8 + ((4 * j + fch) ^ dkey<CI>(lr))]);
+            }
           }
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
@@ -355,6 +374,11 @@ conv_stem_kernel(const ConvK p, const DirK q) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) poff[j][b] = (2 * wave + r) * kSPW + 2 * (16 * b + frow) + sx;
   }
+  bf16x8 wreg[3][NA];                                     // the filter fragments: the same for every tile
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) wreg[j][a] = __builtin_bit_cast(bf16x8, wimg[(a * 16 + frow) * kSWRow + 4 * j + fch]);
   int buf = 0;
   for (int t = first; t < q.ntiles; t += G) {
     const bool more = t + G < q.ntiles;
@@ -373,7 +397,7 @@ conv_stem_kernel(const ConvK p, const DirK q) {
     for (int j = 0; j < 3; ++j) {
       bf16x8 wf[NA], pf[2];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) wf[a] = __builtin_bit_cast(bf16x8, wimg[(a * 16 + frow) * kSWRow + 4 * j + fch]);
+      for (int a = 0; a < NA; ++a) wf[a] = wreg[j][a];
 #pragma unroll
       for (int b = 0; b < 2; ++b) pf[b] = __builtin_bit_cast(bf16x8, pb[poff[j][b]]);
 #pragma unroll
