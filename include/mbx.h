@@ -216,7 +216,8 @@ typedef struct {
   const mbx_bn_bwd_stats* bn_bwd_stats;   /* HOST, may be NULL: see above */
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
-/* tile_config 33..37: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64 tiles); 65: the persistent
+/* tile_config 33..39: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64, 128x192, 128x256 tiles; 128x192
+   without the accumulate + mask epilogue); 65: the persistent
    POINTWISE launch with the filter panel resident in LDS (1x1, unit stride, unpadded, 64 < K <= 384, no statistics; its
    work_counter, if given, is an array of one zeroed int32 per 128-channel column tile, at most 32).  A configuration that
    does not apply returns MBX_ERR_UNSUPPORTED.

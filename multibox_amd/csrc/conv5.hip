@@ -24,11 +24,13 @@ namespace {
 template <int MY, int NW>
 struct Ig5 {
   static constexpr int BM = 64 * MY, BN = 64 * NW;
-  static_assert(NW == 1 || NW == 2 || NW == 4, "64 / 128 / 256 output channels per tile (8-channel groups per row divide 512)");
+  static_assert(NW >= 1 && NW <= 4, "64 / 128 / 192 / 256 output channels per tile");
   // compute-wave grid (WM x WN = 8) and the 16 x 16 blocks per wave:
   //   128x64: 4x2 (2x2 blocks)   256x64: 8x1 (2x4)   192x64: 4x2 (3x2)   64x128: 2x4 (2x2)   128x128: 2x4 (4x2)
-  //   192x128: 2x4 (6x2)         256x128: 4x2 (4x4)  128x256: 2x4 (4x4)
-  static constexpr int WM = (NW == 1) ? (MY == 4 ? 8 : 4) : (MY == 4 && NW == 2) ? 4 : 2;
+  //   192x128: 2x4 (6x2)         256x128: 4x2 (4x4)  128x256: 2x4 (4x4)  128x192: 4x2 (2x6: 96 channels per wave)
+  // (128 x 192, round 4: ONE column tile for the 160 / 192-channel 1x7 / 7x1 layers of block17, whose launches are paced by
+  // the L2 -> LDS operand feed -- two column tiles re-read every pixel row)
+  static constexpr int WM = (NW == 1) ? (MY == 4 ? 8 : 4) : (NW == 3) ? 4 : (MY == 4 && NW == 2) ? 4 : 2;
   static constexpr int WN = 8 / WM;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   static constexpr int STAGE = (BM + BN) * 8;                       // 16-byte slots per ring stage
@@ -321,8 +323,11 @@ int launch5(ConvK& k, hipStream_t s) {
   const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
   // the BN-backward statistics epilogue (EV = 6) on the 256 x 128 tile: 64 accumulator + 48 sum / threshold registers + the
   // reads in flight do not fit the 128-register budget of a 16-wave block (33 spilled): not built, the caller takes 192 x 128
-  constexpr bool kNo6 = MY == 4 && NW == 2;
-  if (ev == 6 && kNo6) return MBX_ERR_UNSUPPORTED;
+  constexpr bool kNo6 = (MY == 4 && NW == 2) || NW >= 3;
+  // (128 x 192: 96 channels per wave -- the accumulate + mask epilogue's reads in flight spill as well: store / statistics /
+  // affine / residual only)
+  constexpr bool kNo2 = NW == 3;
+  if ((ev == 6 && kNo6) || (ev == 2 && kNo2)) return MBX_ERR_UNSUPPORTED;
   if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
   static bool attr[7][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \
@@ -336,7 +341,10 @@ int launch5(ConvK& k, hipStream_t s) {
   } while (0)
 #define MBX5_EV(EV) case EV: if (k.pw) MBX5_LAUNCH(EV, 1); else MBX5_LAUNCH(EV, 0); break;
   switch (ev) {
-    MBX5_EV(0) MBX5_EV(1) MBX5_EV(2) MBX5_EV(3) MBX5_EV(4)
+    MBX5_EV(0) MBX5_EV(1) MBX5_EV(3) MBX5_EV(4)
+    case 2:
+      if constexpr (!kNo2) { if (k.pw) MBX5_LAUNCH(2, 1); else MBX5_LAUNCH(2, 0); }
+      break;
     case 6:
       if constexpr (!kNo6) { if (k.pw) MBX5_LAUNCH(6, 1); else MBX5_LAUNCH(6, 0); }
       break;
@@ -350,8 +358,8 @@ int launch5(ConvK& k, hipStream_t s) {
 }  // namespace
 
 // tile shapes of the igemm5 launch: mbx_conv_desc.tile_config = 32 + index + 1
-extern const int mbx_i5_tiles[][2] = {{128, 64}, {128, 128}, {192, 128}, {256, 128}, {256, 64}};
-extern const int mbx_i5_num_tiles = 5;
+extern const int mbx_i5_tiles[][2] = {{128, 64}, {128, 128}, {192, 128}, {256, 128}, {256, 64}, {128, 192}, {128, 256}};
+extern const int mbx_i5_num_tiles = 7;
 
 int mbx_launch_igemm5(void* convk, int index, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
@@ -362,6 +370,8 @@ int mbx_launch_igemm5(void* convk, int index, hipStream_t s) {
     case 2: return launch5<3, 2>(k, s);
     case 3: return launch5<4, 2>(k, s);
     case 4: return launch5<4, 1>(k, s);
+    case 5: return launch5<2, 3>(k, s);
+    case 6: return launch5<2, 4>(k, s);
     default: return MBX_ERR_UNSUPPORTED;
   }
 }

@@ -151,7 +151,7 @@ def wgrad_overlap_cus():
 
 N_TILE_CONFIGS = 14
 I5_FLAG = 32                                   # tile_config 32 + t: persistent igemm5 launch (csrc/conv5.hip), tile t
-I5_TILE_CONFIGS = (33, 34, 35, 36, 37)         # 128x64, 128x128, 192x128, 256x128, 256x64
+I5_TILE_CONFIGS = (33, 34, 35, 36, 37, 38, 39)     # 128x64, 128x128, 192x128, 256x128, 256x64, 128x192, 128x256
 I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
 I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
 SPLITK_FLAG = 128                              # tile_config 128 + S: split-K in S slices (float32 partials + reduce launch)

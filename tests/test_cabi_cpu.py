@@ -82,7 +82,7 @@ def test_conv_stats_rows_follow_the_tile(lib):
     for cfg, bm in bm3.items():
         d.tile_config = cfg
         assert l.mbx_conv_stats_rows(C.byref(d)) == -(-M // bm), cfg
-    for cfg, bm in zip(ops.I5_TILE_CONFIGS, (128, 128, 192, 256, 256)):
+    for cfg, bm in zip(ops.I5_TILE_CONFIGS, (128, 128, 192, 256, 256, 128, 128)):
         d.tile_config = cfg
         assert l.mbx_conv_stats_rows(C.byref(d)) == -(-M // bm), cfg
     d.tile_config = ops.I5_FLAG + 9

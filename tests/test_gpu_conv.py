@@ -581,6 +581,10 @@ def test_igemm5_epilogues_bit_identical(T, g):
             d1 = variants(y1, st1)[kind]
             d1.tile_config = cfg
             y0.tensor().zero_(); y1.tensor().zero_()
+            if l.mbx_conv_supported(C.byref(d1)) == -2:
+                # the tiles with 96 / 64 x 4 channels per wave have no accumulate + mask instantiation (registers)
+                assert cfg >= 38 and kind == "acc_mask", (cfg, kind)
+                continue
             assert l.mbx_conv(C.byref(d0), stream) == 0 and l.mbx_conv(C.byref(d1), stream) == 0
             torch.cuda.synchronize()
             assert torch.equal(y0.tensor(), y1.tensor()), "%s %s cfg %d" % (name, kind, cfg)

@@ -19,7 +19,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 65)
+CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 38, 65)
 
 
 def main():
@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.015)
     ap.add_argument("--out", default=None)
     ap.add_argument("--dry", action="store_true", help="measure and report, do not write the table")
+    ap.add_argument("--candidates", default=None, help="comma-separated tile configurations to try instead of the full list")
     args = ap.parse_args()
+    global CANDIDATES
+    if args.candidates:
+        CANDIDATES = tuple(int(v) for v in args.candidates.split(","))
     import numpy as np
     import torch
     import __graft_entry__ as g
@@ -84,6 +88,7 @@ def main():
     # every launch gets its own block of work counters for the candidate passes (igemm7 wants 32)
     big = torch.zeros(max(len(reg) * ops.I7_COUNTERS, 8), dtype=torch.int32, device="cuda")
     net.i5_counters, net._i5_used = big, big.numel()
+    net._fwd_clear = big                                   # (what Net.forward() clears at the start of every pass)
     orig_conv, orig_bn = l.mbx_conv, l.mbx_bn_apply_fused
     state = {"cand": None, "rows": None, "calls": []}
 
@@ -137,7 +142,8 @@ def main():
             if "pack_input" in e.name:
                 cur = []
                 steps.append(cur)
-            elif "conv_igemm" in e.name and cur is not None:
+            elif ("conv_igemm" in e.name or "conv_direct3" in e.name or "conv_stem" in e.name) and "pair_kernel" not in e.name \
+                    and cur is not None:                       # (pair launches go through mbx_conv_pair: not tuned here)
                 cur.append(e)
         steps = [s_ for s_ in steps if len(s_) == n_calls]
         assert len(steps) >= max(args.steps - 1, 1), ([len(s_) for s_ in steps], n_calls)
@@ -196,6 +202,8 @@ def main():
         better = min(walls["new"]) < min(walls["old"]) and sum(walls["new"]) < sum(walls["old"])
         if changed and better and not args.dry:
             for key, cfg in new.items():
+                if cfg > ops.SPLITK_FLAG or cfg == ops.DIRECT3_TILE_CONFIG:
+                    continue                                  # chosen by rule at net build (split-K, direct launches): not table entries
                 ops._TUNED[key] = cfg
                 if cfg > ops.I5_FLAG:
                     i3 = {c: t for c, t in times[key].items() if 0 < c <= ops.N_TILE_CONFIGS}

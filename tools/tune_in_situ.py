@@ -17,7 +17,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CONV_CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 65)  # 33..37: the persistent igemm5 tiles; 65: igemm7 (panel-resident 1x1)
+CONV_CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 38, 65)  # 33..38: the persistent igemm5 tiles; 65: igemm7 (panel-resident 1x1)
 WGRAD_CANDIDATES = (2, 3, 4, 7, 8, 9, 10)
 
 
