@@ -205,11 +205,12 @@ typedef struct {
      (deterministic), rounds, stores y and writes the statistics partials (a row per 16 pixels).  The float32 sum is
      grouped differently from the one-pass kernels: results agree with them to 1 bf16 ulp, not bit for bit.          */
   void* splitk_ws; int64_t splitk_ws_bytes;
-  /* stats_rows_mod = R > 0 (round 4): the statistics of a tile are ADDED (float32 atomics) into row (tile index mod R) of
-     stats_partial = [R][stats_ld][2], which must be ZERO at launch -- R rows whatever the tile shape (mbx_conv_stats_rows()
-     = R), few enough for the consumer to reduce them itself (mbx_bn_apply_fused_mapped: no finalize launch), many enough
-     that the adders of one address stay few.  The order of the additions is not fixed: sums differ from run to run in the
-     last float32 bits (callers that need bit-reproducible statistics leave it 0: a plain row per tile).
+  /* stats_rows_mod = R > 0 (round 4): the statistics of a tile are ADDED into row (tile index mod R) of a table
+     [R][stats_ld][2] of INT64 that stats_partial then points at (16 bytes per channel and row) and that must be ZERO at
+     launch -- R rows whatever the tile shape (mbx_conv_stats_rows() = R), few enough for the consumer to reduce them itself
+     (mbx_bn_apply_fused_mapped: no finalize launch), many enough that the adders of one address stay few.  The sums are
+     added as 64-bit integers in fixed point (units of 2^-20: |sum| < 8.8e12, resolution 1e-6): integer addition is
+     associative, so the table does not depend on the order in which the tiles arrive -- bit-reproducible statistics.
      stats_ld (0: C_out): channels per row -- sibling convolutions of a batch-norm group add into channel slices of one
      table (stats_partial then points at the member's first channel).                                              */
   int32_t stats_rows_mod, stats_ld;
@@ -317,12 +318,13 @@ int mbx_bn_apply_fused(const float* stats_partial, int rows, int64_t count, floa
                        const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
                        float* mean, float* rstd, float* moving_mean, float* moving_var,
                        mbx_stream_t stream);
-/* The same in one launch WHATEVER `rows` is, with the activation view addressed through a group's channel map (NULL: the
- * identity; see BATCH-NORM GROUPS below) -- the consumer of a convolution that ADDED its statistics into few rows
- * (mbx_conv_desc.stats_rows_mod = 16: every workgroup re-reduces 16 rows of its 64 channels; no finalize launch).
+/* Finalize + apply in one launch for a convolution that ADDED its statistics into few rows (mbx_conv_desc.stats_rows_mod:
+ * stats_fixed = that INT64 fixed-point table [rows][C][2], rows <= 16, C <= 2048; every workgroup reduces the rows of all
+ * C channels itself, then sweeps whole rows of y), with the activation view addressed through a group's channel map (NULL:
+ * the identity; see BATCH-NORM GROUPS below).
  * relu_thr ([C], may be NULL): the ReLU threshold on y, mean - beta / rstd (-inf without relu): (y - mean) rstd + beta > 0
  * <=> y > relu_thr -- what mbx_conv's BN-backward statistics epilogue masks with.                                      */
-int mbx_bn_apply_fused_mapped(const float* stats_partial, int rows, int64_t count, float eps, float decay,
+int mbx_bn_apply_fused_mapped(const void* stats_fixed, int rows, int64_t count, float eps, float decay,
                               const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
                               const struct mbx_chan_map_s* a_map /*HOST*/, float* mean, float* rstd, float* moving_mean,
                               float* moving_var, float* relu_thr, mbx_stream_t stream);

@@ -72,14 +72,18 @@ __device__ __forceinline__ float row_sum16(float v) {
 __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
   return (unsigned)(((unsigned long long)m * magic) >> shift);
 }
-// one channel's statistics sums of one tile (or of one workgroup) into the partial table: a plain row per tile, or --
-// stats_mod rows whatever the tile count -- float32 atomics into row (tile mod stats_mod) of a table that is zero at launch
-// (hardware float atomics, fire and forget: performed at the memory side, nothing returns)
+// one channel's statistics sums of one tile (or of one workgroup) into the partial table: a plain float32 row per tile, or --
+// stats_mod rows whatever the tile count -- ADDED into row (tile mod stats_mod) of a table that is zero at launch.  The adds
+// are 64-bit INTEGER atomics on the sums in fixed point (2^-20 units: |sum| < 8.8e12, resolution 1e-6 -- the tile sums are
+// float32 values of magnitude 1 .. 1e6): integer addition is associative, so the table does not depend on the order in which
+// the tiles arrive and the forward pass stays bit-reproducible (float atomics made it differ from run to run in the last
+// bits of every mean, which a chaotic network amplifies).  Fire and forget, performed at the memory side.
+constexpr float kStatsFix = 1048576.f;                  // 2^20
 __device__ __forceinline__ void stats_write(const ConvK& p, const int tile_row, const int ch, const float x1, const float x2) {
   if (p.stats_mod) {
-    float* o = p.stats + ((size_t)(tile_row % p.stats_mod) * p.stats_ld + ch) * 2;
-    unsafeAtomicAdd(o, x1);
-    unsafeAtomicAdd(o + 1, x2);
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + ((size_t)(tile_row % p.stats_mod) * p.stats_ld + ch) * 2;
+    atomicAdd(o, (unsigned long long)__float2ll_rn(x1 * kStatsFix));
+    atomicAdd(o + 1, (unsigned long long)__float2ll_rn(x2 * kStatsFix));
   } else {
     float* o = p.stats + ((size_t)tile_row * p.stats_ld + ch) * 2;
     o[0] = x1;

@@ -424,21 +424,20 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
   u32x4 first = u32x4{0u, 0u, 0u, 0u};
   if (active && m < M) first = ld8(y + m * C + c);
   for (int ch = threadIdx.x; ch < C; ch += kT) {
-    const float* src = part + (size_t)ch * 2;
-    double s1 = 0.0, s2 = 0.0;
+    // the rows are 64-bit fixed-point sums (2^-20 units) added by integer atomics: exact integer sum, then one conversion
+    const longlong2* src = reinterpret_cast<const longlong2*>(part) + ch;
+    long long i1 = 0, i2 = 0;
     int r = 0;
     for (; r + 3 < rows; r += 4) {                        // four rows' loads in flight
-      const float2 v0 = *reinterpret_cast<const float2*>(src + (size_t)(r + 0) * C * 2);
-      const float2 v1 = *reinterpret_cast<const float2*>(src + (size_t)(r + 1) * C * 2);
-      const float2 v2 = *reinterpret_cast<const float2*>(src + (size_t)(r + 2) * C * 2);
-      const float2 v3 = *reinterpret_cast<const float2*>(src + (size_t)(r + 3) * C * 2);
-      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+      const longlong2 v0 = src[(size_t)(r + 0) * C], v1 = src[(size_t)(r + 1) * C], v2 = src[(size_t)(r + 2) * C], v3 = src[(size_t)(r + 3) * C];
+      i1 += (v0.x + v1.x) + (v2.x + v3.x);
+      i2 += (v0.y + v1.y) + (v2.y + v3.y);
     }
     for (; r < rows; ++r) {
-      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)r * C * 2);
-      s1 += v.x; s2 += v.y;
+      const longlong2 v = src[(size_t)r * C];
+      i1 += v.x; i2 += v.y;
     }
+    const double s1 = (double)i1 * (1.0 / 1048576.0), s2 = (double)i2 * (1.0 / 1048576.0);
     const double mu = s1 * inv_count;
     double var = s2 * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -1953,33 +1952,25 @@ extern "C" int mbx_ema_update(float* ema, const float* value, int64_t n, float e
   return MBX_OK;
 }
 
-extern "C" int mbx_bn_apply_fused_mapped(const float* stats_partial, int rows, int64_t count, float eps, float decay,
+extern "C" int mbx_bn_apply_fused_mapped(const void* stats_partial, int rows, int64_t count, float eps, float decay,
                                          const void* y, int64_t M, int C, const float* beta, int relu, void* a, int ld_a,
                                          const mbx_chan_map* a_map, float* mean, float* rstd, float* mmean, float* mvar,
                                          float* relu_thr, mbx_stream_t stream) {
   if (!stats_partial || !y || !a || !beta || !mean || !rstd || rows <= 0 || M <= 0 || C <= 0 || C % 8 || ld_a % 8 ||
       count <= 0 || !al16(y) || !al16(a) || !al16(stats_partial))
     return MBX_ERR_INVALID_ARG;
+  if (rows > 16 || C > kRowsMaxC) return MBX_ERR_UNSUPPORTED;
   ChanMap cm;
   if (to_chan_map(a_map, C, cm) != MBX_OK) return MBX_ERR_INVALID_ARG;
   MBX_ENTER();
-  static const int rows_kernel = env_int("MBX_BN_ROWS_KERNEL", 1), rows_blocks = env_int("MBX_BN_ROWS_BLOCKS", 1024);
-  if (rows_kernel && rows <= 16 && C <= kRowsMaxC) {
-    // whole-row sweeps; every workgroup reduces the few rows of all C channels itself (bn_apply_rows_kernel)
-    const int C8 = C / 8, rpi = kT / C8 > 0 ? kT / C8 : 1;
-    long long g = (M + rpi - 1) / rpi;
-    if (g > rows_blocks) g = rows_blocks;
-    hipLaunchKernelGGL(bn_apply_rows_kernel, dim3((unsigned)g), dim3(kT), (size_t)3 * C * sizeof(float), mbx_s(stream), stats_partial,
-                       rows, 1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd,
-                       mmean, mvar, cm, relu_thr);
-    MBX_LAUNCH_CHECK();
-    return MBX_OK;
-  }
-  int groups, chunks, rpc;
-  bn_fused_grid(M, C, rows, groups, chunks, rpc);
-  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(groups, chunks), dim3(kT), 0, mbx_s(stream), stats_partial, rows,
-                     1.0 / (double)count, eps, decay, (cus)y, (long long)M, C, beta, relu, (us)a, ld_a, mean, rstd, mmean,
-                     mvar, rpc, cm, relu_thr);
+  static const int rows_blocks = env_int("MBX_BN_ROWS_BLOCKS", 1024);
+  // whole-row sweeps; every workgroup reduces the few fixed-point rows of all C channels itself (bn_apply_rows_kernel)
+  const int C8 = C / 8, rpi = kT / C8 > 0 ? kT / C8 : 1;
+  long long g = (M + rpi - 1) / rpi;
+  if (g > rows_blocks) g = rows_blocks;
+  hipLaunchKernelGGL(bn_apply_rows_kernel, dim3((unsigned)g), dim3(kT), (size_t)3 * C * sizeof(float), mbx_s(stream),
+                     reinterpret_cast<const float*>(stats_partial), rows, 1.0 / (double)count, eps, decay, (cus)y, (long long)M, C,
+                     beta, relu, (us)a, ld_a, mean, rstd, mmean, mvar, cm, relu_thr);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }

@@ -28,7 +28,7 @@ from . import _lib, ops
 from .ops import View
 
 BN_EPS = 0.001           # train.py:96
-STATS_ROWS = int(os.environ.get("MBX_STATS_ROWS", "16"))          # replica rows of the atomically added batch-norm statistics (mbx_conv_desc.stats_rows_mod)
+STATS_ROWS = int(os.environ.get("MBX_STATS_ROWS", "8"))          # replica rows of the atomically added batch-norm statistics (mbx_conv_desc.stats_rows_mod)
 WEIGHT_DECAY = 0.00004   # train.py:104-105
 
 
@@ -110,18 +110,18 @@ class Net:
         # (no atomics) and un-split weight-gradient tiles (one adder per element); slower, same mathematics
         self.deterministic = bool(int(os.environ.get("MBX_DETERMINISTIC", "0")))
         self.no_onepass = self.deterministic or bool(int(os.environ.get("MBX_NO_BN_ONEPASS", "0")))    # A/B knob: three-launch BN backward
-        # OPTION, off (MBX_ATOMIC_STATS=1): forward batch-norm statistics ADDED by the convolution epilogues into STATS_ROWS
-        # replica rows per layer (float32 atomics; cleared with the work counters at the start of forward()), reduced by the
-        # apply launch itself: no finalize launch.  Measured (round 4, LAB_NOTES): 130 launches of 4.5 us go, the apply launch
-        # grows by 2.2 us (the rows prologue) and every statistics convolution by 0.3-0.5 us (the atomics' acknowledgement at
-        # the end of the kernel): -0.06..-0.14 ms per step -- and the forward pass stops being run-to-run reproducible (the
-        # order of the adds), which at batch 2 / random init moves the losses by percents.  Not worth its price.
-        self.atomic_stats = mode == "train" and not self.deterministic and os.environ.get("MBX_ATOMIC_STATS", "0") == "1"
+        # Forward batch-norm statistics ADDED by the convolution epilogues into STATS_ROWS replica rows per layer (64-bit
+        # fixed-point INTEGER atomics: order-independent, so the forward pass stays bit-reproducible; cleared with the work
+        # counters at the start of forward()), reduced by the apply launch itself: no finalize launch.  Measured (round 4,
+        # LAB_NOTES): 130 launches of 4.5 us go, the apply launch grows by 2.2 us (the rows prologue) and every statistics
+        # convolution by 0.3-0.5 us (the atomics' acknowledgement at the end of the kernel): -0.05..-0.14 ms per step.
+        # MBX_ATOMIC_STATS=0: a plain float32 row per tile + finalize (also what MBX_DETERMINISTIC=1 uses).
+        self.atomic_stats = mode == "train" and not self.deterministic and os.environ.get("MBX_ATOMIC_STATS", "1") != "0"
         # batch-norm BACKWARD statistics produced by the data gradient that writes the activation gradient (mbx_bn_bwd_stats):
         # the layer's backward then is ONE streaming launch (mbx_bn_bwd_apply_rows) instead of the grid-barrier launch --
         # wherever every channel of the layer's activation has exactly one consumer and that is a stride-1 convolution
         # (_plan_bw_stats: the branch layers of block35 / block17 / block8, 121 of 141 launches).  Needs the relu
-        # thresholds the atomic-statistics forward writes.  OPTION, off (MBX_ATOMIC_STATS=1 MBX_BW_STATS=1).  Measured (round
+        # thresholds the atomic-statistics forward writes.  OPTION, off (MBX_BW_STATS=1).  Measured (round
         # 4): the backward launch drops from 14.2 to 8.9 us, but the statistics epilogue costs its data gradient 3.3-5.5 us
         # (threshold loads, sums, cross-wave reduce, the atomics' acknowledgement -- all on the tail of a launch that has one
         # tile per CU) and 17 us where the 256 x 128 tile has no room for it: 15.98 -> 16.5 ms per step.
@@ -542,9 +542,9 @@ class Net:
                 ko = 0 if g is None else g.koff[g.members.index(op)]
                 op.y_view = View(ybuf, N_, H_, W_, op.K, K_all, ko)
                 if lead:
-                    op.stats16_base = n_stats16                 # [STATS_ROWS][K_all][2] floats of the layer / group
-                    n_stats16 += STATS_ROWS * K_all * 2
-                op.stats16_off = (op.stats16_base if g is None else g.members[0].stats16_base) + 2 * ko
+                    op.stats16_base = n_stats16                 # [STATS_ROWS][K_all][2] int64 (fixed point) of the layer / group, in float units
+                    n_stats16 += STATS_ROWS * K_all * 4
+                op.stats16_off = (op.stats16_base if g is None else g.members[0].stats16_base) + 4 * ko
                 d = self._desc(op, op.y_view)
                 rows = max(ops.conv_stats_rows(d), (op.M + 63) // 64)                                   # any tile height
                 if g is None and ops.splitk_slices(d, self.n_cus):

@@ -227,7 +227,7 @@ def test_conv_direct3_bit_identical(T, g):
                          ["mid_cfg%d" % c for c in list(range(1, 15)) + [33, 34, 35, 36, 37]])
 def test_conv_stats_atomic_rows(T, g, cfg):
     """mbx_conv_desc.stats_rows_mod = 16 (round 4): the tiles ADD their statistics sums into 16 rows of a zeroed table
-    (float32 atomics) instead of writing a row each -- for every kernel family with a statistics epilogue.  Outputs
+    (64-bit fixed-point integer atomics: order-independent) instead of writing a row each -- for every kernel family with a statistics epilogue.  Outputs
     bit-identical to the plain launch; the 16 rows sum to the plain rows' sums (float32 rounding of a different grouping:
     rtol 1e-5); with stats_ld the sums land in a channel slice of a wider table, the rest of which stays zero; and
     mbx_bn_apply_fused_mapped on the 16 rows gives mean / rstd / activation of finalize + apply on the plain rows."""
@@ -265,13 +265,18 @@ def test_conv_stats_atomic_rows(T, g, cfg):
     plain = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
     y0, _ = run(plain, 0, 0)
     ld = Co + 24
-    table = torch.zeros((16, ld, 2), dtype=torch.float32, device="cuda")
+    table = torch.zeros((16, ld, 2), dtype=torch.int64, device="cuda")      # fixed point, units of 2^-20 (integer atomics)
     y1, _ = run(table[:, 8:], 16, ld)                 # the member's first channel = channel 8 of the table
     assert torch.equal(y0.tensor(), y1.tensor())
-    assert float(table[:, :8].abs().max()) == 0 and float(table[:, 8 + Co:].abs().max()) == 0
-    want, got = plain.double().sum(0).cpu(), table[:, 8:8 + Co].double().sum(0).cpu()
+    assert int(table[:, :8].abs().max()) == 0 and int(table[:, 8 + Co:].abs().max()) == 0
+    want, got = plain.double().sum(0).cpu(), table[:, 8:8 + Co].sum(0).double().cpu() / 2.0 ** 20
     assert torch.allclose(want, got, rtol=1e-5, atol=1e-3), float((want - got).abs().max())
     assert int((table[:, 8:8 + Co, 1].abs().sum(1) > 0).sum()) == min(16, rows)       # spread over the rows, not piled on one
+    # integer adds are associative: a second launch into a cleared table leaves the same bits whatever order the tiles arrive in
+    first = table.clone()
+    table.zero_()
+    run(table[:, 8:], 16, ld)
+    assert torch.equal(first, table)
     # the consumer: finalize + apply on the plain rows against the one-launch form on the 16 rows
     dense = table[:, 8:8 + Co].contiguous()
     beta = (torch.randn(Co, generator=torch.Generator().manual_seed(1)) * 0.3).cuda()
