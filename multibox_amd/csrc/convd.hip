@@ -496,6 +496,281 @@ int launch_stem(const ConvK& k, const DirK& q, int grid, hipStream_t s) {
   return MBX_OK;
 }
 
+// ------------------------------------------------------------------------------------------ whole-width tiles
+// conv_directw_kernel: the same direct scheme for NARROW maps (block35's 35 x 35: three 3x3 convolutions per block, forward
+// and data gradient, C_in 32 / 48 / 64, C_out 32 / 48 / 64 -- 0.7 ms of the training step at 170-300 TFLOP/s as implicit
+// GEMMs, whose 16-byte gather pieces are 64-96 byte runs of a 480-byte pixel: nine taps' worth of badly coalesced L2 -> LDS
+// traffic).  conv_direct3_kernel's 8 x 32 tiles fill a 35-wide map to 55 %; here a tile is TH whole rows (TH * W <= 256
+// pixels: 7 x 35), the pixels of a tile are numbered row-major and dealt 32 per wave, and the K range is walked LINEARLY in
+// 32-element groups exactly as the implicit GEMM does -- group g = K elements [32 g, 32 g + 32) of (tap, channel), lane
+// group fch holding the 8 channels of chunk 4 g + fch -- so that any C_in that is a multiple of 8 works (48: a group
+// straddles two taps) and the results stay bit-identical to the implicit GEMM.  The filter image is the KRSC rows as they
+// lie in memory (K linear), rows padded to an odd chunk count (conflict-free fragment reads).
+struct DirW { int N, H_out, TH, PH, PW, tiles_h, ntiles, npix; };
+constexpr int kWMaxPix = 340;                             // patch pixels a buffer holds ((7 + 2) x (35 + 2) = 333)
+
+template <int C8>
+__device__ __forceinline__ int wkey(int pcol) { return C8 == 4 ? ((pcol >> 2) & 3) : C8 == 8 ? ((pcol >> 1) & 7) : 0; }
+
+template <int C8, int CO, int EV>
+__device__ __forceinline__ void directw_body(const ConvK& p, const DirW& q, const int first, const int G) {
+  constexpr int CI = 8 * C8, NA = CO / 16, NG = (9 * C8 + 3) / 4;
+  constexpr int PROUNDS = (kWMaxPix * C8 + kDThreads - 1) / kDThreads;
+  constexpr int PBUF = PROUNDS * kDThreads;
+  constexpr int WROW = 4 * NG + 1;                        // chunks per filter-image row: the K range, zero fill, one of padding
+  constexpr int WCH = CO * WROW;
+  constexpr int WROUNDS = (WCH + kDThreads - 1) / kDThreads;
+  constexpr int NS = 2 * (CO / 32 + (CO % 32 ? 1 : 0));   // store instructions of a tile's epilogue, per wave
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* const wimg = smem;
+  u32x4* const pbuf = smem + WROUNDS * kDThreads;         // two patch buffers
+  float* const red = reinterpret_cast<float*>(pbuf + 2 * PBUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int npatch = q.PH * q.PW;
+  int prow[PROUNDS], pcol[PROUNDS], pc8[PROUNDS];
+#pragma unroll
+  for (int i = 0; i < PROUNDS; ++i) {
+    const int ch = i * kDThreads + tid;
+    const int pix = ch / C8, cs = ch - pix * C8;
+    prow[i] = pix / q.PW;
+    pcol[i] = pix - prow[i] * q.PW;
+    pc8[i] = cs ^ wkey<C8>(pcol[i]);                      // the DMA destination is lane-linear: swizzle the SOURCE chunk
+    if (pix >= npatch) prow[i] = -1;
+  }
+  auto issue_patch = [&](int t, int buf) {
+    const int img = t / q.tiles_h, th = t - img * q.tiles_h;
+    const int h_in0 = th * q.TH - p.pad_t, w_in0 = -p.pad_l;
+    u32x4* dst = pbuf + buf * PBUF + wave * 64;
+#pragma unroll
+    for (int i = 0; i < PROUNDS; ++i) {
+      const int h = h_in0 + prow[i], w = w_in0 + pcol[i];
+      const bool ok = prow[i] >= 0 && (unsigned)h < (unsigned)p.H_in && (unsigned)w < (unsigned)p.W_in;
+      glds16(xr, dst + i * kDThreads, ok ? (img * p.x_img_stride + (h * p.W_in + w) * p.ldx + pc8[i] * 8) * 2 : (int)kOOB);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < WROUNDS; ++i) {                     // the filter image: row 16 a + f = output channel dperm(a, f), K linear
+    const int ch = i * kDThreads + tid;
+    const int row = ch / WROW, c = ch - row * WROW;
+    const int co = dperm<CO>(row >> 4, row & 15);
+    const bool ok = ch < WCH && c < 9 * C8 && co < p.C_out;
+    glds16(wr, wimg + i * kDThreads + wave * 64, ok ? (co * 9 * CI + c * 8) * 2 : (int)kOOB);
+  }
+  if (first < q.ntiles) issue_patch(first, 0);
+  wait_vmcnt<0>();
+  lds_readback_wait(lds_readback_issue(pbuf + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+  raw_barrier();
+
+  const int frow = lane & 15, fch = lane >> 4;
+  // this lane's two output pixels (tile-relative, row-major numbering) and the patch slots of their K chunks
+  int orow[2], ocol[2];
+  bool oval[2];
+  int poff[NG][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int pidx = 32 * wave + 16 * b + frow;
+    oval[b] = pidx < q.npix;
+    const int pp = oval[b] ? pidx : 0;
+    orow[b] = pp / p.W_out;
+    ocol[b] = pp - orow[b] * p.W_out;
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int k8 = 4 * g + fch;
+    const int tap = k8 < 9 * C8 ? k8 / C8 : 0, c8 = k8 < 9 * C8 ? k8 - tap * C8 : 0;   // (past the K range the filter chunk is zero)
+    const int r = tap / 3, sx = tap - 3 * r;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) poff[g][b] = ((orow[b] + r) * q.PW + ocol[b] + sx) * C8 + (c8 ^ wkey<C8>(ocol[b] + sx));
+  }
+  float s1[NA][4], s2[NA][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[a][r] = 0.f; s2[a][r] = 0.f; }
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+  constexpr int NPq = CO / 32;
+  float sc8[NPq > 0 ? NPq : 1][8], sh8[NPq > 0 ? NPq : 1][8], sc4[4], sh4[4];
+  if constexpr (EV == 3) {
+#pragma unroll
+    for (int A = 0; A < NPq; ++A)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 32 * A + 8 * fch + j;
+        sc8[A][j] = (p.scale && c < p.C_out) ? p.scale[c] : 1.f;
+        sh8[A][j] = (p.shiftv && c < p.C_out) ? p.shiftv[c] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 2 * NPq * 16 + 4 * fch + j;
+      sc4[j] = (p.scale && c < p.C_out) ? p.scale[c] : 1.f;
+      sh4[j] = (p.shiftv && c < p.C_out) ? p.shiftv[c] : 0.f;
+    }
+  }
+  // filter fragments in registers (as many K groups as ~112 registers hold), the rest read from LDS per tile
+  constexpr int WBUD = NA >= 4 ? 80 : 112;                // (64 output channels: 32 accumulator + 32 statistics registers more)
+  constexpr int WT = (WBUD / (NA * 4)) < NG ? (WBUD / (NA * 4)) : NG;
+  bf16x8 wreg[WT][NA];
+#pragma unroll
+  for (int g = 0; g < WT; ++g)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) wreg[g][a] = __builtin_bit_cast(bf16x8, wimg[(a * 16 + frow) * WROW + 4 * g + fch]);
+
+  int buf = 0;
+  for (int t = first; t < q.ntiles; t += G) {
+    const bool more = t + G < q.ntiles;
+    if (more) issue_patch(t + G, buf ^ 1);                // (the other buffer: free since the barrier that ended tile t - G)
+    const u32x4* pb = pbuf + buf * PBUF;
+    f32x4 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      bf16x8 wf[NA], pf[2];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (g < WT) wf[a] = wreg[g < WT ? g : 0][a];
+        else wf[a] = __builtin_bit_cast(bf16x8, wimg[(a * 16 + frow) * WROW + 4 * g + fch]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) pf[b] = __builtin_bit_cast(bf16x8, pb[poff[g][b]]);
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+    }
+    {
+      const int img = t / q.tiles_h, th = t - img * q.tiles_h;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oh = th * q.TH + orow[b];
+        const bool pv = oval[b] && oh < q.H_out;
+        const int pix_off = img * p.y_img_stride + (oh * p.W_out + ocol[b]) * p.ldy;
+#pragma unroll
+        for (int A = 0; A < NPq; ++A) {
+          const int c0 = 32 * A + 8 * fch;
+          const bool ok = pv && c0 < p.C_out;
+          unsigned h8[8];
+          float v8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v8[r] = acc[2 * A][b][r]; v8[4 + r] = acc[2 * A + 1][b][r]; }
+          if constexpr (EV == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[A][j] + sh8[A][j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+                                                 yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
+          if constexpr (EV == 1) {
+            if (ok) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float f0 = bf2f((unsigned short)h8[r]), f1 = bf2f((unsigned short)h8[4 + r]);
+                s1[2 * A][r] += f0; s2[2 * A][r] += f0 * f0;
+                s1[2 * A + 1][r] += f1; s2[2 * A + 1][r] += f1 * f1;
+              }
+            }
+          }
+        }
+        if constexpr (NA > 2 * NPq) {                       // C_out 48: channels 32 .. 47 in the plain order
+          constexpr int a = 2 * NPq;
+          const int c0 = a * 16 + 4 * fch;
+          const bool ok = pv && c0 < p.C_out;
+          unsigned h4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[a][b][r];
+            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = fmaxf(v, 0.f); }
+            h4[r] = f2bf(v);
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)}, yr,
+                                                ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
+          if constexpr (EV == 1) {
+            if (ok) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float f = bf2f((unsigned short)h4[r]); s1[a][r] += f; s2[a][r] += f * f; }
+            }
+          }
+        }
+      }
+    }
+    if (more) {
+      wait_vmcnt<NS>();                                   // the next patch has retired (behind it: this tile's NS stores only)
+      lds_readback_wait(lds_readback_issue(pbuf + (buf ^ 1) * PBUF + (PROUNDS - 1) * kDThreads + wave * 64 + lane));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+    buf ^= 1;
+  }
+  if constexpr (EV == 1) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
+        if (frow == 0) {
+          const int ch = dperm<CO>(a, 4 * fch + r);
+          red[(wave * CO + ch) * 2] = x1;
+          red[(wave * CO + ch) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (tid < CO && tid < p.C_out) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { x1 += red[(w * CO + tid) * 2]; x2 += red[(w * CO + tid) * 2 + 1]; }
+      stats_write(p, first, tid, x1, x2);
+    }
+  }
+}
+
+template <int C8, int CO, int EV>
+__global__ void __launch_bounds__(kDThreads)
+conv_directw_kernel(const ConvK p, const DirW q) {
+  directw_body<C8, CO, EV>(p, q, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int C8, int CO>
+constexpr int directw_lds() {
+  constexpr int NG = (9 * C8 + 3) / 4, WROW = 4 * NG + 1;
+  constexpr int PBUF = (kWMaxPix * C8 + kDThreads - 1) / kDThreads * kDThreads;
+  constexpr int WB = (CO * WROW + kDThreads - 1) / kDThreads * kDThreads;
+  return (WB + 2 * PBUF) * 16 + 8 * CO * 2 * 4;
+}
+
+template <int C8, int CO>
+int launch_directw(const ConvK& k, const DirW& q, int grid, hipStream_t s) {
+  constexpr int lds = directw_lds<C8, CO>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr[3] = {false, false, false};
+  const int ev = k.epi == MBX_EPI_AFFINE ? 2 : k.stats ? 1 : 0;
+  if (!attr[ev]) {
+    if (ev == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_directw_kernel<C8, CO, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_directw_kernel<C8, CO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_directw_kernel<C8, CO, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr[ev] = true;
+  }
+  if (ev == 2) hipLaunchKernelGGL((conv_directw_kernel<C8, CO, 3>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else if (ev) hipLaunchKernelGGL((conv_directw_kernel<C8, CO, 1>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  else hipLaunchKernelGGL((conv_directw_kernel<C8, CO, 0>), dim3(grid), dim3(kDThreads), lds, s, k, q);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
+// tile height of the whole-width launch for an output W_out wide (0: the map is too wide for it)
+inline int directw_th(int W_out) {
+  if (W_out < 8 || W_out > 64) return 0;
+  int th = 256 / W_out;
+  const int by_patch = kWMaxPix / (W_out + 2) - 2;
+  if (by_patch < th) th = by_patch;
+  return th >= 2 ? th : 0;
+}
+
 template <int CI, int CO>
 constexpr int direct3_lds() {
   constexpr int C8 = CI / 8;
@@ -539,6 +814,41 @@ int mbx_direct3_grid(int N, int H_out, int W_out) {
   const long nt = (long)N * ((H_out + kDTH - 1) / kDTH) * ((W_out + kDTW - 1) / kDTW);
   const int ncu = direct3_cus();
   return nt < ncu ? (int)nt : ncu;
+}
+
+// workgroups (= statistics rows) of the whole-width direct launch (tile_config 97)
+int mbx_directw_grid(int N, int H_out, int W_out) {
+  const int th = directw_th(W_out);
+  if (!th) return 0;
+  const long nt = (long)N * ((H_out + th - 1) / th);
+  const int ncu = direct3_cus();
+  return nt < ncu ? (int)nt : ncu;
+}
+
+// mbx_conv_desc.tile_config = 97: the whole-width direct 3x3 launch (conv_directw_kernel) -- 3x3 / stride 1, forward or data
+// gradient, C_in 32 / 48 / 64, C_out <= 64 (a multiple of 8), maps 8..64 wide; bf16 store with or without statistics, or affine.
+int mbx_launch_directw(void* convk, int N, int H_out, hipStream_t s) {
+  ConvK& k = *reinterpret_cast<ConvK*>(convk);
+  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip ||
+      k.rscale != 0.f || k.bw_n || (k.epi == MBX_EPI_AFFINE && k.stats))
+    return MBX_ERR_UNSUPPORTED;
+  if ((k.C_in != 32 && k.C_in != 48 && k.C_in != 64) || k.C_out > 64 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2)
+    return MBX_ERR_UNSUPPORTED;
+  DirW q;
+  q.TH = directw_th(k.W_out);
+  if (!q.TH || k.W_in > k.W_out + 2) return MBX_ERR_UNSUPPORTED;   // (the patch is W_out + 2 columns wide: VALID / SAME / full padding all fit)
+  q.N = N; q.H_out = H_out;
+  q.PH = q.TH + 2; q.PW = k.W_out + 2;
+  q.tiles_h = (H_out + q.TH - 1) / q.TH;
+  q.ntiles = N * q.tiles_h;
+  q.npix = q.TH * k.W_out;
+  const int grid = mbx_directw_grid(N, H_out, k.W_out);
+  if (k.dry) return MBX_OK;
+  const int co = k.C_out <= 32 ? 32 : k.C_out <= 48 ? 48 : 64;
+#define MBX_DW(C8_, CO_) if (k.C_in == 8 * C8_ && co == CO_) return launch_directw<C8_, CO_>(k, q, grid, s);
+  MBX_DW(4, 32) MBX_DW(4, 48) MBX_DW(4, 64) MBX_DW(6, 32) MBX_DW(6, 48) MBX_DW(6, 64) MBX_DW(8, 32) MBX_DW(8, 48)
+#undef MBX_DW
+  return MBX_ERR_UNSUPPORTED;                             // 64 -> 64: filter image + two patches do not fit 160 KB of LDS
 }
 
 // mbx_conv_desc.tile_config = 96: the direct 3x3 launch.  MBX_ERR_UNSUPPORTED for anything but a 3x3 / stride-1 convolution

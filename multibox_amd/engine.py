@@ -673,7 +673,8 @@ class Net:
                 dd = ops.ConvDesc()                               # (the fields ops.direct3_applies looks at, of X's data gradient)
                 dd.R, dd.S, dd.stride, dd.epilogue, dd.C_in, dd.C_out = X.R, X.S, 1, ops.EPI_STORE, X.K, X.Cin
                 dd.N, dd.H_out, dd.W_out, dd.rscale = X.x.N, X.x.H, X.x.W, (X.rscale if X.kind == "residual" else 0.0)
-                if ops.direct3_applies(dd):
+                dd.W_out = X.x.W
+                if ops.direct3_applies(dd) or ops.directw_applies(dd):
                     continue
                 conv_ok[id(X)] = segs
             drop = set()
@@ -748,6 +749,10 @@ class Net:
             if ops.direct3_applies(d):
                 d.tile_config, d.work_counter = ops.DIRECT3_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 " + op.name)
+            elif ops.directw_applies(d):
+                # few channels on a NARROW map (block35's 3x3 layers, 35 x 35): the whole-width direct launch
+                d.tile_config, d.work_counter = ops.DIRECTW_TILE_CONFIG, None
+                _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 (whole-width) " + op.name)
         return d
 
     def _build_forward_launches(self):

@@ -178,6 +178,25 @@ def direct3_applies(desc: ConvDesc, min_pixels=300000):
     return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_DIRECT3_MIN_PIXELS", min_pixels))
 
 
+DIRECTW_TILE_CONFIG = 97                       # the whole-width direct 3x3 launch for narrow maps (csrc/convd.hip, conv_directw_kernel)
+
+
+def directw_applies(desc: ConvDesc, min_pixels=60000):
+    """The whole-width direct 3x3 launch by rule: 3x3 / stride 1 (forward or data gradient), C_in 32 / 48 / 64, C_out <= 64,
+    plain bf16 store (+ statistics) or affine epilogue, a map 8..64 wide (block35's 35 x 35 layers: 78 400 pixels at
+    BATCH_SIZE 64) and enough pixels to fill the chip.  MBX_DIRECTW=0 turns it off (A/B); MBX_DIRECTW_MIN_PIXELS."""
+    if os.environ.get("MBX_DIRECTW", "1") == "0":
+        return False
+    if desc.R != 3 or desc.S != 3 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
+            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial) or desc.bn_bwd_stats:
+        return False
+    if desc.C_in not in (32, 48, 64) or desc.C_out > 64 or desc.C_out % 8 or (desc.C_in == 64 and desc.C_out > 48):
+        return False
+    if not (8 <= desc.W_out <= 64) or desc.W_in > desc.W_out + 2:
+        return False
+    return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_DIRECTW_MIN_PIXELS", min_pixels))
+
+
 def splitk_slices(desc: ConvDesc, n_cus=256):
     """Split-K slices for a forward convolution by rule (0: none): long K (>= 8192) and at most 96 tiles of 128 x 64, i.e.
     less than half the CUs busy for hundreds of K steps -- the two 3x3 head convolutions on the 1536-channel feature map

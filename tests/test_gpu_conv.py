@@ -310,6 +310,79 @@ def test_conv_stats_atomic_rows(T, g, cfg):
     assert torch.allclose(outs[1][5], thr_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("g", [("w1", 3, 35, 35, 32, 32, 3, 3, 1, (1, 1, 1, 1)), ("w2", 2, 35, 35, 32, 48, 3, 3, 1, (1, 1, 1, 1)),
+                               ("w3", 2, 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1)), ("w4", 2, 35, 35, 64, 48, 3, 3, 1, (1, 1, 1, 1)),
+                               ("w5", 3, 35, 35, 48, 32, 3, 3, 1, (1, 1, 1, 1)), ("w6", 2, 19, 17, 32, 40, 3, 3, 1, (0, 0, 0, 0)),
+                               ("w7", 5, 33, 60, 64, 32, 3, 3, 1, (1, 1, 1, 1)), ("w8", 64, 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1))],
+                         ids=["32_32", "32_48", "48_64", "64_48", "48_32", "valid_17wide_cout40", "60wide_64_32", "block35_0c_b64"])
+def test_conv_directw_bit_identical(T, g):
+    """tile_config 97 (round 4, csrc/convd.hip conv_directw_kernel): the direct 3x3 launch with WHOLE-WIDTH tiles for narrow maps
+    (block35's 35 x 35 layers) -- TH rows of the map per tile, the K range walked linearly in the implicit GEMM's 32-element
+    groups (C_in 48: a group straddles two taps) -- against the implicit-GEMM launch of the same descriptor: forward with
+    statistics, affine + relu, and as a data gradient; ragged last tile, more tiles than workgroups (BATCH_SIZE 64).
+    Outputs bit-identical; statistics = sums of the stored values; slices of wider buffers untouched outside."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=13)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    stream = torch.cuda.current_stream().cuda_stream
+    xb = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    outs = []
+    for cfg in (0, ops.DIRECTW_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb)
+        d.tile_config = cfg
+        rows = ops.conv_stats_rows(d)
+        stats = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=stats)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        full = yb.buf.reshape(N, Ho, Wo, Co + 24)
+        assert float(full[..., :16].abs().max()) == 0 and float(full[..., 16 + Co:].abs().max()) == 0
+        outs.append((yb.tensor().clone(), stats.double().sum(0).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0].float() - outs[1][0].float()).abs().max())
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-3)
+    if N <= 8:
+        ok, msg = close(torch, outs[1][0], ref_conv(torch, x, w, st, pads))
+        assert ok, msg
+    gen = torch.Generator().manual_seed(7)
+    scale, shift = (torch.rand(Co, generator=gen) + 0.5).cuda(), (torch.randn(Co, generator=gen) * 0.2).cuda()
+    aff = []
+    for cfg in (0, ops.DIRECTW_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, epilogue=ops.EPI_AFFINE, relu=1, scale=scale, shift=shift)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        aff.append(yb.tensor().clone())
+    assert torch.equal(aff[0], aff[1]) and float(aff[1].float().max()) > 0
+    # data gradient: input = dy [N,Ho,Wo,Co], flipped / transposed filter, "full" padding R - 1 - pad
+    if Co in (32, 48, 64) and not (Co == 64 and Ci > 48):
+        dy = ops.View.alloc(N, Ho, Wo, Co)
+        dy.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+        wt = w.to(torch.bfloat16).flip(1, 2).permute(3, 1, 2, 0).contiguous().cuda()          # [Ci][R][S][Co]
+        res = []
+        for cfg in (0, ops.DIRECTW_TILE_CONFIG):
+            gx = ops.View.alloc(N, H, W, Ci, zero=True)
+            dd = ops.make_desc(dy, wt, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], gx, transposed=1)
+            dd.tile_config = cfg
+            assert l.mbx_conv(C.byref(dd), stream) == 0
+            torch.cuda.synchronize()
+            res.append(gx.tensor().clone())
+        assert torch.equal(res[0], res[1]) and float(res[0].float().abs().max()) > 0
+    bad = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, accumulate=1)
+    bad.tile_config = ops.DIRECTW_TILE_CONFIG
+    assert l.mbx_conv_supported(C.byref(bad)) == -2
+
+
 @pytest.mark.parametrize("cfg", [0, 2, 5, 6, 10, 12, 14, 33, 34, 35, 37, "pair"])
 def test_conv_bn_bwd_stats_epilogue(T, cfg):
     """mbx_conv_desc.bn_bwd_stats (round 4): the data gradient that writes an activation gradient also adds the batch-norm
