@@ -142,7 +142,7 @@ def main():
             if "pack_input" in e.name:
                 cur = []
                 steps.append(cur)
-            elif ("conv_igemm" in e.name or "conv_direct3" in e.name or "conv_stem" in e.name) and "pair_kernel" not in e.name \
+            elif ("conv_igemm" in e.name or "conv_direct" in e.name or "conv_stem" in e.name) and "pair_kernel" not in e.name \
                     and cur is not None:                       # (pair launches go through mbx_conv_pair: not tuned here)
                 cur.append(e)
         steps = [s_ for s_ in steps if len(s_) == n_calls]
@@ -202,7 +202,7 @@ def main():
         better = min(walls["new"]) < min(walls["old"]) and sum(walls["new"]) < sum(walls["old"])
         if changed and better and not args.dry:
             for key, cfg in new.items():
-                if cfg > ops.SPLITK_FLAG or cfg == ops.DIRECT3_TILE_CONFIG:
+                if cfg > ops.SPLITK_FLAG or cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG):
                     continue                                  # chosen by rule at net build (split-K, direct launches): not table entries
                 ops._TUNED[key] = cfg
                 if cfg > ops.I5_FLAG:
