@@ -749,8 +749,11 @@ class Net:
             if ops.direct3_applies(d):
                 d.tile_config, d.work_counter = ops.DIRECT3_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 " + op.name)
-            elif ops.directw_applies(d):
-                # few channels on a NARROW map (block35's 3x3 layers, 35 x 35): the whole-width direct launch
+            elif ops.directw_applies(d) and not (what == "fwd" and d.stats_partial and getattr(op, "group", None) is not None
+                                                 and len(op.group.members) == 2 and os.environ.get("MBX_CONV_PAIR", "1") != "0"):
+                # few channels on a NARROW map (block35's 3x3 layers, 35 x 35): the whole-width direct launch -- except for the
+                # two sibling FORWARD convolutions of a batch-norm group in training, which the implicit GEMM runs as ONE pair
+                # launch (21.7 us against 12.0 + 11.3 as two direct launches: these launches are latency-bound)
                 d.tile_config, d.work_counter = ops.DIRECTW_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 (whole-width) " + op.name)
         return d
