@@ -222,10 +222,13 @@ typedef struct {
    POINTWISE launch with the filter panel resident in LDS (1x1, unit stride, unpadded, 64 < K <= 384, no statistics; its
    work_counter, if given, is an array of one zeroed int32 per 128-channel column tile, at most 32).  A configuration that
    does not apply returns MBX_ERR_UNSUPPORTED.
-   tile_config 96: the DIRECT 3x3 launch (stride 1, forward or data gradient, C_in 32 / 64, C_out <= 64, bf16 store with or
-   without statistics) for few channels on large maps: a persistent workgroup per CU stages a pixel patch with its halo
-   once and multiplies the nine taps out of LDS instead of gathering the input nine times.  Same accumulation order as
-   the implicit-GEMM tiles: bit-identical outputs; mbx_conv_stats_rows() = one row per workgroup. */
+   tile_config 96: the DIRECT 3x3 launch (stride 1, forward or data gradient, C_in 32 / 64, C_out <= 64; bf16 store with or
+   without statistics, or the affine epilogue) for few channels on large maps: a persistent workgroup per CU stages a pixel
+   patch with its halo once and multiplies the nine taps out of LDS instead of gathering the input nine times -- and, under
+   the same number, the network's first layer (3x3 / stride 2, C_in 8 = the packed RGB input, C_out <= 32; forward only).
+   tile_config 97: the same scheme with WHOLE-WIDTH tiles for narrow maps (8..64 wide: block35's 35 x 35 layers; C_in 32 /
+   48 / 64, C_out <= 64).  Same K order and MFMA grouping as the implicit-GEMM tiles: bit-identical outputs;
+   mbx_conv_stats_rows() = one row per workgroup. */
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);
