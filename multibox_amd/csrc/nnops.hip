@@ -567,10 +567,22 @@ inline void bn_fused_grid(long long M, int C, int rows, int& groups, int& chunks
 // HBM traffic 4 B read + 2 B written per element instead of 8 + 2, and one launch instead of three.
 // The grid is never larger than the CU count and one workgroup always fits a CU, so every workgroup is
 // resident and the barrier cannot deadlock; the spin is bounded all the same (error flag in the workspace).
+#ifndef MBX_OB_SLOTS
+#define MBX_OB_SLOTS 8
+#endif
+#ifndef MBX_OB_SLEEP
+#define MBX_OB_SLEEP 8
+#endif
 constexpr int kObT = 512;
-constexpr int kObSlots = 4;
+constexpr int kObSlots = MBX_OB_SLOTS;                        // (tools/ab_builds.sh: -DMBX_OB_SLOTS=n / -DMBX_OB_SLEEP=n)
 constexpr int kObMaxNV = 20;
-constexpr int kObSub = 16, kObRel = 32, kObLine = 32;           // barrier: counters / release words, words per line
+#ifndef MBX_OB_SUB
+#define MBX_OB_SUB 16
+#endif
+#ifndef MBX_OB_REL
+#define MBX_OB_REL 32
+#endif
+constexpr int kObSub = MBX_OB_SUB, kObRel = MBX_OB_REL, kObLine = 32;   // barrier: counters / release words, words per line
 constexpr int kObCtlWords = kObLine * (2 + kObSub + kObRel);     // line 0: {grid size, timeout flag}
 
 struct ObGeom { int C8, rpi, G, rpb, nv; };
@@ -718,7 +730,7 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
       const unsigned* rel = ctl + kObLine * (2 + kObSub + b % kObRel);
       unsigned spins = 0;
       while (ld_agent(rel) == 0u) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(MBX_OB_SLEEP);
         // cannot happen when the grid is resident.  If it does (CUs taken by another stream's kernels), the totals
         // below are partial: raise the flag AND poison this workgroup's outputs with NaN, so that the step cannot
         // silently train on a wrong gradient (the host also checks the flag: Trainer.check_health)
