@@ -21,7 +21,9 @@ SOURCES = {
     "priors.cpp": ["-ffp-contract=off"],
     "postproc.hip": ["-ffp-contract=off"],
     "conv.hip": ["-munsafe-fp-atomics"],
-    "conv5.hip": [],
+    # (the atomic optimizer turns the tile-fetch atomicAdd of conv_igemm5_kernel into scan + v_readfirstlane of the result,
+    # i.e. waits for it at the issue; without it the wait sits where the value is published)
+    "conv5.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "conv7.hip": [],
     "convd.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],

@@ -73,7 +73,11 @@ conv_igemm5_kernel(const ConvK p) {
   // nk > NST: the loaders read s_ids[j + 1] when they have issued the last K step of tile j, i.e. in iteration nk - NST of
   // tile j's K loop; the compute waves publish that id after the last barrier of tile j - 1 -- with nk == NST the read
   // would sit in iteration 0, behind that same barrier and in front of any other (a race: ADVICE round 3).
-  const bool queued = p.work_counter != nullptr && nk > NST;        // (uniform)
+  // ... and only when there ARE more tiles than workgroups: in a single-round launch (most of this network's) every
+  // workgroup has its one tile by position and the counter could only say "none left" -- but the first fetch is a RETURNING
+  // atomic on one address, 256 workgroups at once (~3 us), and its result used to be awaited in front of the first barrier:
+  // 0.11 ms per step (MBX_I5_STATIC A/B, round 4).  Multi-round launches fetch it without waiting (below).
+  const bool queued = p.work_counter != nullptr && nk > NST && ntiles > (int)gridDim.x;        // (uniform)
 
   if (wave >= 8) {
     // -------------------------------------------------------------------------------------------- loader waves
@@ -204,16 +208,19 @@ conv_igemm5_kernel(const ConvK p) {
   const int fw1 = fwrow * 8 + ((4 + fch) ^ fwkey);
   int st_comp = 0;
   const bool fetcher = queued && tid == 0;
-  auto fetch_tile = [&]() -> int {                                  // next id off the counter (>= ntiles: none left)
-    const int v = (int)gridDim.x + atomicAdd(p.work_counter, 1);
-    return v < ntiles ? v : ntiles;
-  };
-  if (fetcher) { s_ids[0] = first; s_ids[1] = fetch_tile(); }
+  // next id off the counter (>= ntiles: none left) in two halves: the RETURNING atomic is only issued here; the value is
+  // touched where it is published, so that the wait for it sits there and not at the issue (as one expression the compiler
+  // waited for the atomic -- one address, every workgroup at once: 1-3 us -- right behind it, at the start of every tile)
+  auto fetch_raw = [&]() -> int { return atomicAdd(p.work_counter, 1); };
+  auto tile_of = [&](const int raw) -> int { const int v = (int)gridDim.x + raw; return v < ntiles ? v : ntiles; };
+  // the id of this workgroup's SECOND tile: fetched here, published behind the barrier (the loaders read it when they have
+  // issued the first tile's last K step, nk - NST >= 1 iterations later)
+  int raw1 = 0;
+  if (fetcher) { s_ids[0] = first; raw1 = fetch_raw(); }
   raw_barrier();                                                    // step 0 has landed
+  if (fetcher) s_ids[1] = tile_of(raw1);                            // (issued in front of the barrier; visible behind the first K step's)
   int jt = 0;
   for (int t = first; t < ntiles; t = queued ? s_ids[++jt & 3] : t + (int)gridDim.x) {
-    int next2 = ntiles;
-    if (fetcher) next2 = fetch_tile();                              // id of tile jt + 2: returns during the K loop
     const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef MBX_I5_STAMPS
@@ -236,6 +243,10 @@ conv_igemm5_kernel(const ConvK p) {
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
     u32x4 pla[PREB > 0 ? PREB : 1][NA], plb[PREB > 0 ? PREB : 1][NA];
     if constexpr (PREB > 0) conv_epilogue_issue_reads<EV, false, NA, PREB>(p, mlane, clane, 0, pla, plb);
+    // id of tile jt + 2: the returning atomic is issued here (BEHIND the reads above: the compiler pairs its result register
+    // with an address register of theirs otherwise and waits for it at once) and returns during the K loop
+    int raw2 = 0;
+    if (fetcher) raw2 = fetch_raw();
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -267,7 +278,7 @@ conv_igemm5_kernel(const ConvK p) {
     }
     MBX5_STAMP(1);                                                  // K loop done
     // ---------------------------------------------------------------- epilogue: straight from the accumulators
-    if (fetcher) s_ids[(jt + 2) & 3] = next2;                       // visible behind the next tile's K-loop barriers
+    if (fetcher) s_ids[(jt + 2) & 3] = tile_of(raw2);               // visible behind the next tile's K-loop barriers
     float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];
     conv_epilogue_channels<EV, NA>(p, clane, sc, sh, s1, s2);
     if constexpr (PREB > 0) {
