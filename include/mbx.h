@@ -407,7 +407,7 @@ int mbx_bn_bwd_apply_rows(const float* stats, int rows, const void* da, int ld_d
  * one resident workgroup per CU (mbx_bn_bwd_onepass_supported; everything but the 5 stem layers at
  * BATCH_SIZE 64); otherwise MBX_ERR_UNSUPPORTED and the caller uses the three launches above.
  * `ws` (mbx_bn_bwd_onepass_workspace_bytes(C), 16-byte aligned) must be ZERO at launch; after the launch word
- * [4*2*C] holds the grid size and word [4*2*C + 1] a barrier-timeout flag (0 unless the grid was not resident);
+ * [8*2*C] (behind the eight accumulator copies) holds the grid size and word [8*2*C + 1] a barrier-timeout flag (0 unless the grid was not resident);
  * a workgroup that timed out also writes NaN into its part of dy (and dbeta), so a step cannot continue silently on
  * partial totals.  dbeta [C] += sum g (may be NULL).  max_workgroups: 0 = one
  * workgroup per CU; a smaller positive number leaves CUs free for a concurrent stream (e.g. an RCCL

@@ -137,7 +137,7 @@ def test_bn_backward_onepass(T, M, Cc, relu):
         _lib.check(l.mbx_bn_bwd_onepass(dav.ptr, dav.ld, relu, y.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
                                         beta.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), ws.data_ptr(), max_wg, None, S()))
         torch.cuda.synchronize()
-        flags = ws[4 * 2 * Cc:4 * 2 * Cc + 2].view(torch.int32).tolist()
+        flags = ws[8 * 2 * Cc:8 * 2 * Cc + 2].view(torch.int32).tolist()
         assert flags[1] == 0, "grid barrier timed out"
         assert flags[0] > 0
         assert torch.allclose(dbeta, dbeta_ref, rtol=1e-4, atol=1e-3 * float(dbeta_ref.abs().max()))
@@ -465,7 +465,7 @@ def test_bn_group_entry_points(T, M, Ks, offs, relu):
         _lib.check(l.mbx_bn_bwd_onepass_mapped(da.data_ptr() + 2 * base, ld, relu, y.data_ptr(), M, Kt, mean_g.data_ptr(), rstd_g.data_ptr(),
                                                beta.data_ptr(), dbeta_o.data_ptr(), dy_o.data_ptr(), ws.data_ptr(), 0, None, C.byref(cm), S()))
         torch.cuda.synchronize()
-        assert int(ws.view(torch.int32)[4 * 2 * Kt + 1]) == 0                       # no barrier time-out
+        assert int(ws.view(torch.int32)[8 * 2 * Kt + 1]) == 0                       # no barrier time-out
         assert torch.allclose(dbeta_o, dbeta_g, rtol=1e-4, atol=1e-3)
         ok, msg = close_bf16(dy_o, dy_g)
         assert ok, "group one-launch backward: " + msg
