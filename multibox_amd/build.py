@@ -24,7 +24,7 @@ SOURCES = {
     # (the atomic optimizer turns the tile-fetch atomicAdd of conv_igemm5_kernel into scan + v_readfirstlane of the result,
     # i.e. waits for it at the issue; without it the wait sits where the value is published)
     "conv5.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
-    "conv7.hip": [],
+    "conv7.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],        # (as conv5.hip: the tile-fetch atomics)
     "convd.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
     "augment.hip": ["-ffp-contract=off"],

@@ -149,8 +149,6 @@ conv_igemm7_kernel(const ConvK p) {
   raw_barrier();                                                    // panel and step 0 have landed
   int jt = 0;
   for (int t = first; t < none; ) {
-    int next3 = none;
-    if (fetcher) next3 = fetch_tile();                              // id of tile jt + 3: returns during the K loop
     const int m0 = t * BM;
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
     // the epilogue's reads, issued before the K loop (the compute waves never wait on vmcnt inside it)
@@ -158,6 +156,10 @@ conv_igemm7_kernel(const ConvK p) {
     constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
     u32x4 pla[PREB > 0 ? PREB : 1][NA], plb[PREB > 0 ? PREB : 1][NA];
     if constexpr (PREB > 0) conv_epilogue_issue_reads<EV, false, NA, PREB>(p, mlane, clane, 0, pla, plb);
+    // id of tile jt + 3: only the returning atomic is issued here (behind the reads above); its value is touched where the id is
+    // published (as one expression the compiler waited for it right behind the issue, at the start of every tile: conv5.hip)
+    int raw3 = 0;
+    if (fetcher) raw3 = atomicAdd(p.work_counter + g, 1);
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -185,7 +187,7 @@ conv_igemm7_kernel(const ConvK p) {
       raw_barrier();
     }
     // ---------------------------------------------------------------- epilogue: straight from the accumulators
-    if (fetcher) s_ids[(jt + 3) & 7] = next3;                       // read by the loaders two tiles from now at the earliest
+    if (fetcher) { const int v3 = gsize + raw3; s_ids[(jt + 3) & 7] = v3 < none ? v3 : none; }   // read by the loaders two tiles from now at the earliest
     float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];
     conv_epilogue_channels<EV, NA>(p, clane, sc, sh, s1, s2);
     if constexpr (PREB > 0) {
