@@ -174,12 +174,14 @@ bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const 
 
 // ---------------------------------------------------------------- batch norm: backward
 struct BnBwdGeom { int C8, rows_per_iter, rpb, rows; };
+inline int bn_bwd_rows_target() { const char* e = getenv("MBX_BN_BWD_ROWS"); const int v = e ? atoi(e) : 2048; return v >= 64 && v <= 8192 ? v : 2048; }
 inline BnBwdGeom bn_bwd_geom(long long M, int C) {
   BnBwdGeom g;
   g.C8 = C / 8;
   g.rows_per_iter = kT / g.C8;
   if (g.rows_per_iter < 1) g.rows_per_iter = 1;
-  long long rpb = (M + 511) / 512;
+  static const int target = bn_bwd_rows_target();         // partial rows (= workgroups of the reduce launch) aimed at
+  long long rpb = (M + target - 1) / target;
   if (rpb < 4LL * g.rows_per_iter) rpb = 4LL * g.rows_per_iter;
   rpb = ((rpb + g.rows_per_iter - 1) / g.rows_per_iter) * g.rows_per_iter;
   g.rpb = (int)rpb;

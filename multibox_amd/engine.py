@@ -566,7 +566,8 @@ class Net:
                         self._bufs.append(dybuf)
                         if g is not None:
                             g.dy = dybuf
-                        max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, K_all) * K_all * 2)
+                        max_bwd = max(max_bwd, l.mbx_bn_bwd_rows(op.M, K_all) * K_all * 2,
+                                      l.mbx_bn_bwd_rows_pooled(N_, H_, W_, K_all) * K_all * 2)       # (either form of the three-launch backward)
                     else:
                         dybuf = g.dy
                     op.dy_view = View(dybuf, N_, H_, W_, op.K, K_all, ko)
