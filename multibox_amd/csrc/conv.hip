@@ -260,10 +260,12 @@ __device__ __forceinline__ void conv_igemm3_body(const ConvK& p, const int bid_,
       // dimension through LDS (the ring is idle: every wave is past the last barrier of the K loop)
       float* red = reinterpret_cast<float*>(smem);             // [WMW][BN][2]
 #pragma unroll
+      for (int A = 0; A < NA; ++A) { row_sum16_x8(s1[A]); row_sum16_x8(s2[A]); }
+#pragma unroll
       for (int A = 0; A < NA; ++A)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x1 = row_sum16(s1[A][j]), x2 = row_sum16(s2[A][j]);
+          const float x1 = s1[A][j], x2 = s2[A][j];
           if (frow == 0) {
             red[((wm * BN) + cl0 + 32 * A + j) * 2] = x1;
             red[((wm * BN) + cl0 + 32 * A + j) * 2 + 1] = x2;

@@ -295,10 +295,12 @@ conv_igemm5_kernel(const ConvK p) {
       // batch-norm statistics partials of this tile (EV = 6: the backward sums of the layers this data gradient feeds): lane's pixels -> the 16 lanes sharing its channels (DPP row sums)
       // -> the WM waves along the pixel dimension through `red` (its own LDS area: the ring is being refilled)
 #pragma unroll
+      for (int A = 0; A < NA; ++A) { row_sum16_x8(s1[A]); row_sum16_x8(s2[A]); }
+#pragma unroll
       for (int A = 0; A < NA; ++A)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x1 = row_sum16(s1[A][j]), x2 = row_sum16(s2[A][j]);
+          const float x1 = s1[A][j], x2 = s2[A][j];
           if (frow == 0) {
             red[(wm * BN + cl0 + 32 * A + j) * 2] = x1;
             red[(wm * BN + cl0 + 32 * A + j) * 2 + 1] = x2;

@@ -59,14 +59,34 @@ struct ConvK {
 
 constexpr int kThreads = 256;
 
-// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): four v_add_f32_dpp row_ror, every lane
-// ends up with the row sum -- no LDS traffic (ds_bpermute shuffles made the epilogue VALU/LDS-bound).
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): four v_add_f32_dpp row_ror, every lane ends up with the
+// row sum -- no LDS traffic (ds_bpermute shuffles made the epilogue VALU/LDS-bound).  Written as ONE asm block of fused
+// DPP adds: from the builtin (update_dpp + add) the compiler SLP-packs the adds into v_pk_add_f32, which cannot take a DPP
+// operand, and emits v_mov_b32_dpp + hazard nops + packed add: 2.5x the instructions (the statistics epilogues do 32 of these
+// sums on the tail of a tile).  A DPP source written by the preceding VALU instruction needs two wait states: the leading
+// s_nop covers the caller's last write, and inside the block each add's input is three instructions old.
 __device__ __forceinline__ float row_sum16(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+               : "+v"(v));
   return v;
+}
+// ... eight independent sums at once: the adds of one rotation step back to back (no wait states needed between them)
+__device__ __forceinline__ void row_sum16_x8(float (&v)[8]) {
+#define MBX_RS_STEP(R)                                                                                                     \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %4, %4, %4 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %6, %6, %6 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:" #R " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" MBX_RS_STEP(8) MBX_RS_STEP(4) MBX_RS_STEP(2) MBX_RS_STEP(1)
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#undef MBX_RS_STEP
 }
 // exact m / d for m < 2^31: q = (m * magic) >> shift, magic = floor(2^shift / d) + 1, shift = 31 + ceil(log2 d)
 __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigned shift) {
