@@ -1086,17 +1086,17 @@ splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice
         }
       }
       const float v[4] = {a.x, a.y, a.z, a.w};
-      unsigned q[4];
+      const unsigned q2[2] = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      const unsigned q[4] = {q2[0] & 0xffffu, q2[0] >> 16, q2[1] & 0xffffu, q2[1] >> 16};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        q[j] = f2bf(v[j]);
         const float f = (m < M && c + j < C) ? bf2f((unsigned short)q[j]) : 0.f;
         if (4 * gq + j < 256) { red[r][4 * gq + j][0] = f; red[r][4 * gq + j][1] = f * f; }
       }
       if (m < M) {
         const int img = m / HW_out, pix = m - img * HW_out;
         unsigned short* dst = y + img * y_img_stride + (long long)pix * ldy + c;
-        if (c + 3 < C) *reinterpret_cast<u32x2*>(dst) = u32x2{q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+        if (c + 3 < C) *reinterpret_cast<u32x2*>(dst) = u32x2{q2[0], q2[1]};
         else for (int j = 0; j < 4; ++j) if (c + j < C) dst[j] = (unsigned short)q[j];
       }
     }

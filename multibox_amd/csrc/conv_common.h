@@ -14,6 +14,25 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// Two floats to one packed bf16 pair (lo in bits 0..15) in ONE v_cvt_pk_bf16_f32: the same rounding as f2bf, which the
+// compiler emits as one conversion PER VALUE plus a shift and an or (4 instructions a pair instead of 1).
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(pk_f32x2{lo, hi}, pk_bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// max(x, 0) in one v_max_f32 (fmaxf costs a second one: the compiler canonicalises its operand first).  Inline asm is
+// invisible to the compiler's hazard checks: apply it ONLY to the result of a VALU instruction, never straight to an MFMA
+// accumulator (the affine / residual arithmetic always comes first).  The packed conversion above is the vector form of
+// the plain cast for the same reason: it IS the first reader of the accumulators in the store epilogues.
+__device__ __forceinline__ float relu_f(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 struct ConvK {
   const unsigned short* x; int x_img_stride, ldx, H_in, W_in, C_in;
@@ -331,11 +350,16 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
           v[2 * j] = bf2f(w[j] & 0xffffu) + p.rscale * (v[2 * j] + sh[A][2 * j]);
           v[2 * j + 1] = bf2f(w[j] >> 16) + p.rscale * (v[2 * j + 1] + sh[A][2 * j + 1]);
         }
-      } else {
-        if (p.rscale != 0.f) {
+      } else if constexpr (EV == 2) {
+#pragma clang fp contract(off)          // the product is rounded on its own, as it was under the branch (no fma with the add below)
+        const float rs = p.rscale != 0.f ? p.rscale : 1.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= p.rscale;
-        }
+        for (int j = 0; j < 8; ++j) v[j] *= rs;
+      } else {
+        // (x * 1.0f is exact: one multiply for every value instead of a select per value around it)
+        const float rs = p.rscale != 0.f ? p.rscale : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= rs;
       }
       if constexpr (EV == 2) {
         if (do_acc) {
@@ -355,18 +379,17 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
       if constexpr (EV == 3 || EV == 4) {
         if (p.relu) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          for (int j = 0; j < 8; ++j) v[j] = relu_f(v[j]);
         }
       }
-      unsigned q8[8];
+      unsigned q4[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) q8[j] = f2bf(v[j]);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{q8[0] | (q8[1] << 16), q8[2] | (q8[3] << 16), q8[4] | (q8[5] << 16), q8[6] | (q8[7] << 16)},
-                                             yr, (int)yo, 0, 0);
+      for (int j = 0; j < 4; ++j) q4[j] = pack2bf(v[2 * j], v[2 * j + 1]);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{q4[0], q4[1], q4[2], q4[3]}, yr, (int)yo, 0, 0);
       if constexpr (EV == 1) {
         // (out-of-tile lanes hold exact zeros -- zero-filled pixel rows / filter rows -- and add nothing)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = bf2f(q8[j]); s1[A][j] += f; s2[A][j] += f * f; }
+        for (int j = 0; j < 8; ++j) { const float f = (j & 1) ? bf_hi(q4[j >> 1]) : bf_lo(q4[j >> 1]); s1[A][j] += f; s2[A][j] += f * f; }
       }
       if constexpr (EV == 6) {
         // batch-norm backward sums of the STORED gradient: g = relu mask (y > thr; sh holds thr) ? da : 0; sum g, sum g y
@@ -374,7 +397,7 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float yv = bf2f((unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu)));
-          const float g = yv > sh[A][j] ? bf2f(q8[j]) : 0.f;
+          const float g = yv > sh[A][j] ? ((j & 1) ? bf_hi(q4[j >> 1]) : bf_lo(q4[j >> 1])) : 0.f;
           s1[A][j] += g;
           s2[A][j] += g * yv;
         }
@@ -408,10 +431,15 @@ __device__ __forceinline__ void conv_epilogue_channels(const ConvK& p, const int
     for (int A = 0; A < NA; ++A) {
       const int c0 = clane + 32 * A;
       if (c0 < p.C_out) {                                    // C_out % 8 == 0 for bf16 outputs
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (p.scale) sc[A][j] = p.scale[c0 + j];
-          if (p.shiftv) sh[A][j] = p.shiftv[c0 + j];
+        // two 16-byte reads per table (per-element reads compiled to a branch and an address computation each); the
+        // tables are only 4-byte aligned (slices of the parameter buffer), which global memory reads allow
+        if (p.scale) {
+          const f32x4u u0 = *reinterpret_cast<const f32x4u*>(p.scale + c0), u1 = *reinterpret_cast<const f32x4u*>(p.scale + c0 + 4);
+          sc[A][0] = u0.x; sc[A][1] = u0.y; sc[A][2] = u0.z; sc[A][3] = u0.w; sc[A][4] = u1.x; sc[A][5] = u1.y; sc[A][6] = u1.z; sc[A][7] = u1.w;
+        }
+        if (p.shiftv) {
+          const f32x4u u0 = *reinterpret_cast<const f32x4u*>(p.shiftv + c0), u1 = *reinterpret_cast<const f32x4u*>(p.shiftv + c0 + 4);
+          sh[A][0] = u0.x; sh[A][1] = u0.y; sh[A][2] = u0.z; sh[A][3] = u0.w; sh[A][4] = u1.x; sh[A][5] = u1.y; sh[A][6] = u1.z; sh[A][7] = u1.w;
         }
       }
     }

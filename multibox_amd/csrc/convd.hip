@@ -210,11 +210,18 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
           for (int r = 0; r < 4; ++r) { v8[r] = acc[2 * A][b][r]; v8[4 + r] = acc[2 * A + 1][b][r]; }
           if constexpr (EV == 3) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[A][j] + sh8[A][j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
-          }
+            for (int j = 0; j < 8; ++j) v8[j] = v8[j] * sc8[A][j] + sh8[A][j];
+            if (p.relu) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+              for (int j = 0; j < 8; ++j) v8[j] = relu_f(v8[j]);
+            }
+          }
+          unsigned h2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h2[j] = pack2bf(v8[2 * j], v8[2 * j + 1]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h8[j] = (j & 1) ? (h2[j >> 1] >> 16) : (h2[j >> 1] & 0xffffu);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h2[0], h2[1], h2[2], h2[3]},
                                                  yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
             if (ok) {
@@ -232,13 +239,16 @@ conv_direct3_kernel(const ConvK p, const DirK q) {
           const int c0 = a * 16 + 4 * fch;
           const bool ok = pv && c0 < p.C_out;
           unsigned h4[4];
+          float v4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[a][b][r];
-            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = fmaxf(v, 0.f); }
-            h4[r] = f2bf(v);
+            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = relu_f(v); }
+            v4[r] = v;
           }
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)}, yr,
+          const unsigned g2[2] = {pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
+          h4[0] = g2[0] & 0xffffu; h4[1] = g2[0] >> 16; h4[2] = g2[1] & 0xffffu; h4[3] = g2[1] >> 16;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{g2[0], g2[1]}, yr,
                                                 ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
             if (ok) {
@@ -421,11 +431,18 @@ conv_stem_kernel(const ConvK p, const DirK q) {
         for (int r = 0; r < 4; ++r) { v8[r] = acc[0][b][r]; v8[4 + r] = acc[1][b][r]; }
         if constexpr (EV == 3) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[j] + sh8[j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
-        }
+          for (int j = 0; j < 8; ++j) v8[j] = v8[j] * sc8[j] + sh8[j];
+          if (p.relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+            for (int j = 0; j < 8; ++j) v8[j] = relu_f(v8[j]);
+          }
+        }
+        unsigned h2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h2[j] = pack2bf(v8[2 * j], v8[2 * j + 1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h8[j] = (j & 1) ? (h2[j >> 1] >> 16) : (h2[j >> 1] & 0xffffu);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{h2[0], h2[1], h2[2], h2[3]},
                                                yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
         if constexpr (EV == 1) {
           if (ok) {
@@ -660,11 +677,18 @@ __device__ __forceinline__ void directw_body(const ConvK& p, const DirW& q, cons
           for (int r = 0; r < 4; ++r) { v8[r] = acc[2 * A][b][r]; v8[4 + r] = acc[2 * A + 1][b][r]; }
           if constexpr (EV == 3) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v8[j] = v8[j] * sc8[A][j] + sh8[A][j]; if (p.relu) v8[j] = fmaxf(v8[j], 0.f); }
-          }
+            for (int j = 0; j < 8; ++j) v8[j] = v8[j] * sc8[A][j] + sh8[A][j];
+            if (p.relu) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) h8[j] = f2bf(v8[j]);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h8[0] | (h8[1] << 16), h8[2] | (h8[3] << 16), h8[4] | (h8[5] << 16), h8[6] | (h8[7] << 16)},
+              for (int j = 0; j < 8; ++j) v8[j] = relu_f(v8[j]);
+            }
+          }
+          unsigned h2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h2[j] = pack2bf(v8[2 * j], v8[2 * j + 1]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h8[j] = (j & 1) ? (h2[j >> 1] >> 16) : (h2[j >> 1] & 0xffffu);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h2[0], h2[1], h2[2], h2[3]},
                                                  yr, ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
             if (ok) {
@@ -682,13 +706,16 @@ __device__ __forceinline__ void directw_body(const ConvK& p, const DirW& q, cons
           const int c0 = a * 16 + 4 * fch;
           const bool ok = pv && c0 < p.C_out;
           unsigned h4[4];
+          float v4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[a][b][r];
-            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = fmaxf(v, 0.f); }
-            h4[r] = f2bf(v);
+            if constexpr (EV == 3) { v = v * sc4[r] + sh4[r]; if (p.relu) v = relu_f(v); }
+            v4[r] = v;
           }
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)}, yr,
+          const unsigned g2[2] = {pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
+          h4[0] = g2[0] & 0xffffu; h4[1] = g2[0] >> 16; h4[2] = g2[1] & 0xffffu; h4[3] = g2[1] >> 16;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{g2[0], g2[1]}, yr,
                                                 ok ? (int)((pix_off + c0) * 2) : (int)kOOB, 0, 0);
           if constexpr (EV == 1) {
             if (ok) {

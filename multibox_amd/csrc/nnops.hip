@@ -13,14 +13,25 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ unsigned f2bf(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }
+// two floats to a packed bf16 pair in one v_cvt_pk_bf16_f32 (f2bf's rounding; the compiler emits one conversion per value
+// plus a shift and an or), and max(x, 0) in one v_max_f32 (fmaxf canonicalises its operand first)
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(pk_f32x2{lo, hi}, pk_bf16x2));
+}
+__device__ __forceinline__ float relu_f(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
   f[0] = bf2f(v.x & 0xffffu); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffffu); f[3] = bf2f(v.y >> 16);
   f[4] = bf2f(v.z & 0xffffu); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffffu); f[7] = bf2f(v.w >> 16);
 }
 __device__ __forceinline__ u32x4 pack8(const float* f) {
   u32x4 v;
-  v.x = f2bf(f[0]) | (f2bf(f[1]) << 16); v.y = f2bf(f[2]) | (f2bf(f[3]) << 16);
-  v.z = f2bf(f[4]) | (f2bf(f[5]) << 16); v.w = f2bf(f[6]) | (f2bf(f[7]) << 16);
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
   return v;
 }
 __device__ __forceinline__ u32x4 ld8(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -151,7 +162,7 @@ bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = (f[j] - mu[j]) * rs[j] + be[j];
-        f[j] = relu ? fmaxf(v, 0.f) : v;
+        f[j] = relu ? relu_f(v) : v;
       }
       st8(a + m * ld_a + c, pack8(f));
     }
@@ -166,7 +177,7 @@ bn_apply_kernel(const unsigned short* __restrict__ y, long long M, int C, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = (f[j] - mean[c + j]) * rstd[c + j] + beta[c + j];
-      f[j] = relu ? fmaxf(v, 0.f) : v;
+      f[j] = relu ? relu_f(v) : v;
     }
     st8(a + m * ld_a + c + chan_off(map, c), pack8(f));
   }
@@ -387,7 +398,7 @@ bn_apply_fused_kernel(const float* __restrict__ part, int rows, double inv_count
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = (f[j] - s_mean[vc + j]) * s_rstd[vc + j] + s_beta[vc + j];
-      f[j] = relu ? fmaxf(v, 0.f) : v;
+      f[j] = relu ? relu_f(v) : v;
     }
     st8(a + m * ld_a + c0 + vc + chan_off(map, c0 + vc), pack8(f));
   };
@@ -472,7 +483,7 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = (f[j] - mu[j]) * rs[j] + be[j];
-      f[j] = relu ? fmaxf(v, 0.f) : v;
+      f[j] = relu ? relu_f(v) : v;
     }
     st8(a + m * ld_a + c, pack8(f));
     cur = nxt;
@@ -884,7 +895,7 @@ bn_apply_maxpool3s2_kernel(const unsigned short* __restrict__ y, int N, int H, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = (f[j] - mu[j]) * rs[j] + be[j];
-        a = relu ? fmaxf(a, 0.f) : a;
+        a = relu ? relu_f(a) : a;
         a = bf2f(f2bf(a));                              // (the value bn_apply_kernel stores and maxpool_fwd_kernel reads)
         if (a > best[j]) { best[j] = a; arg[j] = tq; }
       }
