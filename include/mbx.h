@@ -215,6 +215,16 @@ typedef struct {
      table (stats_partial then points at the member's first channel).                                              */
   int32_t stats_rows_mod, stats_ld;
   const mbx_bn_bwd_stats* bn_bwd_stats;   /* HOST, may be NULL: see above */
+  /* ReLU SIGN BITS of a residual block output (round 4), or NULL: one bit per element, byte [m * ld_bits + c / 8] bit
+     (c & 7) = (y[m][c] > 0), m = img * H_out * W_out + pixel, c = channel within this launch's C_out; ld_bits bytes per
+     pixel, a multiple of 4 and >= 4 ceil(C_out / 32); the table 4-byte aligned.  MBX_EPI_RESIDUAL with relu: the launch
+     WRITES them beside y, four bytes (32 channels) at a time: bytes [0, 4 ceil(C_out / 32)) of every pixel row, zeros for
+     channels past C_out.  MBX_EPI_STORE: the launch READS them as the relu-backward mask -- y = (acc [* rscale] [+ OLD]) where the
+     bit is set, else 0 -- in place of the `skip` tensor (which must then be NULL): 1/16 of its bytes on a launch that is
+     bound by the three tensors its epilogue streams (model.py:19-23 on the way back; train.py:263).  Same results as
+     the `skip` form (a NaN in the block output counts as positive here, as not positive there).  Not with the
+     stride-2 data gradient, statistics, split-K, the direct launches (96 / 97) or mbx_conv_pair: MBX_ERR_UNSUPPORTED. */
+  void* relu_bits; int32_t ld_bits;
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..39: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64, 128x192, 128x256 tiles; 128x192

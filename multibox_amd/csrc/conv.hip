@@ -1209,7 +1209,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
   if (k.dry == 2) {
     g_capture.k = k; g_capture.bm = BM; g_capture.bn = BN; g_capture.wnw = WNW; g_capture.wmw = WMW; g_capture.nstg = NSTG;
     g_capture.ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
-                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip || k.bits) ? 2 : 0;
     g_capture.mode = k.shift ? 2 : k.pw ? 1 : 0;
     g_capture.valid = 1;
     return MBX_OK;
@@ -1217,7 +1217,7 @@ int launch_igemm(ConvK& k, hipStream_t s) {
   {
     const size_t lds = NSTG * (size_t)(BM + BN) * 128;          // the ring; the epilogue works out of the accumulators
     const int ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
-                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+                   : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip || k.bits) ? 2 : 0;
     static bool attr_set3[7] = {false, false, false, false, false, false, false};
 #define MBX_LAUNCH_EV(EV)                                                                                     \
     case EV:                                                                                                  \
@@ -1365,6 +1365,16 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   k.scale = d->scale; k.shiftv = d->shift;
   k.skip = reinterpret_cast<const unsigned short*>(d->skip);
   k.skip_img_stride = (int)d->skip_img_stride; k.ld_skip = d->ld_skip; k.rscale = d->rscale;
+  k.bits = nullptr; k.bits_ld = 0; k.bits_bytes = 0;
+  if (d->relu_bits) {
+    // sign bits of a residual output: written by RESIDUAL + relu, read as the mask of a plain STORE (see mbx.h)
+    const bool wr = d->epilogue == MBX_EPI_RESIDUAL && d->relu, rd = d->epilogue == MBX_EPI_STORE && !d->skip;
+    if ((!wr && !rd) || d->ld_bits % 4 || d->ld_bits < 4 * ((d->C_out + 31) / 32) || (reinterpret_cast<uintptr_t>(d->relu_bits) & 3)) return MBX_ERR_INVALID_ARG;
+    if (d->stats_partial || d->bn_bwd_stats) return MBX_ERR_UNSUPPORTED;
+    const long long bb = (long long)d->N * d->H_out * d->W_out * d->ld_bits;
+    if (bb >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+    k.bits = reinterpret_cast<unsigned char*>(d->relu_bits); k.bits_ld = d->ld_bits; k.bits_bytes = (unsigned)bb;
+  }
   k.stats = d->stats_partial;
   if (d->stats_rows_mod < 0 || d->stats_rows_mod > 1024 || d->stats_ld < 0 || (d->stats_ld && d->stats_ld < d->C_out)) return MBX_ERR_INVALID_ARG;
   k.stats_mod = d->stats_rows_mod; k.stats_ld = d->stats_ld ? d->stats_ld : d->C_out;
@@ -1432,11 +1442,12 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     }
     k.skip_taps = k.parity = 1;
   }
+  if (k.bits && k.shift) return MBX_ERR_UNSUPPORTED;      // (the sign bits are indexed by the raster pixel index)
   hipStream_t s = mbx_s(stream);
   if (d->tile_config > kSplitFlag) {
     // split-K: forward convolutions with a bf16 store (+ statistics) epilogue only; partials in the caller's workspace
     const int S = d->tile_config - kSplitFlag;
-    if (S < 2 || S > kSplitMax || d->transposed || d->bn_bwd_stats || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->rscale != 0.f)
+    if (S < 2 || S > kSplitMax || d->transposed || d->bn_bwd_stats || d->relu_bits || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->rscale != 0.f)
       return MBX_ERR_UNSUPPORTED;
     const int ldp = ((d->C_out + 7) / 8) * 8;
     int ksplit, kps;

@@ -238,11 +238,16 @@ conv_igemm5_kernel(const ConvK p) {
     // 128x64 / 128x128 / 256x64 residual tiles, half of it for 256x128; the rest is read in the epilogue.)
     constexpr int NA = NI / 2;
     // pixel blocks whose reads are issued ahead: 16 registers' worth (four 16-byte reads per lane)
-    constexpr int PRE_RAW = (EV == 4 || EV == 2 || EV == 6) ? 4 / (NA * (EV == 2 ? 2 : 1)) : 0;
+    // (EV = 7: the accumulate + mask epilogue with the mask read from the relu SIGN BITS, ConvK::bits -- to the shared
+    // epilogue it is EV 2 with the bf16-mask path compiled out; plain EV 2 here has the bits path compiled out: these
+    // kernels have no registers for both.  The 256x128 / 128x256 residual tiles, which also write the bits: one block.)
+    constexpr int EVC = EV == 7 ? 2 : EV, BMODE = EV == 7 ? 2 : EV == 2 ? 0 : 1;
+    constexpr int PRE_RAW = (EV == 4 && G::BM * G::BN >= 256 * 128) ? 1
+                            : (EV == 4 || EVC == 2 || EV == 6) ? 4 / (NA * (EVC == 2 ? 2 : 1)) : 0;
     constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
     u32x4 pla[PREB > 0 ? PREB : 1][NA], plb[PREB > 0 ? PREB : 1][NA];
-    if constexpr (PREB > 0) conv_epilogue_issue_reads<EV, false, NA, PREB>(p, mlane, clane, 0, pla, plb);
+    if constexpr (PREB > 0) conv_epilogue_issue_reads<EVC, false, NA, PREB, BMODE>(p, mlane, clane, 0, pla, plb);
     // id of tile jt + 2: the returning atomic is issued here (BEHIND the reads above: the compiler pairs its result register
     // with an address register of theirs otherwise and waits for it at once) and returns during the K loop
     int raw2 = 0;
@@ -280,15 +285,15 @@ conv_igemm5_kernel(const ConvK p) {
     // ---------------------------------------------------------------- epilogue: straight from the accumulators
     if (fetcher) s_ids[(jt + 2) & 3] = tile_of(raw2);               // visible behind the next tile's K-loop barriers
     float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];
-    conv_epilogue_channels<EV, NA>(p, clane, sc, sh, s1, s2);
+    conv_epilogue_channels<EVC, NA>(p, clane, sc, sh, s1, s2);
     if constexpr (PREB > 0) {
-      conv_epilogue_finish<EV, false, NI, MI, PREB>(p, acc, mlane, clane, 0, pla, plb, sh, sc, s1, s2);
+      conv_epilogue_finish<EVC, false, NI, MI, PREB, BMODE>(p, acc, mlane, clane, 0, pla, plb, sh, sc, s1, s2);
       asm volatile("" ::: "memory");
     }
     if constexpr (PREB < MI) {
       // the rest of the tile: reads issued here, one or two pixel blocks at a time (128 registers per lane in a 16-wave block)
       constexpr int REM = MI - PREB, CH = (EV == 0 || EV == 1 || EV == 3) ? REM : (REM % 2 == 0 ? 2 : 1);
-      conv_epilogue_range<EV, false, NI, MI, PREB, MI, CH>(p, acc, mlane, clane, sh, sc, s1, s2);
+      conv_epilogue_range<EVC, false, NI, MI, PREB, MI, CH, BMODE>(p, acc, mlane, clane, sh, sc, s1, s2);
     }
     MBX5_STAMP(2);                                                  // rows written
     if constexpr (EV == 1 || EV == 6) {
@@ -333,16 +338,16 @@ int launch5(ConvK& k, hipStream_t s) {
   }
   int grid = ntiles < ncu ? ntiles : ncu;                           // one persistent block per CU
   if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;             // ... or fewer: CUs left to a kernel on another stream
-  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.bw_n ? 6 : k.stats ? 1 : (k.accumulate || k.skip) ? 2 : 0;
+  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : k.bw_n ? 6 : k.stats ? 1 : k.bits ? 7 : (k.accumulate || k.skip) ? 2 : 0;
   // the BN-backward statistics epilogue (EV = 6) on the 256 x 128 tile: 64 accumulator + 48 sum / threshold registers + the
   // reads in flight do not fit the 128-register budget of a 16-wave block (33 spilled): not built, the caller takes 192 x 128
   constexpr bool kNo6 = (MY == 4 && NW == 2) || NW >= 3;
   // (128 x 192: 96 channels per wave -- the accumulate + mask epilogue's reads in flight spill as well: store / statistics /
   // affine / residual only)
   constexpr bool kNo2 = NW == 3;
-  if ((ev == 6 && kNo6) || (ev == 2 && kNo2)) return MBX_ERR_UNSUPPORTED;
+  if ((ev == 6 && kNo6) || ((ev == 2 || ev == 7) && kNo2)) return MBX_ERR_UNSUPPORTED;
   if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
-  static bool attr[7][2] = {};
+  static bool attr[8][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \
   do {                                                                                                        \
     if (!attr[EV][MODE]) {                                                                                    \
@@ -360,6 +365,9 @@ int launch5(ConvK& k, hipStream_t s) {
       break;
     case 6:
       if constexpr (!kNo6) { if (k.pw) MBX5_LAUNCH(6, 1); else MBX5_LAUNCH(6, 0); }
+      break;
+    case 7:
+      if constexpr (!kNo2) { if (k.pw) MBX5_LAUNCH(7, 1); else MBX5_LAUNCH(7, 0); }
       break;
   }
 #undef MBX5_EV

@@ -225,7 +225,7 @@ int mbx_launch_igemm7(void* convk, hipStream_t s) {
   if (grid < k.tiles_n) grid = k.tiles_n;
   if (k.tiles_n > 32) return MBX_ERR_UNSUPPORTED;                   // (one work counter per column tile, 32 per launch)
   const int lds = nk * k7PanelTile * 16 + k7NST * k7Stage * 16 + 32;
-  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : (k.accumulate || k.skip) ? 2 : 0;
+  const int ev = k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3 : (k.accumulate || k.skip || k.bits) ? 2 : 0;
   if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
   static bool attr[5] = {};
 #define MBX7_LAUNCH(EV)                                                                                       \

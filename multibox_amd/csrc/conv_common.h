@@ -24,6 +24,15 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// Lanes l, l + 16, l + 32, l + 48 (the four rows of a wave) each hold one byte (bits 0..7 of b, the rest zero): all four
+// get the dword [row 0 | row 1 << 8 | row 2 << 16 | row 3 << 24].  EXEC must be all ones.
+__device__ __forceinline__ unsigned gather4_rows(unsigned b) {
+  typedef unsigned g4_u32x2 __attribute__((ext_vector_type(2)));
+  const g4_u32x2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);     // (even row, odd row) of the lane's row pair
+  const unsigned t = r.x | (r.y << 8);
+  const g4_u32x2 q = __builtin_amdgcn_permlane32_swap(t, t, false, false);     // (lower half, upper half)
+  return q.x | (q.y << 16);
+}
 // max(x, 0) in one v_max_f32 (fmaxf costs a second one: the compiler canonicalises its operand first).  Inline asm is
 // invisible to the compiler's hazard checks: apply it ONLY to the result of a VALU instruction, never straight to an MFMA
 // accumulator (the affine / residual arithmetic always comes first).  The packed conversion above is the vector form of
@@ -45,6 +54,10 @@ struct ConvK {
   const float* scale; const float* shiftv;
   const unsigned short* skip; int skip_img_stride, ld_skip; float rscale;
   const unsigned short* acc_src; int acc_img_stride, ld_acc;      // accumulate: OLD value read from here (may alias y)
+  // ReLU sign bits, one per output element: byte [m * bits_ld + c / 8] bit (c & 7) = (stored y[m][c] > 0).  WRITTEN by the
+  // residual epilogue (EV = 4, relu); READ by the accumulate epilogue (EV = 2) as the relu-backward mask in place of the
+  // 16-times larger bf16 tensor (skip is NULL then).  m = raster pixel index (never the parity walk: host check).
+  unsigned char* bits; int bits_ld; unsigned bits_bytes;
   float* stats;
   int stats_mod, stats_ld;               // stats_mod = R > 0: tile sums ADDED atomically into row (tile % R) of [R][stats_ld][2] (zero at launch); 0: a plain row per tile
   // EV = 6 (data gradients): BATCH-NORM BACKWARD statistics of the layers whose activation gradient this launch writes.
@@ -274,7 +287,9 @@ __device__ __forceinline__ void epi_pixel(const ConvK& p, const int m, int& img,
 }
 
 // Phase 1 for pixel blocks [b0, b0 + BCH): issue every 16-byte read of the epilogue (nothing waits here).
-template <int EV, bool SH, int NA, int BCH>
+// BMODE: the relu sign bits (ConvK::bits) -- 1: used when the pointer is set (one uniform branch), 0: compiled out,
+// 2: EV = 2 masks by them unconditionally and the bf16 mask path is compiled out (igemm5's registers do not hold both).
+template <int EV, bool SH, int NA, int BCH, int BMODE = 1>
 __device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const int mlane, const int clane, const int b0,
                                                           u32x4 (&la)[BCH][NA], u32x4 (&lb)[BCH][NA]) {
   if constexpr (EV == 6) {
@@ -296,7 +311,9 @@ __device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const 
   if constexpr (EV == 2 || EV == 4) {
     const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
     const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.acc_src, p.acc_bytes);
-    const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+    const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && BMODE != 2 && p.skip != nullptr;     // (uniform)
+    const bool do_bits = EV == 2 && (BMODE == 2 || (BMODE == 1 && p.bits != nullptr));        // (uniform; never with do_mask)
+    const __amdgpu_buffer_rsrc_t br = make_rsrc(p.bits, p.bits ? p.bits_bytes : 0u);
 #pragma unroll
     for (int bb = 0; bb < BCH; ++bb) {
       const int m = mlane + (b0 + bb) * 16;
@@ -313,6 +330,8 @@ __device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const 
           const unsigned ao = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
           if (do_acc) la[bb][A] = buf_load16(ar, ao);
           if (do_mask) lb[bb][A] = buf_load16(kr_, so);
+          // one byte = the lane's eight mask bits (out-of-range lanes read 0: their values are dropped anyway)
+          if (do_bits) lb[bb][A].x = __builtin_amdgcn_raw_buffer_load_b8(br, ok ? m * p.bits_ld + (c0 >> 3) : (int)kOOB, 0, 0);
         }
       }
     }
@@ -320,20 +339,24 @@ __device__ __forceinline__ void conv_epilogue_issue_reads(const ConvK& p, const 
 }
 
 // Phase 2 for pixel blocks [b0, b0 + BCH): arithmetic and the 16-byte stores (fire and forget).
-template <int EV, bool SH, int NI, int MI, int BCH>
+template <int EV, bool SH, int NI, int MI, int BCH, int BMODE = 1>
 __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
                                                      const int b0, const u32x4 (&la)[BCH][NI / 2], const u32x4 (&lb)[BCH][NI / 2],
                                                      const float (&sh)[NI / 2][8], const float (&sc)[NI / 2][8],
                                                      float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
   constexpr int NA = NI / 2;
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
-  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && BMODE != 2 && p.skip != nullptr;     // (uniform)
+  const bool do_bits = (EV == 2 && BMODE == 2) || ((EV == 2 || EV == 4) && BMODE == 1 && p.bits != nullptr);   // (uniform)
+  const __amdgpu_buffer_rsrc_t br = make_rsrc(p.bits, p.bits ? p.bits_bytes : 0u);
+  const int fch_ = (threadIdx.x >> 4) & 3;              // the lane's channel octet within a 32-channel block (clane = ... + 8 fch)
 #pragma unroll
   for (int bb = 0; bb < BCH; ++bb) {
     const int b = b0 + bb;
     const int m = mlane + b * 16;
     int img, pix;
     epi_pixel<SH>(p, m, img, pix);
+    unsigned bits_dw = 0;
 #pragma unroll
     for (int A = 0; A < NA; ++A) {
       const int c0 = clane + 32 * A;
@@ -385,7 +408,37 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
       unsigned q4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) q4[j] = pack2bf(v[2 * j], v[2 * j + 1]);
+      if constexpr (EV == 2) {
+        if (do_bits) {                      // relu backward from the sign bits: bit 2j / 2j + 1 -> the halves of pair j
+          const int byte = (int)lb[bb][A].x;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            q4[j] &= ((unsigned)__builtin_amdgcn_sbfe(byte, 2 * j, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(byte, 2 * j + 1, 1) << 16);
+        }
+      }
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{q4[0], q4[1], q4[2], q4[3]}, yr, (int)yo, 0, 0);
+      if constexpr (EV == 4) {
+        if (do_bits) {                      // (relu: the stored halves are >= 0 or -0; > 0 <=> non-zero below the sign bit)
+          // min(half, 1) of both halves of a pair in one packed instruction: bits 0 / 16 of t[j]; the four pairs side by side
+          // (bits 0, 2, 4, 6 and 16, 18, 20, 22), then the upper halves folded down beside the lower ones
+          // (inline asm -- on values the VALU has just produced: the compiler turns the vector min into a compare and a select
+          // per half)
+          unsigned sidx = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned h;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(h) : "v"(q4[j] & 0x7fff7fffu), "s"(0x00010001u));
+            sidx |= h << (2 * j);
+          }
+          const unsigned byte = (sidx | (sidx >> 15)) & 0xffu;
+          // the four lanes of a pixel (lane, +16, +32, +48: fch 0..3) hold four CONSECUTIVE bytes of its row: gathered into
+          // one dword in all of them (two row swaps, no LDS), and the lane with fch == A keeps the dword of channel block A
+          // -- ONE 4-byte store per pixel block and 32 channels below, instead of a byte store per lane (64 single bytes
+          // per instruction cost the residual launches of block17 3.9 us each, more than the data gradients gained)
+          const unsigned dw = gather4_rows(byte);
+          if (A == 0 || fch_ == A) bits_dw = dw;
+        }
+      }
       if constexpr (EV == 1) {
         // (out-of-tile lanes hold exact zeros -- zero-filled pixel rows / filter rows -- and add nothing)
 #pragma unroll
@@ -401,6 +454,13 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvK& p, const f32x4
           s1[A][j] += g;
           s2[A][j] += g * yv;
         }
+      }
+    }
+    if constexpr (EV == 4) {
+      if (do_bits) {
+        // lane (pixel, fch) stores the dword of channel block A = fch: channels [32 fch, 32 fch + 32) from the wave's first
+        const int cw = clane - 8 * fch_ + 32 * fch_;
+        __builtin_amdgcn_raw_buffer_store_b32(bits_dw, br, (fch_ < NA && m < p.M && cw < p.C_out) ? m * p.bits_ld + (cw >> 3) : (int)kOOB, 0, 0);
       }
     }
   }
@@ -449,7 +509,7 @@ __device__ __forceinline__ void conv_epilogue_channels(const ConvK& p, const int
 // Pixel blocks [B0, B1) in chunks of BCH: reads of a chunk issued back to back, then its arithmetic and stores.  The
 // empty asm keeps the compiler from hoisting the NEXT chunk's reads above this chunk (BCH bounds the registers the
 // reads in flight take: hoisted all together they spilled).
-template <int EV, bool SH, int NI, int MI, int B0, int B1, int BCH>
+template <int EV, bool SH, int NI, int MI, int B0, int B1, int BCH, int BMODE = 1>
 __device__ __forceinline__ void conv_epilogue_range(const ConvK& p, const f32x4 (&acc)[NI][MI], const int mlane, const int clane,
                                                     const float (&sh)[NI / 2][8], const float (&sc)[NI / 2][8],
                                                     float (&s1)[NI / 2][8], float (&s2)[NI / 2][8]) {
@@ -458,8 +518,8 @@ __device__ __forceinline__ void conv_epilogue_range(const ConvK& p, const f32x4 
 #pragma unroll
   for (int b0 = B0; b0 < B1; b0 += BCH) {
     u32x4 la[BCH][NA], lb[BCH][NA];
-    conv_epilogue_issue_reads<EV, SH, NA, BCH>(p, mlane, clane, b0, la, lb);
-    conv_epilogue_finish<EV, SH, NI, MI, BCH>(p, acc, mlane, clane, b0, la, lb, sh, sc, s1, s2);
+    conv_epilogue_issue_reads<EV, SH, NA, BCH, BMODE>(p, mlane, clane, b0, la, lb);
+    conv_epilogue_finish<EV, SH, NI, MI, BCH, BMODE>(p, acc, mlane, clane, b0, la, lb, sh, sc, s1, s2);
     if (b0 + BCH < B1) asm volatile("" ::: "memory");
   }
 }

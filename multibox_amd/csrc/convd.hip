@@ -856,7 +856,7 @@ int mbx_directw_grid(int N, int H_out, int W_out) {
 // gradient, C_in 32 / 48 / 64, C_out <= 64 (a multiple of 8), maps 8..64 wide; bf16 store with or without statistics, or affine.
 int mbx_launch_directw(void* convk, int N, int H_out, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
-  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip ||
+  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.bits ||
       k.rscale != 0.f || k.bw_n || (k.epi == MBX_EPI_AFFINE && k.stats))
     return MBX_ERR_UNSUPPORTED;
   if ((k.C_in != 32 && k.C_in != 48 && k.C_in != 64) || k.C_out > 64 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2)
@@ -885,7 +885,7 @@ int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
   if (k.mul == 2 && !k.shift && k.C_in == 8) {
     // the network's first layer (forward only: stride 2, packed RGB input): conv_stem_kernel
-    if (k.R != 3 || k.S != 3 || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.rscale != 0.f || k.bw_n ||
+    if (k.R != 3 || k.S != 3 || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.bits || k.rscale != 0.f || k.bw_n ||
         (k.epi == MBX_EPI_AFFINE && k.stats) || k.C_out > 32 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2 ||
         k.Ktot != 72)
       return MBX_ERR_UNSUPPORTED;
@@ -899,7 +899,7 @@ int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
     if (k.dry) return MBX_OK;
     return launch_stem(k, q, mbx_direct3_grid(N, H_out, k.W_out), s);
   }
-  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip ||
+  if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.bits ||
       k.rscale != 0.f || k.bw_n || (k.epi == MBX_EPI_AFFINE && k.stats))
     return MBX_ERR_UNSUPPORTED;
   if ((k.C_in != 32 && k.C_in != 64) || k.C_out > 64 || k.C_out % 8 || k.pad_t < 0 || k.pad_t > 2 || k.pad_l < 0 || k.pad_l > 2 ||

@@ -126,6 +126,11 @@ class Net:
         # (threshold loads, sums, cross-wave reduce, the atomics' acknowledgement -- all on the tail of a launch that has one
         # tile per CU) and 17 us where the 256 x 128 tile has no room for it: 15.98 -> 16.5 ms per step.
         self.bw_stats = self.atomic_stats and os.environ.get("MBX_BW_STATS", "0") == "1"
+        # relu backward of the residual block outputs from SIGN BITS (mbx_conv_desc.relu_bits): the residual launch writes one
+        # bit per element beside its bf16 output, the data gradient that applies the mask reads that byte per eight channels
+        # instead of 16 bytes of the tensor -- its epilogue streams two tensors and a sixteenth instead of three.
+        # MBX_RELU_BITS=0: the bf16 tensor as the mask (rounds 2-3).
+        self.relu_bits = mode == "train" and os.environ.get("MBX_RELU_BITS", "1") != "0"
         # every conv launch times the library's tile pick against the other tile configurations once, at build time
         self.autotune = torch.device(device).type == "cuda" and bool(int(os.environ.get("MBX_AUTOTUNE", "1")))
         # grid cap of the one-launch BN backward: data-parallel runs leave CUs to the RCCL kernels of the bucket in flight
@@ -728,7 +733,7 @@ class Net:
     def _tune(self, op, d, what):
         """Pick the tile configuration of one conv launch by measurement (ops.autotune); a no-op on CPU."""
         key = (what, op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, d.C_out, d.C_in,
-               d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip), d.relu)
+               d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip) or (bool(d.relu_bits) and d.epilogue == ops.EPI_STORE), d.relu)
         self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
             ops.autotune(d, key)
@@ -894,7 +899,8 @@ class Net:
                 L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
             elif op.kind == "residual":
                 d = self._tune(op, self._desc(op, op.out, epilogue=ops.EPI_RESIDUAL, relu=op.relu,
-                                              shift=self._sl(self.W, op.b_off, op.K), skip=op.skip, rscale=op.rscale), "fwd")
+                                              shift=self._sl(self.W, op.b_off, op.K), skip=op.skip, rscale=op.rscale,
+                                              relu_bits=getattr(op, "relu_bits", None)), "fwd")
                 L.append(lambda d=d, op=op: _lib.check(l.mbx_conv(C.byref(d), st()), op.name))
             elif op.kind == "head":
                 d = self._desc(op, op.out, epilogue=ops.EPI_STORE_F32)
@@ -1117,6 +1123,16 @@ class Net:
                                       op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
                                       rscale=(scale if scale != 1.0 else 0.0), skip=(mr.out if mr is not None else None),
                                       acc_src=acc_src)
+                if mr is not None and self.relu_bits and op.Cin % 8 == 0:
+                    # the relu-backward mask from the SIGN BITS the residual launch writes beside its output (1/16 of the
+                    # bytes of the bf16 tensor, on a launch that is bound by the tensors its epilogue streams); where the
+                    # library has no such launch (the stride-2 data gradients of Mixed_6a / 7a) the bf16 form stays
+                    bits = torch.zeros((op.x.N * op.x.H * op.x.W, (op.Cin + 31) // 32 * 4), dtype=torch.uint8, device=self.dev)
+                    alt = ops.make_desc(dyin, self.Wd[op.dgrad_off:], op.Cin, op.R, op.S, op.stride,
+                                        op.R - 1 - op.pad_t, op.S - 1 - op.pad_l, gx, transposed=1, accumulate=acc,
+                                        rscale=(scale if scale != 1.0 else 0.0), acc_src=acc_src, relu_bits=bits)
+                    if torch.device(self.dev).type != "cuda" or l.mbx_conv_supported(C.byref(alt)) == 0:
+                        ddesc, mr.relu_bits = alt, bits
                 self._tune(op, ddesc, "dgrad")
                 if op.bw_segments is not None:
                     # this data gradient writes the activation gradient of batch-norm layers on the streaming backward: its

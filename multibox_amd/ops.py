@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("stats_rows_mod", C.c_int32), ("stats_ld", C.c_int32),
         ("bn_bwd_stats", C.c_void_p),
+        ("relu_bits", C.c_void_p), ("ld_bits", C.c_int32),
     ]
 
 
@@ -102,7 +103,7 @@ def _p(t):
 
 def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed=0, epilogue=EPI_STORE, relu=0,
               accumulate=0, scale=None, shift=None, skip: View = None, rscale=0.0, stats=None, acc_src: View = None,
-              stats_rows_mod=0, stats_ld=0):
+              stats_rows_mod=0, stats_ld=0, relu_bits=None, ld_bits=0):
     d = ConvDesc()
     d.x, d.x_img_stride, d.ldx = x.ptr, x.img_stride, x.ld
     d.N, d.H_in, d.W_in, d.C_in = x.N, x.H, x.W, x.C
@@ -119,6 +120,9 @@ def make_desc(x: View, w, C_out, R, S, stride, pad_t, pad_l, y: View, transposed
     d.stats_rows_mod, d.stats_ld = int(stats_rows_mod), int(stats_ld)
     if acc_src is not None:
         d.acc_src, d.acc_img_stride, d.ld_acc = acc_src.ptr, acc_src.img_stride, acc_src.ld
+    if relu_bits is not None:
+        # sign bits of a residual output (uint8 tensor [M, ld_bits]): written by RESIDUAL + relu, read as the mask of a STORE
+        d.relu_bits, d.ld_bits = relu_bits.data_ptr(), int(ld_bits if ld_bits else relu_bits.shape[-1])
     return d
 
 

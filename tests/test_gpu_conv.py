@@ -697,6 +697,106 @@ def test_igemm5_epilogues_bit_identical(T, g):
                     assert torch.equal(st1, st2), "%s stats cfg %d capped queued=%s" % (name, cfg, ctr_on)
 
 
+@pytest.mark.parametrize("g", [("b1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("b2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
+                               ("b3", 5, 8, 8, 448, 2080, 1, 1, 1, (0, 0, 0, 0)), ("b4", 2, 17, 17, 96, 72, 3, 3, 1, (1, 1, 1, 1))],
+                         ids=["block17_up", "block35_up", "block8_up", "3x3_cout72"])
+def test_conv_relu_sign_bits(T, g):
+    """mbx_conv_desc.relu_bits (round 4).  WRITE: the residual + relu launch stores, beside y, one bit per element = (y > 0),
+    eight channels to a byte, 32 channels to a 4-byte store, in a [M, ld_bits] table wider than 4 ceil(C_out / 32) (zeros for
+    the channels past C_out, bytes outside untouched) -- y itself is bit-identical to the launch without the table.  READ: the accumulate (+ scale) launch masked by those bits equals,
+    bit for bit, the same launch masked by the bf16 tensor (`skip`).  Every tile family: the library's pick and the other
+    igemm3 tiles, the persistent igemm5 tiles (EV 7), the panel-resident launch where it applies.  Refusals: with
+    statistics, with a `skip` mask as well, on the stride-2 data gradient, on the direct and split-K launches."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=31)
+    gen = torch.Generator().manual_seed(32)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    M = N * Ho * Wo
+    xb = ops.View.alloc(N, H, W, Ci + 8).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    sh = torch.randn(Co, generator=gen).cuda()
+    skip = ops.View.alloc(N, Ho, Wo, Co + 8).slice(8, Co)
+    skip.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+    old = ops.View.alloc(N, Ho, Wo, Co)
+    old.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+    stream = torch.cuda.current_stream().cuda_stream
+    wb = (Co + 31) // 32 * 4                    # bytes per pixel row the launch writes
+    ldb = wb + 4
+    cfgs = [0] + list(range(1, ops.N_TILE_CONFIGS + 1)) + list(ops.I5_TILE_CONFIGS) + [ops.I7_TILE_CONFIG]
+    # the block output with exact zeros, negative zeros and tiny values in it: relu(skip + 0.17 (conv + shift))
+    y_ref = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y_ref, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17))
+    torch.cuda.synchronize()
+    pos = (y_ref.tensor().float() > 0).reshape(M, Co // 8, 8).to(torch.uint8)
+    want = torch.zeros((M, wb), dtype=torch.uint8, device="cuda")
+    want[:, :Co // 8] = (pos << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    assert 0.2 < float(pos.float().mean()) < 0.8
+    ran_w = ran_r = 0
+    for cfg in cfgs:
+        # ---- write
+        bits = torch.full((M, ldb), 0xA5, dtype=torch.uint8, device="cuda")
+        y1 = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y1, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17,
+                          relu_bits=bits)
+        d.tile_config = cfg
+        if l.mbx_conv_supported(C.byref(d)) == 0:
+            assert l.mbx_conv(C.byref(d), stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y1.tensor(), y_ref.tensor()), "%s write cfg %d: y" % (name, cfg)
+            assert torch.equal(bits[:, :wb], want), "%s write cfg %d: bits" % (name, cfg)
+            assert bool((bits[:, wb:] == 0xA5).all()), "%s write cfg %d: bytes outside" % (name, cfg)
+            ran_w += 1
+        else:
+            d.relu_bits = None
+            assert l.mbx_conv_supported(C.byref(d)) != 0, "cfg %d refuses the table only" % cfg    # (the tile does not apply at all)
+        # ---- read: y = (old + 0.2 conv) masked
+        bits = torch.zeros((M, ldb), dtype=torch.uint8, device="cuda")
+        bits[:, :wb] = want
+        outs = []
+        for form in ("skip", "bits"):
+            y2 = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+            if form == "skip":
+                d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y2, accumulate=1, skip=y_ref, acc_src=old, rscale=0.2)
+            else:
+                d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y2, accumulate=1, acc_src=old, rscale=0.2, relu_bits=bits)
+            d.tile_config = cfg if form == "bits" else 0
+            if l.mbx_conv_supported(C.byref(d)) != 0:
+                outs = None
+                break
+            assert l.mbx_conv(C.byref(d), stream) == 0
+            torch.cuda.synchronize()
+            outs.append(y2.tensor().clone())
+        if outs is not None:
+            assert torch.equal(outs[0], outs[1]), "%s read cfg %d" % (name, cfg)
+            ran_r += 1
+    assert ran_w >= 8 and ran_r >= 8, (ran_w, ran_r)
+    # the mask without an accumulate source, unscaled
+    y3, y4 = ops.View.alloc(N, Ho, Wo, Co, zero=True), ops.View.alloc(N, Ho, Wo, Co, zero=True)
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, skip=y_ref))
+    ops.conv(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y4, relu_bits=bits))
+    torch.cuda.synchronize()
+    assert torch.equal(y3.tensor(), y4.tensor())
+    # refusals
+    stats = torch.zeros((4096, Co, 2), device="cuda")
+    assert l.mbx_conv_supported(C.byref(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, stats=stats, relu_bits=bits))) != 0
+    assert l.mbx_conv_supported(C.byref(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, skip=y_ref, relu_bits=bits))) != 0
+    assert l.mbx_conv_supported(C.byref(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, epilogue=ops.EPI_RESIDUAL, relu=0, shift=sh,
+                                                      skip=skip, rscale=0.17, relu_bits=bits))) != 0
+    assert l.mbx_conv_supported(C.byref(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, epilogue=ops.EPI_AFFINE, relu=1, scale=sh,
+                                                      shift=sh, relu_bits=bits))) != 0
+    small = torch.zeros((M, wb - 4), dtype=torch.uint8, device="cuda")
+    assert l.mbx_conv_supported(C.byref(ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, relu_bits=small))) != 0
+    for bad in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.SPLITK_FLAG + 4):
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], y3, relu_bits=bits)
+        d.tile_config = bad
+        assert l.mbx_conv_supported(C.byref(d)) != 0, bad
+
+
 @pytest.mark.parametrize("g", [("p1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("p2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
                                ("p3", 16, 17, 17, 320, 1088, 1, 1, 1, (0, 0, 0, 0)), ("p4", 5, 35, 35, 96, 320, 1, 1, 1, (0, 0, 0, 0)),
                                ("p5", 64, 8, 8, 384, 2080, 1, 1, 1, (0, 0, 0, 0))], ids=["k384", "k128", "k320_many_tiles", "k96", "k384_n2080"])

@@ -399,6 +399,54 @@ def test_overfits_one_batch(env):
     assert last[0] < first[0] / 8.0 and last[1] < first[1] / 4.0, (first, last)      # both terms of loss.py:100-101
 
 
+def test_relu_sign_bits_same_gradients():
+    """The relu backward of the residual block outputs from SIGN BITS (mbx_conv_desc.relu_bits, the default) against the bf16
+    tensor as the mask (MBX_RELU_BITS=0): the same network, batch and head gradients under MBX_DETERMINISTIC=1 -- every
+    head output and the whole parameter gradient bit for bit.  The default really uses the bits: at least 36 of the 39
+    relu'd residual blocks write them (block35_10's output is first consumed by a stride-2 convolution, whose data
+    gradient keeps the tensor form)."""
+    import os
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd.engine import Net
+    B = 2
+    grads, n_bits = [], []
+    gen = torch.Generator().manual_seed(17)
+    images = (torch.rand(B, 299, 299, 3, generator=gen) * 2 - 1).cuda()
+    d_locs = d_logits = betas = None
+    for flag in ("1", "0"):
+        old = {k_: os.environ.get(k_) for k_ in ("MBX_DETERMINISTIC", "MBX_RELU_BITS")}
+        os.environ["MBX_DETERMINISTIC"], os.environ["MBX_RELU_BITS"] = "1", flag
+        try:
+            net = Net(batch=B, input_size=299, k=5, mode="train", seed=9)
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+        assert net.relu_bits == (flag == "1")
+        n_bits.append(sum(1 for op in net.convs if getattr(op, "relu_bits", None) is not None))
+        if betas is None:
+            betas = (torch.randn(net.nBt, generator=gen) * 0.1).cuda()
+            d_locs = torch.randn(net.d_locs.shape, generator=gen).cuda() * 1e-2
+            d_logits = torch.randn(net.d_logits.shape, generator=gen).cuda() * 1e-2
+        net.Bt.copy_(betas)
+        net.set_input(images)
+        net.forward()
+        net.d_locs.copy_(d_locs); net.d_logits.copy_(d_logits)
+        net.zero_grads()
+        net.backward()
+        torch.cuda.synchronize()
+        grads.append((net.G.clone(), net.locs.clone(), net.logits.clone()))
+        del net
+    assert n_bits[0] >= 36 and n_bits[1] == 0, n_bits
+    assert torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
+    assert bool(torch.isfinite(grads[0][0]).all()) and float(grads[0][0].abs().max()) > 0
+    assert torch.equal(grads[0][0], grads[1][0]), float((grads[0][0] - grads[1][0]).abs().max())
+
+
 def test_full_depth_backward_teacher_forced():
     """ONE tight end-to-end check of the assembled full-depth (10 / 20 / 9) backward pass in the REAL
     training mode (batch-statistics BN) -- all 409 convolution launches, the BN backward of every layer, the out-of-place
