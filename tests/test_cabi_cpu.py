@@ -89,6 +89,38 @@ def test_conv_stats_rows_follow_the_tile(lib):
     assert l.mbx_conv_stats_rows(C.byref(d)) < 0
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of the C-ABI structs (ops.ConvDesc, ops.WgradJob, _lib.BnBwdStats) against include/mbx.h as a C
+    compiler lays it out: size and the offset of every field of mbx_conv_desc (gcc on a ten-line program; no GPU).  A field
+    added to the header and not to the mirror (or the other way round) shifts everything behind it -- mbx_wgrad_job embeds
+    the descriptor, so the library would read the job array with the wrong stride."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from multibox_amd import ops, _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in ops.ConvDesc._fields_]
+    hdr = {"shift": "shift", "stats_partial": "stats_partial"}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mbx.h"', 'int main(void) {',
+           '  printf("sizeof_desc %zu\\n", sizeof(mbx_conv_desc));', '  printf("sizeof_job %zu\\n", sizeof(mbx_wgrad_job));',
+           '  printf("sizeof_bw %zu\\n", sizeof(mbx_bn_bwd_stats));']
+    for f in fields:
+        src.append('  printf("%s %%zu\\n", offsetof(mbx_conv_desc, %s));' % (f, hdr.get(f, f)))
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", exe], check=True)
+    out = dict(line.split() for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof_desc"]) == C.sizeof(ops.ConvDesc)
+    assert int(out["sizeof_job"]) == C.sizeof(ops.WgradJob)
+    assert int(out["sizeof_bw"]) == C.sizeof(_lib.BnBwdStats)
+    for f in fields:
+        assert int(out[f]) == getattr(ops.ConvDesc, f).offset, f
+
+
 def test_no_kernel_uses_scratch_memory(tmp_path):
     """Every kernel of libmbx must fit its registers: a launch that needs scratch (private segment) makes the queue set
     scratch up, which showed as a ~0.1 ms stall per training step while the 192x192 weight-gradient tile spilled five
