@@ -734,6 +734,8 @@ class Net:
         """Pick the tile configuration of one conv launch by measurement (ops.autotune); a no-op on CPU."""
         key = (what, op.x.N, op.x.H, op.x.W, op.x.C, op.K, op.R, op.S, op.stride, op.pad_t, op.pad_l, d.C_out, d.C_in,
                d.epilogue, bool(d.stats_partial), d.accumulate, bool(d.skip) or (bool(d.relu_bits) and d.epilogue == ops.EPI_STORE), d.relu)
+        if d.relu_bits and d.epilogue == ops.EPI_RESIDUAL:
+            key = key + ("bits",)      # the training forward of a residual block also writes the sign bits: its own table entry
         self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
             ops.autotune(d, key)
