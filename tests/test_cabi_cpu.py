@@ -89,6 +89,51 @@ def test_conv_stats_rows_follow_the_tile(lib):
     assert l.mbx_conv_stats_rows(C.byref(d)) < 0
 
 
+def test_relu_bits_descriptor_rules(lib):
+    """mbx_conv_desc.relu_bits through mbx_conv_supported (every check of mbx_conv, no launch, no GPU): written by
+    RESIDUAL + relu, read by a plain STORE in place of `skip`; ld_bits a multiple of 4 and >= 4 ceil(C_out / 32), the table
+    4-byte aligned; never with statistics, a `skip` mask, the stride-2 data gradient, the direct or split-K launches; the
+    persistent tiles take the bits form except 128x192 (no accumulate + mask instantiation at all)."""
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+
+    def desc(epilogue, **kw):
+        d = ops.ConvDesc()
+        d.x, d.x_img_stride, d.ldx = 0x10000, 17 * 17 * 384, 384
+        d.N, d.H_in, d.W_in, d.C_in = 4, 17, 17, 384
+        d.w, d.C_out, d.R, d.S = 0x20000, 1088, 1, 1
+        d.stride, d.H_out, d.W_out = 1, 17, 17
+        d.y, d.y_img_stride, d.ldy = 0x30000, 17 * 17 * 1088, 1088
+        d.epilogue = epilogue
+        d.relu_bits, d.ld_bits = 0x50000, 136
+        for k_, v in kw.items():
+            setattr(d, k_, v)
+        return d
+    skip = dict(skip=0x40000, skip_img_stride=17 * 17 * 1088, ld_skip=1088)
+    ok = lambda d: l.mbx_conv_supported(C.byref(d))
+    assert ok(desc(ops.EPI_RESIDUAL, relu=1, rscale=0.1, **skip)) == 0                     # write
+    assert ok(desc(ops.EPI_STORE, accumulate=1)) == 0 and ok(desc(ops.EPI_STORE)) == 0   # read
+    assert ok(desc(ops.EPI_RESIDUAL, relu=0, rscale=0.1, **skip)) == -1                    # no relu: nothing to record
+    assert ok(desc(ops.EPI_STORE, **skip)) == -1                                           # two masks
+    assert ok(desc(ops.EPI_AFFINE, relu=1)) == -1
+    assert ok(desc(ops.EPI_STORE, ld_bits=135)) == -1 and ok(desc(ops.EPI_STORE, ld_bits=132)) == -1
+    assert ok(desc(ops.EPI_STORE, ld_bits=140)) == 0
+    assert ok(desc(ops.EPI_STORE, relu_bits=0x50002)) == -1
+    assert ok(desc(ops.EPI_STORE, stats_partial=0x60000)) != 0
+    # stride-2 data gradient (3x3, transposed): the bits are indexed by the raster pixel index
+    d = desc(ops.EPI_STORE, R=3, S=3, stride=2, transposed=1, H_in=8, W_in=8, x_img_stride=8 * 8 * 384, pad_t=2, pad_l=2)
+    assert ok(d) == -2
+    d.relu_bits = None
+    assert ok(d) == 0
+    for cfg in ops.I5_TILE_CONFIGS:
+        want = -2 if cfg == 38 else 0
+        assert ok(desc(ops.EPI_STORE, accumulate=1, tile_config=cfg)) == want, cfg
+        assert ok(desc(ops.EPI_RESIDUAL, relu=1, rscale=0.1, tile_config=cfg, **skip)) == 0, cfg
+    for cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.SPLITK_FLAG + 4):
+        assert ok(desc(ops.EPI_STORE, tile_config=cfg)) != 0, cfg
+
+
 def test_ctypes_structs_match_the_header(tmp_path):
     """The ctypes mirrors of the C-ABI structs (ops.ConvDesc, ops.WgradJob, _lib.BnBwdStats) against include/mbx.h as a C
     compiler lays it out: size and the offset of every field of mbx_conv_desc (gcc on a ten-line program; no GPU).  A field
