@@ -26,6 +26,7 @@ SOURCES = {
     "conv5.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "conv7.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],        # (as conv5.hip: the tile-fetch atomics)
     "convd.hip": [],
+    "convr.hip": [],
     "nnops.hip": ["-munsafe-fp-atomics"],
     "augment.hip": ["-ffp-contract=off"],
 }

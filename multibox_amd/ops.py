@@ -201,6 +201,27 @@ def directw_applies(desc: ConvDesc, min_pixels=60000):
     return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_DIRECTW_MIN_PIXELS", min_pixels))
 
 
+RESIDENT_TILE_CONFIG = 98                      # the resident-image launch for multi-tap convolutions on small maps (csrc/convr.hip)
+
+
+def resident_applies(desc: ConvDesc, min_images=32):
+    """The resident-image launch by rule: a stride-1, same-size 1x7 / 7x1 convolution (forward or data gradient) on a map of at
+    most 17 x 17 pixels with C_in 128 / 160 / 192 (block17's branch layers, model.py:33-37): a tile = a whole image (staged in
+    LDS once) x a quarter of the output channels, where the implicit GEMM gathers every pixel row once per tap.  Plain bf16
+    store (+ statistics) or the affine epilogue; enough images to fill the chip (4 tiles per image).  MBX_RESIDENT=0 turns it
+    off (A/B).  The library has the last word (mbx_conv_supported)."""
+    if os.environ.get("MBX_RESIDENT", "1") == "0":
+        return False
+    if desc.R * desc.S != 7 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
+            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial) or desc.bn_bwd_stats or desc.relu_bits:
+        return False
+    if desc.C_in not in (128, 160, 192) or desc.C_out > 192 or desc.C_out % 8:
+        return False
+    if desc.H_in != desc.H_out or desc.W_in != desc.W_out or not (64 <= desc.H_out * desc.W_out <= 289):
+        return False
+    return desc.N >= int(os.environ.get("MBX_RESIDENT_MIN_IMAGES", min_images))
+
+
 def splitk_slices(desc: ConvDesc, n_cus=256):
     """Split-K slices for a forward convolution by rule (0: none): long K (>= 8192) and at most 96 tiles of 128 x 64, i.e.
     less than half the CUs busy for hundreds of K steps -- the two 3x3 head convolutions on the 1536-channel feature map

@@ -383,6 +383,89 @@ def test_conv_directw_bit_identical(T, g):
     assert l.mbx_conv_supported(C.byref(bad)) == -2
 
 
+@pytest.mark.parametrize("g", [("r1", 3, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), ("r2", 3, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)),
+                               ("r3", 5, 12, 15, 128, 160, 1, 7, 1, (0, 3, 0, 3)), ("r4", 2, 9, 11, 160, 192, 7, 1, 1, (3, 0, 3, 0)),
+                               ("r5", 64, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), ("r6", 64, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)),
+                               ("r7", 70, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0))],
+                         ids=["1x7_128_160", "7x1_160_192", "1x7_12x15", "7x1_9x11", "1x7_b64", "7x1_b64", "7x1_b70_two_rounds"])
+def test_conv_resident_bit_identical(T, g):
+    """tile_config 98 (round 5, csrc/convr.hip conv_resident_kernel): block17's 1x7 / 7x1 layers (model.py:33-37) with the whole
+    input image of a tile resident in LDS and the filter streamed per tap -- against the implicit-GEMM launch of the same
+    descriptor: forward with statistics (plain rows and the 8 integer-atomic rows), affine + relu, and as a data gradient
+    (160 -> 128 and 192 -> 160 channels); smaller maps, more tiles than workgroups.  Outputs bit-identical; statistics =
+    sums of the stored values; slices of wider buffers untouched outside."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=17)
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    stream = torch.cuda.current_stream().cuda_stream
+    xb = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    outs = []
+    for cfg in (0, ops.RESIDENT_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb)
+        d.tile_config = cfg
+        rows = ops.conv_stats_rows(d)
+        assert cfg == 0 or rows == N
+        stats = torch.zeros((rows, Co, 2), dtype=torch.float32, device="cuda")
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=stats)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        full = yb.buf.reshape(N, Ho, Wo, Co + 24)
+        assert float(full[..., :16].abs().max()) == 0 and float(full[..., 16 + Co:].abs().max()) == 0
+        # the 8 integer-atomic rows (the training default): order-independent, so the two launches agree to the last bit
+        st8 = torch.zeros((8, Co, 2), dtype=torch.int64, device="cuda")
+        d8 = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=st8, stats_rows_mod=8, stats_ld=Co)
+        d8.tile_config = cfg
+        ops.conv(d8)
+        torch.cuda.synchronize()
+        outs.append((yb.tensor().clone(), stats.double().sum(0).cpu(), st8.sum(0).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0].float() - outs[1][0].float()).abs().max())
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-3)
+    o64 = outs[1][0].double().cpu().reshape(-1, Co)
+    assert torch.allclose(outs[1][1][:, 0], o64.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(outs[1][1][:, 1], (o64 * o64).sum(0), rtol=1e-5)
+    assert torch.allclose(outs[0][2].double(), outs[1][2].double(), rtol=1e-6, atol=64.0)      # fixed point, 2^-20 units: per-tile roundings differ
+    if N <= 8:
+        ok, msg = close(torch, outs[1][0], ref_conv(torch, x, w, st, pads))
+        assert ok, msg
+    gen = torch.Generator().manual_seed(7)
+    scale, shift = (torch.rand(Co, generator=gen) + 0.5).cuda(), (torch.randn(Co, generator=gen) * 0.2).cuda()
+    aff = []
+    for cfg in (0, ops.RESIDENT_TILE_CONFIG):
+        yb = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, epilogue=ops.EPI_AFFINE, relu=1, scale=scale, shift=shift)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        torch.cuda.synchronize()
+        aff.append(yb.tensor().clone())
+    assert torch.equal(aff[0], aff[1]) and float(aff[1].float().max()) > 0
+    # data gradient: input = dy [N,Ho,Wo,Co], flipped / transposed filter, "full" padding R - 1 - pad
+    dy = ops.View.alloc(N, Ho, Wo, Co + 32).slice(32, Co)
+    dy.tensor().copy_(torch.randn(N, Ho, Wo, Co, generator=gen).to(torch.bfloat16))
+    wt = w.to(torch.bfloat16).flip(1, 2).permute(3, 1, 2, 0).contiguous().cuda()          # [Ci][R][S][Co]
+    res = []
+    for cfg in (0, ops.RESIDENT_TILE_CONFIG):
+        gx = ops.View.alloc(N, H, W, Ci + 8, zero=True).slice(8, Ci)
+        dd = ops.make_desc(dy, wt, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], gx, transposed=1)
+        dd.tile_config = cfg
+        assert l.mbx_conv(C.byref(dd), stream) == 0
+        torch.cuda.synchronize()
+        assert float(gx.buf.reshape(N, H, W, Ci + 8)[..., :8].abs().max()) == 0
+        res.append(gx.tensor().clone())
+    assert torch.equal(res[0], res[1]) and float(res[0].float().abs().max()) > 0
+    bad = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, accumulate=1)
+    bad.tile_config = ops.RESIDENT_TILE_CONFIG
+    assert l.mbx_conv_supported(C.byref(bad)) == -2
+
+
 @pytest.mark.parametrize("cfg", [0, 2, 5, 6, 10, 12, 14, 33, 34, 35, 37, "pair"])
 def test_conv_bn_bwd_stats_epilogue(T, cfg):
     """mbx_conv_desc.bn_bwd_stats (round 4): the data gradient that writes an activation gradient also adds the batch-norm

@@ -66,8 +66,12 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
     dw = torch.zeros((Co, R, S, Ci), dtype=torch.float32, device="cuda")
     flops = 2.0 * B * Ho * Wo * Co * R * S * Ci
     kb_cfg = int(os.environ.get("KB_CFG", "0"))      # mbx_conv_desc.tile_config of the forward / data-gradient launches
+    import ctypes as _C
+    from multibox_amd import _lib as _L
     d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y)
     d_f.tile_config = kb_cfg
+    if _L.lib().mbx_conv_supported(_C.byref(d_f)) != 0:     # (a configuration that does not apply: the statistics rows of the default)
+        d_f.tile_config = 0
     rows = ops.conv_stats_rows(d_f)
     stats = torch.zeros((rows, Co, 2), device="cuda")
     d_f = ops.make_desc(x, w, Co, R, S, st, pt, pl, y, stats=stats)
@@ -85,7 +89,7 @@ for name, H, W, Ci, Co, R, S, st, (pt, pl), cnt in SHAPES:
     import ctypes as _C
     from multibox_amd import _lib as _L
     for d_ in (d_f, d_d):                              # a configuration that does not apply to this shape: library default
-        if _L.lib().mbx_conv(_C.byref(d_), torch.cuda.current_stream().cuda_stream) != 0:
+        if _L.lib().mbx_conv_supported(_C.byref(d_)) != 0:
             d_.tile_config = 0
     tf = timeit(lambda: ops.conv(d_f))
     td = timeit(lambda: ops.conv(d_d))
