@@ -54,6 +54,19 @@ __device__ __forceinline__ int renc(int row, int fch) {
 }
 template <int C8>
 __device__ __forceinline__ int rslot(int E, int j) { return (E ^ (4 * (j & rjx<C8>()))) + 4 * (j & ~rjx<C8>()); }
+// ... the same in BYTES off the start of LDS, the region's offset `base` folded in (a multiple of 256: the XOR-ed bits stay clear)
+template <int C8>
+__device__ __forceinline__ int rencb(int row, int fch, int base) { return base + 16 * renc<C8>(row, fch); }
+// (Eb is an LDS ADDRESS -- the 32-bit value of an address_space(3) pointer -- so that the read is one ds_read_b128 off a register
+// the XOR produced, with the rest of j in the instruction's offset field; through a generic pointer the compiler adds the
+// aperture base back in with an instruction per read)
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_cptr;
+__device__ __forceinline__ int lds_addr(const void* p) { return (int)(unsigned)(size_t)((const __attribute__((address_space(3))) char*)p); }
+template <int C8>
+__device__ __forceinline__ bf16x8 rread(int Eb, int j) {
+  const unsigned a = (unsigned)((Eb ^ (64 * (j & rjx<C8>()))) + 64 * (j & ~rjx<C8>()));
+  return __builtin_bit_cast(bf16x8, *(lds_u32x4_cptr)(size_t)a);
+}
 
 // LDS row 16 a + f of a filter slot holds output channel rperm(a, f) of the tile: blocks 2A and 2A + 1 leave a lane EIGHT
 // consecutive channels of one pixel (16-byte stores, conv_igemm3_kernel's order); a trailing unpaired block the plain order
@@ -62,12 +75,13 @@ __device__ __forceinline__ int rperm(int a, int f) {
   return (a < (NB / 2) * 2) ? 32 * (a >> 1) + 8 * (f >> 2) + 4 * (a & 1) + (f & 3) : 16 * a + f;
 }
 
-// scheduling pattern of one K step: NR LDS reads (the next step's fragments), each followed by its share of the NM MFMAs
+// scheduling pattern of one K step: the NR LDS reads of the next step's fragments interleaved with the first MFMAs
 template <int NR, int NM, int I = 0>
 __device__ __forceinline__ void sched_interleave() {
   if constexpr (I < NR) {
+    // (one read per MFMA up front: the rest of the step's MFMAs cover the latency of the last one)
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, (NM * (I + 1)) / NR - (NM * I) / NR, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, I + 1 < NR ? 1 : NM - (NR - 1), 0);
     sched_interleave<NR, NM, I + 1>();
   }
 }
@@ -178,34 +192,45 @@ conv_resident_kernel(const ConvK p, const ResK q) {
 
   // ---------------------------------------------------------------------------------------------- multiplying waves
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
-  // filter fragments: row 16 a + frow of a slot
+  // filter fragments: row 16 a + frow of a slot (byte offset within the slot + the ring's)
+  constexpr int RING_OFF0 = G::RED_CH * 16, IMG_OFF0 = RING_OFF0 + D * SLOTP * 16;
+  const int RING_OFF = RING_OFF0 + lds_addr(smem), IMG_OFF = IMG_OFF0 + lds_addr(smem);    // (dynamic LDS starts at 0 here: no static LDS)
+  static_assert(RING_OFF0 % 256 == 0 && (SLOTP * 16) % 256 == 0, "the XOR-ed address bits of a row must be clear in the region offsets");
   int EA[NB];
 #pragma unroll
-  for (int a = 0; a < NB; ++a) EA[a] = renc<C8>(16 * a + frow, fch);
-  // this lane's output pixels (fragment f of wave w = pixels 16 (w + 4 f) + frow) and, per tap, the LDS row they read
-  // ... computed one tap AHEAD inside the K loop (a dozen VALU operations per pixel block and tap in the shadow of the MFMAs;
-  // all taps up front were ~550 instructions between the image's issue and its first use)
+  for (int a = 0; a < NB; ++a) EA[a] = rencb<C8>(16 * a + frow, fch, RING_OFF);
+  // this lane's output pixels (fragment f of wave w = pixels 16 (w + 4 f) + frow) and the taps whose input pixel lies in the image
+  // (bit `tap` of vm); the LDS row of every (tap, pixel block) is computed one tap AHEAD inside the K loop (nine VALU
+  // operations in the shadow of the MFMAs; all taps up front were ~550 instructions between the image's issue and its first use)
   int E[2][MI];
-  int opix[MI], ohh[MI], oww[MI];
+  int opix[MI], vm[MI];
 #pragma unroll
   for (int f = 0; f < MI; ++f) {
     const int pl = 16 * (wave + kRCW * f) + frow;
     const bool pv = pl < q.HW;
     opix[f] = pv ? pl : -1;
-    ohh[f] = pv ? (int)fast_div((unsigned)pl, p.mg_w, p.sh_w) : -(1 << 20);          // (an invalid pixel: no tap is in range)
-    oww[f] = pv ? pl - ohh[f] * q.W : 0;
+    const int oh = pv ? (int)fast_div((unsigned)pl, p.mg_w, p.sh_w) : -(1 << 20);          // (an invalid pixel: no tap is in range)
+    const int ow = pv ? pl - oh * q.W : 0;
+    int m = 0;
+#pragma unroll
+    for (int tap = 0; tap < RS; ++tap)       // (bitwise: with && the compiler builds a branch per term)
+      m |= ((int)((unsigned)(oh + q.dh[tap]) < (unsigned)q.H) & (int)((unsigned)(ow + q.dw[tap]) < (unsigned)q.W)) << tap;
+    vm[f] = m;
   }
   auto tap_rows = [&](const int tap, int (&e)[MI]) {
 #pragma unroll
-    for (int f = 0; f < MI; ++f) {
-      // (bitwise: with && the compiler builds a branch per term)
-      const int ok = (int)((unsigned)(ohh[f] + q.dh[tap]) < (unsigned)q.H) & (int)((unsigned)(oww[f] + q.dw[tap]) < (unsigned)q.W);
-      e[f] = renc<C8>(ok ? opix[f] + q.dd[tap] : q.HW, fch);
-    }
+    for (int f = 0; f < MI; ++f) e[f] = rencb<C8>((vm[f] & (1 << tap)) ? opix[f] + q.dd[tap] : q.HW, fch, IMG_OFF);
   };
+#ifdef MBX_I5_STAMPS
+  const bool stamp = p.stamps && tid == 0 && blockIdx.x < 64;      // debug build (tools/res_stamps.py): tile phases of the first tile
+#define MBXR_STAMP(i) do { if (stamp && t == first) p.stamps[(blockIdx.x * 8) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define MBXR_STAMP(i) do { } while (0)
+#endif
   for (int t = first; t < q.ntiles; t += G_) {
     const int im = t / q.NG, g = t - im * q.NG;
     const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
+    MBXR_STAMP(0);
     issue_image(im);
     // per-channel scale / shift of the affine epilogue (folded batch norm, detect.py:313-326)
     float sc8[NP > 0 ? NP : 1][8], sh8[NP > 0 ? NP : 1][8], sc4[4], sh4[4];
@@ -229,12 +254,13 @@ conv_resident_kernel(const ConvK p, const ResK q) {
     wait_vmcnt<0>();
     lds_readback_wait(lds_readback_issue(img + lane));
     raw_barrier();                                        // P
+    MBXR_STAMP(1);
     // (the rows are the same for every tile; opaque to the compiler here, or it hoists every K step's address out of the
     // tile loop -- a hundred registers of loop invariants, spilled)
 #pragma unroll
     for (int a = 0; a < NB; ++a) asm volatile("" : "+v"(EA[a]));
 #pragma unroll
-    for (int f = 0; f < MI; ++f) asm volatile("" : "+v"(ohh[f]), "+v"(oww[f]));
+    for (int f = 0; f < MI; ++f) asm volatile("" : "+v"(opix[f]), "+v"(vm[f]));
 
     f32x4 acc[NB][MI];
 #pragma unroll
@@ -249,9 +275,9 @@ conv_resident_kernel(const ConvK p, const ResK q) {
     constexpr int NS = RS * KC, NR = NB + MI, NM = NB * MI;
     bf16x8 wf[2][NB], pf[2][MI];
 #pragma unroll
-    for (int a = 0; a < NB; ++a) wf[0][a] = __builtin_bit_cast(bf16x8, ring[rslot<C8>(EA[a], 0)]);
+    for (int a = 0; a < NB; ++a) wf[0][a] = rread<C8>(EA[a], 0);
 #pragma unroll
-    for (int f = 0; f < MI; ++f) pf[0][f] = __builtin_bit_cast(bf16x8, img[rslot<C8>(E[0][f], 0)]);
+    for (int f = 0; f < MI; ++f) pf[0][f] = rread<C8>(E[0][f], 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -264,21 +290,23 @@ conv_resident_kernel(const ConvK p, const ResK q) {
       }
       if (s % KC == 0 && s / KC + 1 < RS) tap_rows(s / KC + 1, E[(s / KC + 1) & 1]);     // the next tap's rows (used KC - 1 steps on)
       if (s + 1 < NS) {
-        const u32x4* sl = ring + (tap1 % D) * SLOTP;
+        const int so = (tap1 % D) * SLOTP * 16;
 #pragma unroll
-        for (int a = 0; a < NB; ++a) wf[nxt][a] = __builtin_bit_cast(bf16x8, sl[rslot<C8>(EA[a], j1)]);
+        for (int a = 0; a < NB; ++a) wf[nxt][a] = rread<C8>(EA[a] + so, j1);
 #pragma unroll
-        for (int f = 0; f < MI; ++f) pf[nxt][f] = __builtin_bit_cast(bf16x8, img[rslot<C8>(E[tap1 & 1][f], j1)]);
+        for (int f = 0; f < MI; ++f) pf[nxt][f] = rread<C8>(E[tap1 & 1][f], j1);
       }
+      // pixel-block-major: the fragment read LAST (pixel block MI - 1) is needed last in the next step
 #pragma unroll
-      for (int a = 0; a < NB; ++a)
+      for (int f = 0; f < MI; ++f)
 #pragma unroll
-        for (int f = 0; f < MI; ++f)
+        for (int a = 0; a < NB; ++a)
           acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], pf[cur][f], acc[a][f], 0, 0, 0);
       if (s + 1 < NS) sched_interleave<NR, NM>();
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    MBXR_STAMP(2);
     // ---- epilogue: blocks 2A, 2A + 1 -> 8 consecutive channels (cb + 32 A + 8 fch ..) of the lane's pixel: 16-byte stores;
     // an unpaired last block: 4 consecutive channels (cb + 32 NP + 4 fch ..), 8-byte stores
     float s1[NB][4], s2[NB][4];
@@ -347,18 +375,28 @@ conv_resident_kernel(const ConvK p, const ResK q) {
       }
     }
     if constexpr (EV == 1) {
-      // ONE statistics row per image: lane sums -> the 16 lanes that share its channels -> the four waves, fixed order
+      // ONE statistics row per image: lane sums -> the 16 lanes that share its channels (DPP row sums, eight at a time) -> the
+      // four waves, fixed order
+      {
+        float v[NB * 8];
 #pragma unroll
-      for (int a = 0; a < NB; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x1 = row_sum16(s1[a][r]), x2 = row_sum16(s2[a][r]);
+          for (int r = 0; r < 4; ++r) { v[a * 8 + r] = s1[a][r]; v[a * 8 + 4 + r] = s2[a][r]; }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          float u[8] = {v[a * 8], v[a * 8 + 1], v[a * 8 + 2], v[a * 8 + 3], v[a * 8 + 4], v[a * 8 + 5], v[a * 8 + 6], v[a * 8 + 7]};
+          row_sum16_x8(u);
           if (frow == 0) {
-            const int ch = rperm<NB>(a, 4 * fch + r);
-            red[(wave * 16 * NB + ch) * 2] = x1;
-            red[(wave * 16 * NB + ch) * 2 + 1] = x2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ch = rperm<NB>(a, 4 * fch + r);
+              red[(wave * 16 * NB + ch) * 2] = u[r];
+              red[(wave * 16 * NB + ch) * 2 + 1] = u[4 + r];
+            }
           }
         }
+      }
       lds_barrier();                                      // (the loaders attend)
       if (tid < 16 * NB && cb + tid < ce) {
         float x1 = 0.f, x2 = 0.f;
@@ -367,7 +405,9 @@ conv_resident_kernel(const ConvK p, const ResK q) {
         stats_write(p, im, cb + tid, x1, x2);
       }
     }
+    MBXR_STAMP(3);
   }
+#undef MBXR_STAMP
 }
 
 int resident_cus() {

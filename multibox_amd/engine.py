@@ -680,7 +680,8 @@ class Net:
                 dd.R, dd.S, dd.stride, dd.epilogue, dd.C_in, dd.C_out = X.R, X.S, 1, ops.EPI_STORE, X.K, X.Cin
                 dd.N, dd.H_out, dd.W_out, dd.rscale = X.x.N, X.x.H, X.x.W, (X.rscale if X.kind == "residual" else 0.0)
                 dd.W_out = X.x.W
-                if ops.direct3_applies(dd) or ops.directw_applies(dd):
+                dd.H_in, dd.W_in, dd.H_out = X.x.H, X.x.W, X.x.H
+                if ops.direct3_applies(dd) or ops.directw_applies(dd) or (X.out.H == X.x.H and X.out.W == X.x.W and ops.resident_applies(dd)):
                     continue
                 conv_ok[id(X)] = segs
             drop = set()
@@ -764,6 +765,11 @@ class Net:
                 # launch (21.7 us against 12.0 + 11.3 as two direct launches: these launches are latency-bound)
                 d.tile_config, d.work_counter = ops.DIRECTW_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 (whole-width) " + op.name)
+            elif ops.resident_applies(d):
+                # many channels on a SMALL map with a multi-tap filter (block17's 1x7 / 7x1 layers, forward and data gradient): the
+                # resident-image launch stages each image once instead of gathering it once per tap (by rule; bit-identical outputs)
+                d.tile_config, d.work_counter = ops.RESIDENT_TILE_CONFIG, None
+                _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "resident image " + op.name)
         return d
 
     def _build_forward_launches(self):

@@ -202,7 +202,7 @@ def main():
         better = min(walls["new"]) < min(walls["old"]) and sum(walls["new"]) < sum(walls["old"])
         if changed and better and not args.dry:
             for key, cfg in new.items():
-                if cfg > ops.SPLITK_FLAG or cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG):
+                if cfg > ops.SPLITK_FLAG or cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG):
                     continue                                  # chosen by rule at net build (split-K, direct launches): not table entries
                 ops._TUNED[key] = cfg
                 if cfg > ops.I5_FLAG:
