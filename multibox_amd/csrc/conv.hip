@@ -29,6 +29,7 @@ int mbx_directw_grid(int N, int H_out, int W_out);
 // convr.hip: the resident-image launch for multi-tap convolutions on small maps (mbx_conv_desc.tile_config = kResidentCfg)
 int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s);
 int mbx_resident_rows(int N);
+int mbx_launch_pwres(void* convk, hipStream_t s);
 extern const int mbx_i5_tiles[][2];
 extern const int mbx_i5_num_tiles;
 
@@ -1155,6 +1156,7 @@ constexpr int kI5Flag = 32;      // mbx_conv_desc.tile_config = 32 + t: igemm5 t
 constexpr int kI7Cfg = 65;       // mbx_conv_desc.tile_config = 65: igemm7 (conv7.hip), persistent pointwise launch with the filter panel in LDS
 constexpr int kDirectCfg = 96;   // mbx_conv_desc.tile_config = 96: the direct 3x3 launch (convd.hip)
 constexpr int kDirectWCfg = 97;  // mbx_conv_desc.tile_config = 97: the whole-width direct 3x3 launch for narrow maps (convd.hip)
+constexpr int kPwResCfg = 99;    // mbx_conv_desc.tile_config = 99: the pixel-resident pointwise launch for the epilogue-bound 1x1 layers (convr.hip)
 constexpr int kResidentCfg = 98; // mbx_conv_desc.tile_config = 98: the resident-image launch for 1x7 / 7x1 layers on small maps (convr.hip)
 constexpr int kSplitFlag = 128;  // mbx_conv_desc.tile_config = 128 + S: split-K in S slices (float32 partials + reduce launch)
 constexpr int kSplitMax = 32;
@@ -1476,6 +1478,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   if (d->tile_config == kDirectCfg) return mbx_launch_direct3(&k, d->N, d->H_out, s);
   if (d->tile_config == kDirectWCfg) return mbx_launch_directw(&k, d->N, d->H_out, s);
   if (d->tile_config == kResidentCfg) return mbx_launch_resident(&k, d->N, d->H_out, s);
+  if (d->tile_config == kPwResCfg) return mbx_launch_pwres(&k, s);
   if (d->tile_config == kI7Cfg) return mbx_launch_igemm7(&k, s);
   if (d->tile_config > kI5Flag) return mbx_launch_igemm5(&k, d->tile_config - kI5Flag - 1, s);
   switch (choose_cfg(k.M, k.C_out, d->tile_config)) {

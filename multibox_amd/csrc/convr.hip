@@ -410,6 +410,325 @@ conv_resident_kernel(const ConvK p, const ResK q) {
 #undef MBXR_STAMP
 }
 
+// ------------------------------------------------------------------------------------------ pointwise, pixels resident
+// conv_pwres_kernel: the 1x1 convolutions whose launch time is their EPILOGUE's memory traffic -- the residual "up" convolutions
+// of block35 / block17 / block8 (model.py:19-23, 39-43, 59-63: 128 -> 320, 384 -> 1088, 448 -> 2080 channels; relu(skip +
+// s (conv + b)) + sign bits) and the data gradients of the fused first 1x1s (96 -> 320, 320 -> 1088, 384 -> 2080; accumulate +
+// relu mask): 2.36 ms of the round-4 training step at half the streaming rate of the chip.  As persistent 128 x 256 / 256 x
+// 128 tiles every workgroup runs K loop and epilogue back to back, and all of them in step: the chip alternates between an
+// operand-feed phase and an HBM phase.  Here a workgroup keeps an 80-PIXEL tile of the input resident in LDS (loaded once:
+// 80 x K) and walks the OUTPUT CHANNELS in column tiles of 128: the filter -- 0.1-0.9 MB, L2-resident, a fifth of a
+// microsecond away -- streams through a ring of 64-deep slots (four loader waves), each column tile is 120 MFMAs per wave and
+// then 40 KB of epilogue traffic whose reads were issued before its K loop.  Per CU the HBM stream is fine-grained (nine
+// small epilogues per launch instead of three large ones) and one tile per workgroup needs no persistence: 232 workgroups
+// for block17, whatever else holds CUs.  Same K order and MFMA grouping as every implicit-GEMM tile, the shared epilogue
+// (conv_common.h): bit-identical results.
+struct PwK {
+  int npt, NCS, nct, ctper, nunits;                       // pixel tiles (80 pixels), column splits, column tiles (128 channels), column tiles per split
+  int npi;                                                // 1 KB pieces of the resident pixel tile
+};
+constexpr int kPwPix = 80, kPwMI = 5, kPwCol = 128;
+constexpr int kPwThreads = 768, kPwCW = 8;                // waves 0-3 / 4-7: the two multiplying groups; 8-11: loaders
+
+// Vector-memory READS of the multiplying waves as inline asm, waited for by hand.  The compiler's own s_waitcnt insertion is
+// exact inside straight-line code but CONSERVATIVE across a loop's back edge: for epilogue operands fetched one column tile
+// ahead it waited for everything outstanding -- the previous tile's stores and the next tile's reads included -- which is the
+// serialisation this kernel exists to remove.  Loads the compiler does not see are never waited for by it; pw_wait<N>
+// (s_waitcnt vmcnt(N), N = the stores issued since) names every destination register, so their uses stay behind it.
+__device__ __forceinline__ u32x4 pw_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu,
+               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void pw_load16(u32x4& dst, const u32x4 rsrc, const unsigned off) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void pw_load1(unsigned& dst, const u32x4 rsrc, const unsigned off) {
+  asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rsrc) : "memory");
+}
+template <int EV, int N>
+__device__ __forceinline__ void pw_wait(u32x4 (&la)[kPwMI][1], u32x4 (&lb)[kPwMI][1], u32x4 (&sh)[2]) {
+  if constexpr (EV == 4) {          // (skip rows + the shift row; lb is not used)
+    asm volatile("s_waitcnt vmcnt(%7)"
+                 : "+v"(la[0][0]), "+v"(la[1][0]), "+v"(la[2][0]), "+v"(la[3][0]), "+v"(la[4][0]), "+v"(sh[0]), "+v"(sh[1])
+                 : "n"(N) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(la[0][0]), "+v"(la[1][0]), "+v"(la[2][0]), "+v"(la[3][0]), "+v"(la[4][0]),
+                   "+v"(lb[0][0]), "+v"(lb[1][0]), "+v"(lb[2][0]), "+v"(lb[3][0]), "+v"(lb[4][0])
+                 : "n"(N) : "memory");
+  }
+}
+// The reads of conv_epilogue_issue_reads (EV 2 / 4: same offsets, same uniform choices) and the shift row of
+// conv_epilogue_channels (EV 4; a range-checked buffer read: zeros past C_out or without a table, as there), for pixel
+// blocks 0 .. 4 of a lane whose first pixel is mlane and first channel clane.
+template <int EV>
+__device__ __forceinline__ void pw_issue_reads(const ConvK& p, const int mlane, const int clane, u32x4 (&la)[kPwMI][1], u32x4 (&lb)[kPwMI][1],
+                                               u32x4 (&sh)[2]) {
+  static_assert(EV == 2 || EV == 4, "accumulate (+ mask) / residual");
+  const u32x4 kr = pw_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
+  const u32x4 ar = pw_rsrc(p.acc_src, p.acc_bytes);
+  const u32x4 br = pw_rsrc(p.bits, p.bits ? p.bits_bytes : 0u);
+  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
+  const bool do_bits = EV == 2 && p.bits != nullptr;                                       // (uniform; never with do_mask)
+  const int c0 = clane;
+#pragma unroll
+  for (int b = 0; b < kPwMI; ++b) {
+    const int m = mlane + b * 16;
+    int img, pix;
+    epi_pixel<false>(p, m, img, pix);
+    const bool ok = m < p.M && c0 < p.C_out;
+    const unsigned so = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
+    if constexpr (EV == 2) { la[b][0] = u32x4{0u, 0u, 0u, 0u}; lb[b][0] = u32x4{0u, 0u, 0u, 0u}; }
+    if constexpr (EV == 4) {
+      pw_load16(la[b][0], kr, so);
+    } else {
+      const unsigned ao = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
+      if (do_acc) pw_load16(la[b][0], ar, ao);
+      if (do_mask) pw_load16(lb[b][0], kr, so);
+      if (do_bits) { unsigned byte_; pw_load1(byte_, br, ok ? (unsigned)(m * p.bits_ld + (c0 >> 3)) : kOOB); lb[b][0].x = byte_; }
+    }
+  }
+  if constexpr (EV == 4) {
+    const u32x4 sr = pw_rsrc(p.shiftv, p.shiftv ? (unsigned)p.C_out * 4u : 0u);
+    pw_load16(sh[0], sr, (unsigned)c0 * 4u);             // (C_out % 8 == 0: a lane's eight channels are all in or all out)
+    pw_load16(sh[1], sr, (unsigned)c0 * 4u + 16u);
+  }
+}
+
+template <int C8>
+struct PwG {
+  static constexpr int KC = C8 / 4;                       // K steps of 32
+  static constexpr int KS = (C8 % 8 == 0) ? 2 : 1;        // K steps per ring slot (64-deep slots where K allows)
+  static constexpr int NSL = KC / KS;                     // slots per column tile
+  static constexpr int C8S = 4 * KS;                      // 16-byte chunks per filter row of a slot
+  static constexpr int SLOT_CH = kPwCol * C8S;            // chunks per slot (16 or 8 KB)
+  static constexpr int PT = SLOT_CH / (64 * kRLW);        // pieces per loader wave and slot
+  static constexpr int PIX_CH = (kPwPix * C8 + 63) / 64 * 64;
+  static constexpr int NST_RAW = (160 * 1024 / 16 - PIX_CH) / SLOT_CH;
+  static constexpr int NST = NST_RAW > 8 ? 8 : NST_RAW;   // ring depth
+  static constexpr int LDS_BYTES = (NST * SLOT_CH + PIX_CH) * 16;
+  static_assert(KC % KS == 0 && NST >= 3 && (NST - 1) * PT < 64, "ring");
+};
+
+template <int C8, int EV>
+__global__ void __launch_bounds__(kPwThreads)
+conv_pwres_kernel(const ConvK p, const PwK q) {
+  using G = PwG<C8>;
+  constexpr int KC = G::KC, KS = G::KS, NSL = G::NSL, C8S = G::C8S, SLOT_CH = G::SLOT_CH, PT = G::PT, NST = G::NST, MI = kPwMI;
+  constexpr int NI = 2, NA = 1;
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* const ring = smem;                               // [NST][128 rows][C8S]
+  u32x4* const pix = smem + NST * SLOT_CH;                // [80 pixels][C8] (swizzled)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id();
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int first = xcd_remap((int)blockIdx.x, (int)gridDim.x), G_ = (int)gridDim.x;
+  const int frow = lane & 15, fch = lane >> 4;
+
+  // the pixel tile: pieces wave, wave + 8, ...; chunk ci = row ci / C8 (pixel m0 + row), slot ci % C8 holds source chunk slot ^ key(row)
+  auto issue_pixels = [&](const int m0) {
+    for (int i = wave; i < q.npi; i += kPwThreads / 64) {
+      const int ci = i * 64 + lane;
+      const int row = ci / C8, cs = ci - row * C8;
+      const int c = cs ^ rkey<C8>(row);
+      const int m = m0 + row;
+      const bool ok = row < kPwPix && m < p.M;
+      const int img = (int)fast_div((unsigned)(ok ? m : 0), p.mg_hw, p.sh_hw);
+      glds16(xr, pix + i * 64, ok ? (img * p.x_img_stride + (m - img * p.HW_out) * p.ldx + c * 8) * 2 : (int)kOOB);
+    }
+  };
+
+  if (wave >= kPwCW) {
+    // ------------------------------------------------------------------------------------------ loader waves
+    const int lw = wave - kPwCW;
+    int wo[PT], chn[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int ci = (lw + kRLW * i) * 64 + lane;
+      const int row = ci / C8S, cs = ci - row * C8S;
+      const int c = cs ^ rkey<C8S>(row);
+      // LDS row 32 w + 16 a + f = channel 32 w + rperm<2>(a, f) of the column tile (wave w's 32 channels, igemm3's order)
+      chn[i] = 32 * (row >> 5) + rperm<2>((row >> 4) & 1, row & 15);
+      wo[i] = (chn[i] * (8 * C8) + c * 8) * 2;
+    }
+    for (int u = first; u < q.nunits; u += G_) {
+      const int pt = u / q.NCS, cs_ = u - pt * q.NCS;
+      const int ct0 = cs_ * q.ctper, ct1 = min(ct0 + q.ctper, q.nct);
+      const int NS = (ct1 - ct0) * NSL;                   // slots of this unit
+      int si = 0, si_ct = ct0, si_kc = 0, si_pos = 0;     // issue cursor: slot index, its column tile / K chunk, ring position
+      auto issue_slot = [&]() {
+        const int n0 = si_ct * kPwCol;
+        u32x4* dst = ring + si_pos * SLOT_CH + lw * 64;
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+          glds16(wr, dst + i * (kRLW * 64), (n0 + chn[i] < p.C_out) ? n0 * (8 * C8) * 2 + wo[i] + si_kc * (KS * 64) : (int)kOOB);
+        ++si;
+        if (++si_kc == NSL) { si_kc = 0; ++si_ct; }
+        si_pos = si_pos == NST - 1 ? 0 : si_pos + 1;
+      };
+      issue_pixels(pt * kPwPix);
+      const int ahead = NS < NST ? NS : NST;
+      for (int i = 0; i < ahead; ++i) issue_slot();
+      // the pixel tile and slot 0 have retired (this wave's share), then landed
+      if (ahead == NST) wait_vmcnt<(NST - 1) * PT>(); else wait_vmcnt<0>();
+      lds_readback_wait(lds_readback_issue(ring + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
+      raw_barrier();                                      // P
+      int pos1 = 1 % NST;                                 // ring position of slot s + 1
+      for (int s_ = 0; s_ < NS; ++s_) {
+        if (s_ + 1 < NS) {
+          // slot s + 1 has retired: behind it this wave has issued the slots up to min(NS - 1, s + NST - 1)
+          const int newer = (s_ + NST - 1 < NS - 1 ? s_ + NST - 1 : NS - 1) - (s_ + 1);
+          if (newer >= NST - 2) wait_vmcnt<(NST - 2) * PT>();
+          else if (NST > 3 && newer == NST - 3) wait_vmcnt<(NST - 3 > 0 ? NST - 3 : 0) * PT>();
+          else if (NST > 4 && newer == NST - 4) wait_vmcnt<(NST - 4 > 0 ? NST - 4 : 0) * PT>();
+          else if (NST > 5 && newer == NST - 5) wait_vmcnt<(NST - 5 > 0 ? NST - 5 : 0) * PT>();
+          else if (NST > 6 && newer == NST - 6) wait_vmcnt<(NST - 6 > 0 ? NST - 6 : 0) * PT>();
+          else if (NST > 7 && newer == NST - 7) wait_vmcnt<(NST - 7 > 0 ? NST - 7 : 0) * PT>();
+          else wait_vmcnt<0>();
+          lds_readback_wait(lds_readback_issue(ring + pos1 * SLOT_CH + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
+        }
+        raw_barrier();                                    // B_s: slot s is free, slot s + 1 is published
+        if (si < NS) issue_slot();                        // slot s + NST into the ring position slot s had
+        pos1 = pos1 == NST - 1 ? 0 : pos1 + 1;
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- multiplying waves
+  // TWO GROUPS of four (waves 0-3 and 4-7: one wave of each per SIMD) that ALTERNATE column tiles: while one group multiplies
+  // column tile i, the other converts, masks and stores tile i - 1 -- the epilogue is ~300 vector instructions and 40 KB of
+  // memory traffic per tile and wave, which on four waves alone was a third of every tile's time (stamps: K loop 2.1 us,
+  // epilogue 1.1 us) with the matrix cores idle.  One barrier per ring slot for everyone: the multiplying group's sits in its K
+  // loop, the other group's between the pixel blocks of its epilogue (whose reads were issued before ITS K loop and whose
+  // stores nobody waits for, so it never holds a barrier up for memory).
+  // (EV 2: the relu mask comes from the SIGN BITS only -- the tensor-mask path is compiled out, 128 registers hold no 20 more)
+  constexpr int EVC = EV, BMODE = EV == 2 ? 2 : 1;
+  const int grp = wave >> 2, gw = wave & 3;
+  const int lds0 = lds_addr(smem);
+  int EA[NI], Ep[MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) EA[a] = rencb<C8S>(32 * gw + 16 * a + frow, fch, lds0);
+#pragma unroll
+  for (int f = 0; f < MI; ++f) Ep[f] = rencb<C8>(16 * f + frow, fch, lds0 + NST * SLOT_CH * 16);
+#ifdef MBX_I5_STAMPS
+  // debug build (tools/pw_stamps.py): [block][column tile (first 8)][K loop starts, K loop done, epilogue done] of the first unit
+  const bool stamp = p.stamps && (tid & 255) == 0 && blockIdx.x < 64;
+#define MBXP_STAMP(ci, i) do { if (stamp && u == first && (ci) < 8) p.stamps[(blockIdx.x * 8 + (ci)) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define MBXP_STAMP(ci, i) do { } while (0)
+#endif
+  for (int u = first; u < q.nunits; u += G_) {
+    const int pt = u / q.NCS, cs_ = u - pt * q.NCS;
+    const int ct0 = cs_ * q.ctper, ct1 = min(ct0 + q.ctper, q.nct);
+    const int nct = ct1 - ct0;
+    const int m0 = pt * kPwPix;
+    issue_pixels(m0);
+    wait_vmcnt<0>();
+    lds_readback_wait(lds_readback_issue(pix + lane));
+    raw_barrier();                                        // P
+#pragma unroll
+    for (int a = 0; a < NI; ++a) asm volatile("" : "+v"(EA[a]));       // (opaque per unit: no hoisting of every K step's address)
+#pragma unroll
+    for (int f = 0; f < MI; ++f) asm volatile("" : "+v"(Ep[f]));
+    const int mlane = m0 + frow;
+    f32x4 acc[NI][MI];
+    u32x4 la[MI][NA], lb[MI][NA];
+    // the epilogue of this group's column tile CE (local index), its MI pixel blocks dealt over the NSL slot barriers of the
+    // tile the other group multiplies meanwhile (WITH = false: the unit's last tile -- no one multiplies, no barriers are left)
+#define PW_EPILOGUE(CE, WITH)                                                                                        \
+  do {                                                                                                               \
+    const int clane_e = (ct0 + (CE)) * kPwCol + 32 * gw + 8 * fch;                                                   \
+    float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];                                                                \
+    conv_epilogue_channels<EVC, NA>(p, clane_e, sc, sh, s1, s2);                                                     \
+    _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                                             \
+      _Pragma("unroll") for (int b = 0; b < MI; ++b)                                                                 \
+        if (b >= (MI * sl) / NSL && b < (MI * (sl + 1)) / NSL)                                                       \
+          conv_epilogue_finish<EVC, false, NI, MI, 1, BMODE>(p, acc, mlane, clane_e, b, *reinterpret_cast<u32x4 (*)[1][NA]>(&la[b]), \
+                                                      *reinterpret_cast<u32x4 (*)[1][NA]>(&lb[b]), sh, sc, s1, s2);  \
+      if (WITH) raw_barrier();                                                                                       \
+    }                                                                                                                \
+  } while (0)
+    int so = 0;                                           // byte offset of the ring position being read
+    for (int ci = 0; ci < nct; ++ci) {
+      if ((ci & 1) != grp) {
+        // ---- the other group multiplies column tile ci: this group's previous tile goes out (or, at the start, nothing does)
+        if (ci > 0) { PW_EPILOGUE(ci - 1, true); MBXP_STAMP(ci - 1, 2); }
+        else {
+#pragma unroll 1
+          for (int sl = 0; sl < NSL; ++sl) raw_barrier();
+        }
+        so += NSL * SLOT_CH * 16;                         // (the ring moved on by this tile's slots)
+        while (so >= NST * SLOT_CH * 16) so -= NST * SLOT_CH * 16;
+        continue;
+      }
+      const int clane = (ct0 + ci) * kPwCol + 32 * gw + 8 * fch;
+      MBXP_STAMP(ci, 0);
+      // the epilogue's reads (residual skip / accumulate source / mask), issued before the K loop: they land while the tile is
+      // multiplied (the multiplying waves issue no other vector-memory instruction)
+      conv_epilogue_issue_reads<EVC, false, NA, MI, BMODE>(p, mlane, clane, 0, la, lb);
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int f = 0; f < MI; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[2][NI], pf[2][MI];
+#pragma unroll
+      for (int a = 0; a < NI; ++a) wf[0][a] = rread<C8S>(EA[a] + so, 0);
+#pragma unroll
+      for (int f = 0; f < MI; ++f) pf[0][f] = rread<C8>(Ep[f], 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        const int j1 = (s + 1) % KS;
+        if (j1 == 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done
+          raw_barrier();                                        // B: the slot may be refilled; the next one is published
+          so = so == (NST - 1) * SLOT_CH * 16 ? 0 : so + SLOT_CH * 16;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s + 1 < KC) {
+#pragma unroll
+          for (int a = 0; a < NI; ++a) wf[nxt][a] = rread<C8S>(EA[a] + so, j1);
+#pragma unroll
+          for (int f = 0; f < MI; ++f) pf[nxt][f] = rread<C8>(Ep[f], s + 1);
+        }
+#pragma unroll
+        for (int f = 0; f < MI; ++f)
+#pragma unroll
+          for (int a = 0; a < NI; ++a)
+            acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], pf[cur][f], acc[a][f], 0, 0, 0);
+        if (s + 1 < KC) sched_interleave<NI + MI, NI * MI>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      MBXP_STAMP(ci, 1);
+    }
+    if (((nct - 1) & 1) == grp) { PW_EPILOGUE(nct - 1, false); MBXP_STAMP(nct - 1, 2); }      // the unit's last tile
+  }
+#undef MBXP_STAMP
+#undef PW_EPILOGUE
+}
+
+template <int C8>
+int launch_pwres(const ConvK& k, const PwK& q, int grid, hipStream_t s) {
+  using G = PwG<C8>;
+  constexpr int lds = G::LDS_BYTES;
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr[2] = {false, false};
+  const int ev = k.epi == MBX_EPI_RESIDUAL ? 1 : 0;
+  if (!attr[ev]) {
+    if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwres_kernel<C8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwres_kernel<C8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr[ev] = true;
+  }
+  if (ev) hipLaunchKernelGGL((conv_pwres_kernel<C8, 4>), dim3(grid), dim3(kPwThreads), lds, s, k, q);
+  else hipLaunchKernelGGL((conv_pwres_kernel<C8, 2>), dim3(grid), dim3(kPwThreads), lds, s, k, q);
+  MBX_LAUNCH_CHECK();
+  return MBX_OK;
+}
+
 int resident_cus() {
   static int ncu = 0;
   if (!ncu) {
@@ -485,5 +804,37 @@ int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s) {
   }
   MBX_RES(16, 3, 7) MBX_RES(20, 3, 7) MBX_RES(20, 2, 7) MBX_RES(24, 3, 7)
 #undef MBX_RES
+  return MBX_ERR_UNSUPPORTED;
+}
+
+// mbx_conv_desc.tile_config = 99: the PIXEL-RESIDENT pointwise launch (conv_pwres_kernel).  MBX_ERR_UNSUPPORTED for anything but
+// a 1x1 / stride-1 / unpadded convolution with C_in 96 / 128 / 320 / 384 / 448 and a residual epilogue (+ relu, + sign bits) or a
+// bf16 store masked by relu sign bits (with or without an accumulate source).
+int mbx_launch_pwres(void* convk, hipStream_t s) {
+  ConvK& k = *reinterpret_cast<ConvK*>(convk);
+  if (!k.pw || k.shift || k.stats || k.bw_n || k.C_out % 8) return MBX_ERR_UNSUPPORTED;
+  const bool res = k.epi == MBX_EPI_RESIDUAL, accm = k.epi == MBX_EPI_STORE && k.bits && !k.skip;     // (masks by the sign bits only)
+  if (!res && !accm) return MBX_ERR_UNSUPPORTED;
+  PwK q;
+  q.npt = (k.M + kPwPix - 1) / kPwPix;
+  q.nct = (k.C_out + kPwCol - 1) / kPwCol;
+  const int ncu = resident_cus();
+  int ncs = ncu / q.npt;
+  if (ncs < 1) ncs = 1;
+  if (ncs > q.nct) ncs = q.nct;
+  q.ctper = (q.nct + ncs - 1) / ncs;
+  q.NCS = (q.nct + q.ctper - 1) / q.ctper;
+  q.nunits = q.npt * q.NCS;
+  const int C8 = k.C_in / 8;
+  q.npi = (kPwPix * C8 + 63) / 64;
+  int grid = q.nunits < ncu ? q.nunits : ncu;
+  if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;
+#define MBX_PW(C8_)                                                   \
+  if (k.C_in == 8 * C8_) {                                           \
+    if (k.dry) return MBX_OK;                                        \
+    return launch_pwres<C8_>(k, q, grid, s);                         \
+  }
+  MBX_PW(12) MBX_PW(16) MBX_PW(40) MBX_PW(48) MBX_PW(56)
+#undef MBX_PW
   return MBX_ERR_UNSUPPORTED;
 }

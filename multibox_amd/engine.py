@@ -765,6 +765,11 @@ class Net:
                 # launch (21.7 us against 12.0 + 11.3 as two direct launches: these launches are latency-bound)
                 d.tile_config, d.work_counter = ops.DIRECTW_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 (whole-width) " + op.name)
+            elif ops.pwres_applies(d):
+                # the 1x1 launches whose time is their epilogue's trunk traffic (residual "up" forward, accumulate + mask data
+                # gradients): pixels resident, filter streamed, one small epilogue per 128 output channels (by rule; bit-identical)
+                d.tile_config, d.work_counter = ops.PWRES_TILE_CONFIG, None
+                _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "pixel-resident 1x1 " + op.name)
             elif ops.resident_applies(d):
                 # many channels on a SMALL map with a multi-tap filter (block17's 1x7 / 7x1 layers, forward and data gradient): the
                 # resident-image launch stages each image once instead of gathering it once per tap (by rule; bit-identical outputs)

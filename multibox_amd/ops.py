@@ -222,6 +222,28 @@ def resident_applies(desc: ConvDesc, min_images=32):
     return desc.N >= int(os.environ.get("MBX_RESIDENT_MIN_IMAGES", min_images))
 
 
+PWRES_DEFAULT = "0"                            # (off until it beats the persistent tiles in the step: LAB_NOTES round 5)
+PWRES_TILE_CONFIG = 99                         # the pixel-resident pointwise launch for the epilogue-bound 1x1 layers (csrc/convr.hip, conv_pwres_kernel)
+
+
+def pwres_applies(desc: ConvDesc, min_pixels=4096):
+    """The pixel-resident pointwise launch by rule: a 1x1 / stride-1 convolution with C_in 96 / 128 / 320 / 384 / 448 whose epilogue
+    streams trunk tensors -- the residual "up" convolutions of block35 / block17 / block8 (model.py:19-23, 39-43, 59-63) and the
+    accumulate (+ relu mask) data gradients of their fused first 1x1s -- with at least 256 output channels.  MBX_PWRES=0 turns it
+    off (A/B).  The library has the last word (mbx_conv_supported)."""
+    if os.environ.get("MBX_PWRES", PWRES_DEFAULT) == "0":
+        return False
+    if desc.R != 1 or desc.S != 1 or desc.stride != 1 or desc.pad_t or desc.pad_l or desc.stats_partial or desc.bn_bwd_stats:
+        return False
+    if desc.C_in not in (96, 128, 320, 384, 448) or desc.C_out < 256 or desc.C_out % 8:
+        return False
+    res = desc.epilogue == EPI_RESIDUAL
+    accm = desc.epilogue == EPI_STORE and desc.relu_bits and not desc.skip
+    if not (res or accm):
+        return False
+    return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_PWRES_MIN_PIXELS", min_pixels))
+
+
 def splitk_slices(desc: ConvDesc, n_cus=256):
     """Split-K slices for a forward convolution by rule (0: none): long K (>= 8192) and at most 96 tiles of 128 x 64, i.e.
     less than half the CUs busy for hundreds of K steps -- the two 3x3 head convolutions on the 1536-channel feature map

@@ -932,6 +932,79 @@ def test_igemm7_panel_resident_bit_identical(T, g):
     assert l.mbx_conv(C.byref(d), stream) == -2                      # MBX_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("g", [("q1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("q2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
+                               ("q3", 5, 8, 8, 448, 2080, 1, 1, 1, (0, 0, 0, 0)), ("q4", 16, 17, 17, 320, 1088, 1, 1, 1, (0, 0, 0, 0)),
+                               ("q5", 5, 35, 35, 96, 320, 1, 1, 1, (0, 0, 0, 0)), ("q6", 64, 8, 8, 384, 2080, 1, 1, 1, (0, 0, 0, 0)),
+                               ("q7", 64, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0))],
+                         ids=["block17_up", "block35_up", "block8_up", "block17_dgrad_k320", "block35_dgrad_k96", "block8_dgrad_b64", "block17_up_b64"])
+def test_conv_pwres_bit_identical(T, g):
+    """tile_config 99 (round 5, csrc/convr.hip conv_pwres_kernel): the pointwise launch with an 80-pixel tile resident in LDS and
+    the filter streamed per 128 output channels, against the implicit-GEMM launch of the same descriptor: residual + relu with
+    and without the sign-bit table (y AND the bits identical), accumulate + tensor mask, accumulate + sign-bit mask, accumulate
+    only, scaled -- the block35 / block17 / block8 "up" convolutions (model.py:19-23, 39-43, 59-63) and the data gradients of
+    their fused first 1x1s; ragged pixel tiles, column splits (few pixels), more units than workgroups.  Bit-identical."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    x, w = make_case(torch, g, seed=41)
+    gen = torch.Generator().manual_seed(42)
+    M = N * H * W
+    xb = ops.View.alloc(N, H, W, Ci + 8).slice(8, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    sh = torch.randn(Co, generator=gen).cuda()
+    skip = ops.View.alloc(N, H, W, Co + 8).slice(8, Co)
+    skip.tensor().copy_(torch.randn(N, H, W, Co, generator=gen).to(torch.bfloat16))
+    old = ops.View.alloc(N, H, W, Co)
+    old.tensor().copy_(torch.randn(N, H, W, Co, generator=gen).to(torch.bfloat16))
+    stream = torch.cuda.current_stream().cuda_stream
+    wb = (Co + 31) // 32 * 4
+    ldb = wb + 4
+
+    def variants(y, bits):
+        return {
+            "residual": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17),
+            "residual_bits": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, epilogue=ops.EPI_RESIDUAL, relu=1, shift=sh, skip=skip, rscale=0.17, relu_bits=bits),
+            "residual_norelu": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, epilogue=ops.EPI_RESIDUAL, relu=0, shift=sh, skip=skip, rscale=1.0),
+            "acc_mask": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, accumulate=1, skip=skip, acc_src=old, rscale=0.2),
+            "acc_bits": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, accumulate=1, acc_src=old, relu_bits=bits),
+            "acc_only": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, accumulate=1, acc_src=old),
+            "mask_only": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, skip=skip),
+            "bits_only": ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, relu_bits=bits, rscale=0.3),
+        }
+    gbits = torch.randint(0, 256, (M, ldb), dtype=torch.uint8, generator=gen).cuda()
+    for kind in ("residual", "residual_bits", "residual_norelu", "acc_mask", "acc_bits", "acc_only", "mask_only", "bits_only"):
+        res = []
+        for cfg in (0, ops.PWRES_TILE_CONFIG):
+            y = ops.View.alloc(N, H, W, Co + 16, zero=True).slice(8, Co)
+            bits = torch.full((M, ldb), 0xA5, dtype=torch.uint8, device="cuda") if kind == "residual_bits" else gbits.clone()
+            d = variants(y, bits)[kind]
+            d.tile_config = cfg
+            if cfg and kind in ("acc_mask", "acc_only", "mask_only"):
+                assert l.mbx_conv_supported(C.byref(d)) == -2, (kind, cfg)      # (it masks by the sign bits only)
+                res.append(res[0])
+                continue
+            assert l.mbx_conv_supported(C.byref(d)) == 0, (kind, cfg)
+            assert l.mbx_conv(C.byref(d), stream) == 0
+            torch.cuda.synchronize()
+            full = y.buf.reshape(N, H, W, Co + 16)
+            assert float(full[..., :8].abs().max()) == 0 and float(full[..., 8 + Co:].abs().max()) == 0
+            res.append((y.tensor().clone(), bits.clone()))
+        assert torch.equal(res[0][0], res[1][0]), "%s %s: %g" % (name, kind, float((res[0][0].float() - res[1][0].float()).abs().max()))
+        assert torch.equal(res[0][1], res[1][1]), "%s %s: bits" % (name, kind)
+        assert float(res[1][0].float().abs().max()) > 0
+    # what it does not apply to is refused: statistics, a plain store, 3x3
+    y = ops.View.alloc(N, H, W, Co, zero=True)
+    d = ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y)
+    d.tile_config = ops.PWRES_TILE_CONFIG
+    assert l.mbx_conv_supported(C.byref(d)) == -2
+    d = ops.make_desc(xb, wd, Co, 1, 1, 1, 0, 0, y, stats=torch.zeros((M, Co, 2), device="cuda"))
+    d.tile_config = ops.PWRES_TILE_CONFIG
+    assert l.mbx_conv_supported(C.byref(d)) == -2
+
+
 def test_conv_f32_head_output(T):
     """model.py:213-219: 1x1, no BN/bias/act, C_out = 5k = 25 (locations 4k + confidences k), fp32 out."""
     torch = T
