@@ -47,8 +47,10 @@ def _prune(logdir, max_to_keep, keep_every_n_hours, now=None):
 def save(logdir, trainer, max_to_keep=3, keep_checkpoint_every_n_hours=10000.0):
     net = trainer.net
     os.makedirs(logdir, exist_ok=True)
-    path = os.path.join(logdir, "model.ckpt-%d.pt" % trainer.global_step)
-    state = dict(global_step=trainer.global_step, k=net.k, input_size=net.S,
+    # (only APPLIED steps count: steps skipped since the trainer's last health check are taken off here without touching its state)
+    gstep = trainer.applied_global_step() if hasattr(trainer, "applied_global_step") else trainer.global_step
+    path = os.path.join(logdir, "model.ckpt-%d.pt" % gstep)
+    state = dict(global_step=gstep, k=net.k, input_size=net.S,
                  index={n: (b, o, tuple(s), c) for n, (b, o, s, c) in net.param_index.items()},
                  W=net.W.cpu(), Bt=net.Bt.cpu(), MM=net.MM.cpu(), MV=net.MV.cpu(),
                  Wms=trainer.Wms.cpu(), Btms=trainer.Btms.cpu(),

@@ -1112,8 +1112,7 @@ splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice
         for (int r = 0; r < kSplitRows; ++r) { x1 += red[r][tid][0]; x2 += red[r][tid][1]; }
         if (stats_mod) {                              // (fixed-point integer adds: stats_write, conv_common.h)
           unsigned long long* o = reinterpret_cast<unsigned long long*>(stats) + ((size_t)((int)blockIdx.x % stats_mod) * stats_ld + cb + tid) * 2;
-          atomicAdd(o, (unsigned long long)__float2ll_rn(x1 * kStatsFix));
-          atomicAdd(o + 1, (unsigned long long)__float2ll_rn(x2 * kStatsFix));
+          stats_add_fixed(o, x1, x2);
         } else {
           float* o = stats + ((size_t)blockIdx.x * stats_ld + cb + tid) * 2;
           o[0] = x1;

@@ -131,11 +131,26 @@ __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigne
 // the tiles arrive and the forward pass stays bit-reproducible (float atomics made it differ from run to run in the last
 // bits of every mean, which a chaotic network amplifies).  Fire and forget, performed at the memory side.
 constexpr float kStatsFix = 1048576.f;                  // 2^20
+// OUT OF RANGE.  The conversion is defined for |x| 2^20 < 2^63 only, and a row that sums a few hundred tiles
+// must stay below that as well: a tile sum that is not finite or not below kStatsMax (2^41: 2^61 in fixed point -- reachable:
+// `--fine_tune` straight after a fresh start feeds activations of ~1e16 into the training-mode head batch norms) POISONS
+// its channel instead of wrapping into finite garbage: the sum-of-squares word, never negative otherwise, is forced to the
+// most negative integer by a signed atomic MIN, which no later add of a legitimate (< 2^61) value can bring back above zero
+// and which wins whatever the order of arrival.  The consumer (bn_apply_rows_kernel) turns a negative word into NaN mean / rstd:
+// the activations, the loss and the matching status go non-finite exactly as with the float32 rows -- loud, not silent.
+constexpr float kStatsMax = 2199023255552.f;            // 2^41
+__device__ __forceinline__ void stats_add_fixed(unsigned long long* o, const float x1, const float x2) {
+  if (__builtin_fabsf(x1) < kStatsMax && __builtin_fabsf(x2) < kStatsMax) {          // (false for NaN / inf as well)
+    atomicAdd(o, (unsigned long long)__float2ll_rn(x1 * kStatsFix));
+    atomicAdd(o + 1, (unsigned long long)__float2ll_rn(x2 * kStatsFix));
+  } else {
+    atomicMin(reinterpret_cast<long long*>(o + 1), (long long)0x8000000000000000ull);
+  }
+}
 __device__ __forceinline__ void stats_write(const ConvK& p, const int tile_row, const int ch, const float x1, const float x2) {
   if (p.stats_mod) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + ((size_t)(tile_row % p.stats_mod) * p.stats_ld + ch) * 2;
-    atomicAdd(o, (unsigned long long)__float2ll_rn(x1 * kStatsFix));
-    atomicAdd(o + 1, (unsigned long long)__float2ll_rn(x2 * kStatsFix));
+    stats_add_fixed(o, x1, x2);
   } else {
     float* o = p.stats + ((size_t)tile_row * p.stats_ld + ch) * 2;
     o[0] = x1;

@@ -440,21 +440,28 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
     // the rows are 64-bit fixed-point sums (2^-20 units) added by integer atomics: exact integer sum, then one conversion
     const longlong2* src = reinterpret_cast<const longlong2*>(part) + ch;
     long long i1 = 0, i2 = 0;
+    bool bad = false;
     int r = 0;
     for (; r + 3 < rows; r += 4) {                        // four rows' loads in flight
       const longlong2 v0 = src[(size_t)(r + 0) * C], v1 = src[(size_t)(r + 1) * C], v2 = src[(size_t)(r + 2) * C], v3 = src[(size_t)(r + 3) * C];
       i1 += (v0.x + v1.x) + (v2.x + v3.x);
       i2 += (v0.y + v1.y) + (v2.y + v3.y);
+      bad |= ((v0.y | v1.y) | (v2.y | v3.y)) < 0;
     }
     for (; r < rows; ++r) {
       const longlong2 v = src[(size_t)r * C];
       i1 += v.x; i2 += v.y;
+      bad |= v.y < 0;
     }
     const double s1 = (double)i1 * (1.0 / 1048576.0), s2 = (double)i2 * (1.0 / 1048576.0);
     const double mu = s1 * inv_count;
     double var = s2 * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
-    const float fm = (float)mu, fr = (float)(1.0 / sqrt(var + (double)eps)), be = beta[ch];
+    // a negative sum of squares = a tile sum was out of the fixed-point range or not finite (stats_add_fixed, conv_common.h):
+    // the channel's statistics are NaN, as the float32 rows would have made them (inf - inf), never finite garbage
+    const bool poisoned = bad;
+    if (poisoned) var = (double)__builtin_nanf("");
+    const float fm = poisoned ? __builtin_nanf("") : (float)mu, fr = poisoned ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps)), be = beta[ch];
     s_par[ch] = fm; s_par[C + ch] = fr; s_par[2 * C + ch] = be;
     if (blockIdx.x == 0) {
       mean[ch] = fm; rstd[ch] = fr;

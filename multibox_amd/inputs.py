@@ -136,11 +136,21 @@ class _DecodePool:
     def __init__(self, processes, slots=160, slot_bytes=3 << 19):
         import multiprocessing as mp
         import queue
+        import shutil
         from concurrent.futures import ProcessPoolExecutor
         from multiprocessing import shared_memory
+        # the block lives in /dev/shm: size it from what is free there (the 64 MB default of many containers holds 40 slots,
+        # not 160 -- a worker writing past it would die of SIGBUS, not fall back); fewer slots only mean more pictures
+        # decoded in this process
+        try:
+            avail = shutil.disk_usage("/dev/shm").free
+            slots = min(int(slots), max(1, int(0.5 * avail) // int(slot_bytes)))
+        except OSError:
+            pass
         self.slot_bytes, self.slots, self._closing = int(slot_bytes), int(slots), False
         self.shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
         self.free = queue.SimpleQueue()
+        self.out = {}                                           # slot -> its decode future, until result() has taken it
         for i in range(int(slots)):
             self.free.put(i)
         self.pool = ProcessPoolExecutor(max_workers=int(processes), mp_context=mp.get_context("spawn"),
@@ -152,16 +162,26 @@ class _DecodePool:
             slot = self.free.get_nowait()
         except Exception:                                       # (queue.Empty) every slot is referenced: decode here, later
             return (None, jpeg_bytes)
-        return (slot, self.pool.submit(_decode_into_shm, slot * self.slot_bytes, self.slot_bytes, jpeg_bytes), jpeg_bytes)
+        try:
+            fut = self.pool.submit(_decode_into_shm, slot * self.slot_bytes, self.slot_bytes, jpeg_bytes)
+        except Exception:                                       # (BrokenProcessPool: a worker died) decode in this process
+            self.free.put(slot)
+            return (None, jpeg_bytes)
+        self.out[slot] = fut
+        return (slot, fut, jpeg_bytes)
 
     def result(self, handle):
         import weakref
         if handle[0] is None:
             return decode_image_u8(handle[1])
         slot, fut, jpeg_bytes = handle
-        hw = fut.result()
+        self.out.pop(slot, None)
+        try:
+            hw = fut.result()
+        except Exception:                                       # a failed / cancelled decode: the slot comes back, the picture is decoded here
+            hw = None
         if hw is None:                                          # larger than a slot
-            self.free.put(slot)
+            self._release(slot)
             return decode_image_u8(jpeg_bytes)
         arr = np.ndarray((hw[0], hw[1], 3), np.uint8, buffer=self.shm.buf, offset=slot * self.slot_bytes)
         # views of `arr` keep it alive through .base; the bound method keeps THIS object -- and with it the mapping -- alive
@@ -175,13 +195,18 @@ class _DecodePool:
             self.shm.close()
 
     def close(self):
-        """Stop the workers and remove the block's name; the mapping itself goes when the last picture does."""
+        """Stop the workers and remove the block's name; the mapping itself goes when the last picture does.  Slots whose
+        decode was still pending (an early exit of the consumer: their futures are cancelled and result() never comes) are
+        handed back here -- without that the count never reached `slots` and the mapping leaked."""
         self.pool.shutdown(wait=True, cancel_futures=True)
         try:
             self.shm.unlink()
         except FileNotFoundError:
             pass
         self._closing = True
+        for slot in list(self.out):
+            self.out.pop(slot, None)
+            self.free.put(slot)
         if self.free.qsize() >= self.slots:
             self.shm.close()
 

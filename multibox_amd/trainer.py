@@ -184,6 +184,29 @@ class Trainer:
         host synchronisation (train.py used to all-reduce an `ok` flag and read it back before every step)."""
         self._stop_flag.fill_(1.0)
 
+    def fold_skipped(self, **note):
+        """Take the steps the optimiser did NOT apply (flagged step control word: counted on the device, the same number on
+        every rank) off global_step -- one host read of the counter, no collective.  check_health() does it every
+        LOG_EVERY_N_STEPS; train.py also calls it in front of every checkpoint save, so that a checkpoint never names or
+        stores a step count that includes unapplied steps.  Returns the number folded."""
+        sk = getattr(self, "skipped_steps", None)
+        skipped = (int(sk) - self._skipped_seen) if sk is not None else 0
+        if skipped:
+            self._skipped_seen += skipped
+            ev = {"event": "skipped_steps", "count": skipped, "global_step_before": self.global_step,
+                  "global_step": self.global_step - skipped}
+            ev.update(note)
+            self.events.append(ev)
+            self.global_step -= skipped                # only applied steps count
+        return skipped
+
+    def applied_global_step(self):
+        """global_step without the steps the optimiser skipped since the last fold -- a host read of the device counter that
+        changes NOTHING (rank 0's time-triggered checkpoint must not move its global_step ahead of the other ranks': the
+        health check that folds the count is a collective every rank enters at the same global_step)."""
+        sk = getattr(self, "skipped_steps", None)
+        return self.global_step - ((int(sk) - self._skipped_seen) if sk is not None else 0)
+
     def check_health(self):
         """Host sync; call it at logging intervals.  Verdict over ALL ranks on the steps since the last call:
           * matching failed (non-finite predictions / more boxes than predictions; the reference's py_func raises there,
@@ -210,13 +233,7 @@ class Trainer:
             if dist.get_world_size(self.pg) > 1:
                 dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.pg)
         t, m, w, stop = (int(v) for v in bad.tolist())
-        sk = getattr(self, "skipped_steps", None)
-        skipped = (int(sk) - self._skipped_seen) if sk is not None else 0
-        if skipped:
-            self._skipped_seen += skipped
-            self.events.append({"event": "skipped_steps", "count": skipped, "global_step_before": self.global_step,
-                                "global_step": self.global_step - skipped, "stop_requested": bool(stop), "barrier_timeouts": t})
-            self.global_step -= skipped                # only applied steps count
+        self.fold_skipped(stop_requested=bool(stop), barrier_timeouts=t)
         if stop:
             return {"stop": True, "fallback": False}
         if m:

@@ -310,6 +310,63 @@ def test_conv_stats_atomic_rows(T, g, cfg):
     assert torch.allclose(outs[1][5], thr_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [0, 33, 96, 98])
+def test_conv_stats_fixed_point_out_of_range_poisons(T, cfg):
+    """the 64-bit fixed-point statistics rows (stats_rows_mod > 0) are exact while a tile sum stays
+    below 2^41; beyond that -- activations of ~1e8 and ~1e16, as `--fine_tune` straight after a fresh start produces them, or
+    a NaN -- the conversion used to wrap into FINITE garbage.  Now: in range (inputs ~1e3) the one-launch consumer agrees with
+    finalize on the float32 rows; out of range the channel is POISONED (negative sum-of-squares word) and
+    mbx_bn_apply_fused_mapped returns NaN mean / rstd / activations for it -- never finite values that are wrong -- whatever
+    kernel family wrote the rows (implicit GEMM, persistent, direct, resident image); the other channels stay exact."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    g = {0: ("s", 3, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), 33: ("s", 3, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
+         96: ("s", 2, 150, 150, 32, 32, 3, 3, 1, (1, 1, 1, 1)), 98: ("s", 40, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3))}[cfg]
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    M = N * Ho * Wo
+    stream = torch.cuda.current_stream().cuda_stream
+    x, w = make_case(torch, g, seed=5)
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    beta = torch.zeros(Co, device="cuda")
+    for scale, hot in ((1e3, None), (1e8, 5), (1e16, 5), (float("nan"), 5)):
+        xs = x.clone()
+        if hot is None:
+            xs *= scale
+        else:
+            # only the weights of output channel `hot` see the huge / NaN values: input channel 0 is large, its weight non-zero there
+            xs[..., 0] = scale if scale == scale else float("nan")
+            wz = w.clone(); wz[:, :, :, 0] = 0.0; wz[hot, :, :, 0] = 1.0
+            wd = wz.to(torch.bfloat16).cuda().contiguous()
+        xb = ops.View.alloc(N, H, W, Ci)
+        xb.tensor().copy_(xs.to(torch.bfloat16))
+        yb = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+        table = torch.zeros((8, Co, 2), dtype=torch.int64, device="cuda")
+        d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=table, stats_rows_mod=8, stats_ld=Co)
+        d.tile_config = cfg
+        assert l.mbx_conv_supported(C.byref(d)) == 0
+        ops.conv(d)
+        mean, rstd = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        a = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+        assert l.mbx_bn_apply_fused_mapped(table.data_ptr(), 8, M, 0.001, -1.0, yb.ptr, M, Co, beta.data_ptr(), 0, a.ptr, a.ld,
+                                           None, mean.data_ptr(), rstd.data_ptr(), None, None, None, stream) == 0
+        torch.cuda.synchronize()
+        y64 = yb.tensor().double().reshape(M, Co)
+        want_mean = y64.mean(0)
+        want_rstd = 1.0 / torch.sqrt(y64.var(0, unbiased=False) + 0.001)
+        ok = torch.ones(Co, dtype=torch.bool, device="cuda")
+        if hot is not None:
+            ok[hot] = False
+            assert bool(torch.isnan(mean[hot])) and bool(torch.isnan(rstd[hot])), (scale, float(mean[hot]), float(rstd[hot]))
+            assert bool(torch.isnan(a.tensor().float()[..., hot]).all())
+            assert int(table[:, hot, 1].min()) < 0
+        assert torch.allclose(mean[ok].double(), want_mean[ok], rtol=1e-4, atol=1e-4 * float(want_mean[ok].abs().max()))
+        assert torch.allclose(rstd[ok].double(), want_rstd[ok], rtol=1e-4)
+        assert bool(torch.isfinite(a.tensor().float()[..., ok]).all())
+
+
 @pytest.mark.parametrize("g", [("w1", 3, 35, 35, 32, 32, 3, 3, 1, (1, 1, 1, 1)), ("w2", 2, 35, 35, 32, 48, 3, 3, 1, (1, 1, 1, 1)),
                                ("w3", 2, 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1)), ("w4", 2, 35, 35, 64, 48, 3, 3, 1, (1, 1, 1, 1)),
                                ("w5", 3, 35, 35, 48, 32, 3, 3, 1, (1, 1, 1, 1)), ("w6", 2, 19, 17, 32, 40, 3, 3, 1, (0, 0, 0, 0)),

@@ -245,10 +245,8 @@ def test_stagewise_gradients(env):
         assert worst[0] > 0.985 and worst[1] < 0.2, report
 
 
-def test_head_gradients_tight(env):
-    """Heads only (2-3 layers): the oracle heads are fed the ENGINE's features, so the comparison is
-    not polluted by the chaotic backbone; cosine > 0.99, rel L2 < 0.15 (typically 0.006), d(features) too."""
-    torch, net = env["torch"], env["net"]
+def _head_gradients(env, net, bound):
+    torch = env["torch"]
     from oracle.torch_model import Model, q_bf16, multibox_loss
     from oracle import ref_numpy as R
     from multibox_amd.loss import MultiboxLoss
@@ -287,12 +285,33 @@ def test_head_gradients_tight(env):
         # without the atomic statistics, any tile configuration): 0.017-0.088 on ONE parameter of a head whose batch norm sees
         # 8-128 samples at batch 2 -- a bf16 rounding of a gradient that flips with the order of the float atomics upstream,
         # amplified by the cancellation in rstd (g - mean g - xhat mean(g xhat)) over so few samples; the cosine stays > 0.995.
-        assert _cos(g_eng, g_ref) > 0.99 and rel_l2(g_eng, g_ref) < 0.15, (n, _cos(g_eng, g_ref), rel_l2(g_eng, g_ref))
+        assert _cos(g_eng, g_ref) > 0.99 and rel_l2(g_eng, g_ref) < bound, (n, _cos(g_eng, g_ref), rel_l2(g_eng, g_ref))
         checked += 1
     print("head gradients: worst rel-L2", worst)
     assert checked >= 25
     dfeat = net._gview(net.features).tensor().float().cpu().permute(0, 3, 1, 2)
     assert _cos(dfeat, feat.grad) > 0.99 and rel_l2(dfeat, feat.grad) < 8e-2
+
+
+def test_head_gradients_tight(env):
+    """Heads only (2-3 layers): the oracle heads are fed the ENGINE's features, so the comparison is not polluted by the
+    chaotic backbone; cosine > 0.99, d(features) too.  Shipped configuration (float atomics in the backward pass: their
+    order moves a bf16 rounding upstream of a batch norm that sees 8-128 samples): rel L2 < 0.15, typically 0.006."""
+    _head_gradients(env, env["net"], 0.15)
+
+
+def test_head_gradients_tight_deterministic(env, monkeypatch):
+    """The same check where nothing depends on an order of arrival (MBX_DETERMINISTIC=1: three-launch batch-norm backward,
+    un-split weight-gradient tiles, float32 statistics rows): the bound is the tight one, rel L2 < 8e-2."""
+    torch = env["torch"]
+    from multibox_amd.engine import Net
+    monkeypatch.setenv("MBX_DETERMINISTIC", "1")
+    torch.manual_seed(0)
+    net = Net(batch=env["B"], input_size=299, k=5, mode="train")
+    assert net.deterministic
+    net.W.copy_(env["net"].W); net.Bt.copy_(env["net"].Bt)
+    net.refresh_bf16()
+    _head_gradients(env, net, 8e-2)
 
 
 def test_train_steps_graph_equals_eager(env):
@@ -316,7 +335,8 @@ def test_train_steps_graph_equals_eager(env):
         assert losses[0][2] > 0 and abs(losses[0][3] - sum(losses[0][:3])) < 1e-3 * abs(losses[0][3])
         res.append((losses, net.W.clone(), tr.Wema.clone()))
     # graph replay runs the same kernels on the same data: the first step's losses are identical (the forward pass is
-    # bit-reproducible: statistics rows are written, not added; the MBX_ATOMIC_STATS=1 option gives that up);
+    # bit-reproducible: the statistics rows are added with 64-bit fixed-point INTEGER atomics, which commute -- the default since
+    # round 4; MBX_ATOMIC_STATS=0 writes a float32 row per tile instead);
     # later steps differ only through the order of fp32 atomics in wgrad (chaotic at batch 2).
     assert np.allclose(res[0][0][0][:2], res[1][0][0][:2], rtol=1e-6), (res[0][0][0], res[1][0][0])
     assert np.isclose(res[0][0][0][2], res[1][0][0][2], rtol=1e-4)          # regulariser: float atomics order

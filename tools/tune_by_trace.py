@@ -88,7 +88,13 @@ def main():
     # every launch gets its own block of work counters for the candidate passes (igemm7 wants 32)
     big = torch.zeros(max(len(reg) * ops.I7_COUNTERS, 8), dtype=torch.int32, device="cuda")
     net.i5_counters, net._i5_used = big, big.numel()
-    net._fwd_clear = big                                   # (what Net.forward() clears at the start of every pass)
+    # What Net.forward() clears at the start of every pass must cover BOTH the tool's counters and the statistics rows the
+    # convolutions ADD into (net.stats16, a view of the net's own _fwd_clear): with only `big` swapped in, the rows were never
+    # zeroed and every candidate pass normalised by statistics accumulated over all the passes before it.
+    class _ClearBoth:
+        def __init__(self, a, b): self.a, self.b = a, b
+        def zero_(self): self.a.zero_(); self.b.zero_(); return self
+    net._fwd_clear = _ClearBoth(big, net._fwd_clear)
     orig_conv, orig_bn = l.mbx_conv, l.mbx_bn_apply_fused
     state = {"cand": None, "rows": None, "calls": []}
 

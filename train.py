@@ -145,7 +145,8 @@ def main():
             images, gt, n = synthetic_batch(cfg.BATCH_SIZE, cfg.INPUT_SIZE, cfg.MAX_NUM_BBOXES, seed=tr.global_step * world + rank)
             tr.set_batch(torch.from_numpy(images).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(n).cuda())
         tr.step()
-        if tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:       # (a collective: the same steps on every rank)
+        log_now = tr.global_step % cfg.LOG_EVERY_N_STEPS == 0  # (decided BEFORE the health check takes skipped steps off global_step)
+        if log_now:                                           # (a collective: the same steps on every rank)
             # every rank: matching status (py_func error -> abort, loss.py:82), barrier timeouts (-> in-process fall-back
             # to the three-launch BN backward), weight-gradient work tallies, stop requests
             health = tr.check_health()
@@ -160,7 +161,7 @@ def main():
                 if world > 1:
                     torch.distributed.destroy_process_group()
                 raise SystemExit("input exhausted on at least one rank; stopped at step %d (applied steps)" % tr.global_step)
-        if rank == 0 and tr.global_step % cfg.LOG_EVERY_N_STEPS == 0:
+        if rank == 0 and log_now:
             loc, conf, reg, total = tr.losses()
             now = time.time()
             ips = cfg.BATCH_SIZE * world * (tr.global_step - step0) / (now - t_log) if now > t_log else 0.0
@@ -175,6 +176,7 @@ def main():
             t_save = time.time()
     if real is not None:
         real.close()                                              # stop the input worker processes
+    tr.fold_skipped()
     if rank == 0:
         print("saved", CK.save(args.logdir, tr, cfg.MAX_TO_KEEP, cfg.get("KEEP_CHECKPOINT_EVERY_N_HOURS", 10000.0)))
     if world > 1:
