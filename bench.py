@@ -262,8 +262,10 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     `event_ms` the HIP-event figure), else from the HIP events."""
     for cls, o in classes.items():
         o["event_ms"] = o["ms"]
+        o["traced_launches"] = None
         if traced is not None and cls in traced:
             o["ms"] = traced[cls][0]
+            o["traced_launches"] = traced[cls][1]
     kernels = []
     for cls, o in sorted(classes.items()):
         if o["ms"] <= 0 or o["work"] <= 0:
@@ -278,10 +280,18 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
+    # The tracer can DROP events (round 4's step trace had a 3 ms hole): time summed over fewer launches than the eager pass
+    # counted would print an inflated fraction.  The traced launch count per step must equal the eager call count -- pair
+    # launches are ONE traced kernel for TWO counted calls, split-K is one counted call for slices + reduce: the count of
+    # traced kernels may differ from the calls by those, so the check is on what is comparable: never FEWER traced kernels
+    # than calls minus the pair launches, and the frac is withheld (null) when it is.
+    tl = d.get("traced_launches")
+    traced_ok = traced is None or tl is None or tl >= d["calls"] - d.get("pair_calls", 0) - 0.5
     main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_stem_kernel (convolution on MFMA: forward + data-gradient launches)",
-            "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-            "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
+            "achieved": round(ach, 2) if traced_ok else None, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if traced_ok else None, "traffic": traffic, "traffic_source": src,
+            "launches_per_step": d["calls"], "traced_launches_per_step": (round(tl, 2) if tl is not None else None),
+            "traced_complete": bool(traced_ok), "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
             "ms_per_step": round(d["ms"], 3),
             "timing": ("kernel begin/end timestamps of 3 real (graph-replayed) steps, recorded live by the ROCm tracer via "
                        "torch.profiler: the timestamps of a rocprofv3 kernel trace (profiles/r04_bench_b64_kernel_stats.csv)"

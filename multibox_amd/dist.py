@@ -31,7 +31,7 @@ class BucketReducer:
 
     def reduce_async(self, flat, lo, hi):
         """Start SUM all-reduce of flat[lo:hi] (in place)."""
-        if self.enabled and hi > lo:
+        if self.enabled and hi > lo and not os.environ.get("MBX_DP_NO_ALLREDUCE"):       # (A/B knob: the form of the step without the collectives)
             self.works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def wait(self):

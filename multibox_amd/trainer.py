@@ -103,7 +103,12 @@ class Trainer:
             # without a process group the segments are not buckets: ONE backward segment = one grouped weight-gradient launch
             # for the whole network (longest-first over every layer, one launch tail instead of four) and one captured graph
             # for the whole step -- 16.54 -> 16.29 ms against four segments, same box (8 segments: 16.78)
-            n_segments = int(os.environ.get("MBX_DP_SEGMENTS", "4")) if self.reducer.enabled else int(os.environ.get("MBX_SEGMENTS", "1"))
+            # (round 5: TWO buckets of ~117 MB + the 6.7 MB tail instead of four of 60 MB.  On one rank, collectives switched off
+            # (MBX_DP_NO_ALLREDUCE=1), the bucketed form of the step costs +0.03 ms with one segment, +0.15 with 2 + tail, +0.25 with
+            # 4 + tail against the single-GPU step -- each segment is one more grouped weight-gradient launch and one more graph;
+            # by the xGMI estimate of dist.py a 117 MB bucket takes ~0.8 ms at 8 ranks and the first is ready with half of the
+            # backward pass still to run: tools/dp_ab.sh, profiles/r05_dp_form_ab.txt)
+            n_segments = int(os.environ.get("MBX_DP_SEGMENTS", "2")) if self.reducer.enabled else int(os.environ.get("MBX_SEGMENTS", "1"))
             tail = int(os.environ.get("MBX_DP_TAIL_PARAMS", "2000000")) if self.reducer.enabled else 0      # (A/B knobs)
             if self.overlap_cus and not self.reducer.enabled:
                 n_segments, by_work = int(os.environ.get("MBX_WG_GROUPS", "8")), True
@@ -329,6 +334,7 @@ class Trainer:
         step: the BN moving statistics it touched are put back (the captured step that follows would otherwise apply this
         batch's moving-average update twice -- at the first step and after every in-process re-capture)."""
         net = self.net
+        self._front_merged = False
         mm, mv = net.MM.clone(), net.MV.clone()
         self._front()
         for i in range(len(self._segments)):
@@ -391,9 +397,14 @@ class Trainer:
                 self._run_segment(0)
             self.graphs = [g]
             return
+        # data-parallel form without overlapped weight gradients: graph 0 = forward + loss + segment 0, graph i = segment i --
+        # one graph per gradient bucket (round 4 replayed the forward pass as a graph of its own: one more launch gap)
+        self._front_merged = not K
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, **mode):
             self._front()
+            if self._front_merged:
+                self._run_segment(0)
         graphs.append(g)
         if K:
             # data-parallel form: graph i = chain of segment i BESIDE the weight gradients of segment i-1 (joined at its end,
@@ -412,7 +423,7 @@ class Trainer:
                         join()
                 graphs.append(g)
         else:
-            for i in range(nseg):
+            for i in range(1, nseg):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, **mode):
                     self._run_segment(i)
@@ -439,6 +450,11 @@ class Trainer:
                     g.replay()
                     if i > 0:
                         reduce(i - 1, *self._segments[i - 1][1:])
+            elif getattr(self, "_front_merged", False) and len(self.graphs) == len(self._segments):
+                reduce(0, *self._segments[0][1:])              # (graph 0 held segment 0)
+                for i, (g, (_, lo, hi)) in enumerate(zip(self.graphs[1:], self._segments[1:]), start=1):
+                    g.replay()
+                    reduce(i, lo, hi)
             else:
                 for i, (g, (_, lo, hi)) in enumerate(zip(self.graphs[1:], self._segments)):
                     g.replay()

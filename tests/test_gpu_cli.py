@@ -99,6 +99,40 @@ def test_train_then_detect(tmp_path):
     assert os.path.exists(log2 / "model.ckpt-1.pt")
 
 
+def test_finetune_after_fresh_start_is_handled_cleanly(tmp_path):
+    """the SAME two runs with the reference's own BATCHNORM_MOVING_AVERAGE_DECAY (0.9997) and learning rate
+    (0.01, train.py defaults): three steps from a random start, then `--fine_tune` on moving statistics that are still (0, 1) --
+    activations of ~1e16 reach the training-mode head batch norms (outside the fixed-point range of the statistics rows) and
+    the step's losses are 1e32 .. inf.  Whatever the three chaotic steps made of it, the run must end in ONE of two clean
+    ways -- a logged step whose loss is a float (huge or inf, never a NaN disguised as a finite number), or the reference's
+    own failure mode, the matcher's error (loss.py:82: the py_func raises on non-finite predictions) -- and a checkpoint
+    that an inference run can still read.  Never a hang, a crash without message, or finite garbage."""
+    import __graft_entry__ as g
+    g.build()
+    from multibox_amd import priors as PR
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CFG.replace("BATCHNORM_MOVING_AVERAGE_DECAY : 0.3", "BATCHNORM_MOVING_AVERAGE_DECAY : 0.9997")
+                   .replace("INITIAL_LEARNING_RATE : 0.00001", "INITIAL_LEARNING_RATE : 0.01"))
+    pri = tmp_path / "priors.pkl"
+    PR.save_priors(str(pri), PR.generate_priors([1, 2, 3, 1 / 2., 1 / 3.]))
+    logdir = tmp_path / "log"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(logdir),
+                        "--config", str(cfg), "--max_number_of_steps", "3", "--synthetic"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--priors", str(pri), "--logdir", str(logdir),
+                        "--config", str(cfg), "--max_number_of_steps", "4", "--synthetic", "--fine_tune"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    log = [json.loads(l) for l in open(logdir / "train_log.jsonl") if "total_loss" in l]
+    if r.returncode == 0:
+        assert len(log) == 4 and isinstance(log[3]["total_loss"], float), log[-1]
+        assert not np.isnan(log[3]["location_loss"]) or not np.isfinite(log[3]["total_loss"]), log[3]
+    else:
+        assert "bipartite matching failed" in (r.stdout + r.stderr), r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(logdir / "model.ckpt-3.pt")
+
+
 @pytest.mark.parametrize("on_device", ["true", "false"])
 def test_train_from_tfrecords_with_input_workers(tmp_path, on_device):
     """train.py --tfrecords: JPEG records -> NUM_INPUT_THREADS worker processes (multibox_amd/input_workers.py) ->
