@@ -1428,8 +1428,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   {  // debug build (MBX_BUILD_DEFS=-DMBX_I5_STAMPS): MBX_I5_STAMP_PTR = device address of 64 x 8 x 4 uint64 (tools/i5_stamps.py)
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
     k.stamps = reinterpret_cast<unsigned long long*>(sp);
-    static const int dbg5 = getenv("MBX_I5_DBG") ? atoi(getenv("MBX_I5_DBG")) : 0;
-    k.dbg = dbg5;
+    k.dbg = getenv("MBX_I5_DBG") ? atoi(getenv("MBX_I5_DBG")) : 0;      // (read per call: tools switch it between launches)
   }
 #endif
   for (int c = 0; c < 4; ++c) { k.cls_m0[c] = 0; k.cls_hw[c] = 1; k.cls_w[c] = 1; }

@@ -424,102 +424,50 @@ conv_resident_kernel(const ConvK p, const ResK q) {
 // for block17, whatever else holds CUs.  Same K order and MFMA grouping as every implicit-GEMM tile, the shared epilogue
 // (conv_common.h): bit-identical results.
 struct PwK {
-  int npt, NCS, nct, ctper, nunits;                       // pixel tiles (80 pixels), column splits, column tiles (128 channels), column tiles per split
+  int npt, NCS, nct, ctper, nunits;                       // pixel tiles, column splits, column tiles (128 channels), column tiles per split
   int npi;                                                // 1 KB pieces of the resident pixel tile
 };
-constexpr int kPwPix = 80, kPwMI = 5, kPwCol = 128;
-constexpr int kPwThreads = 768, kPwCW = 8;                // waves 0-3 / 4-7: the two multiplying groups; 8-11: loaders
+constexpr int kPwCol = 128;
 
-// Vector-memory READS of the multiplying waves as inline asm, waited for by hand.  The compiler's own s_waitcnt insertion is
-// exact inside straight-line code but CONSERVATIVE across a loop's back edge: for epilogue operands fetched one column tile
-// ahead it waited for everything outstanding -- the previous tile's stores and the next tile's reads included -- which is the
-// serialisation this kernel exists to remove.  Loads the compiler does not see are never waited for by it; pw_wait<N>
-// (s_waitcnt vmcnt(N), N = the stores issued since) names every destination register, so their uses stay behind it.
-__device__ __forceinline__ u32x4 pw_rsrc(const void* ptr, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
-  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu,
-               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
-}
-__device__ __forceinline__ void pw_load16(u32x4& dst, const u32x4 rsrc, const unsigned off) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ void pw_load1(unsigned& dst, const u32x4 rsrc, const unsigned off) {
-  asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rsrc) : "memory");
-}
-template <int EV, int N>
-__device__ __forceinline__ void pw_wait(u32x4 (&la)[kPwMI][1], u32x4 (&lb)[kPwMI][1], u32x4 (&sh)[2]) {
-  if constexpr (EV == 4) {          // (skip rows + the shift row; lb is not used)
-    asm volatile("s_waitcnt vmcnt(%7)"
-                 : "+v"(la[0][0]), "+v"(la[1][0]), "+v"(la[2][0]), "+v"(la[3][0]), "+v"(la[4][0]), "+v"(sh[0]), "+v"(sh[1])
-                 : "n"(N) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(%10)"
-                 : "+v"(la[0][0]), "+v"(la[1][0]), "+v"(la[2][0]), "+v"(la[3][0]), "+v"(la[4][0]),
-                   "+v"(lb[0][0]), "+v"(lb[1][0]), "+v"(lb[2][0]), "+v"(lb[3][0]), "+v"(lb[4][0])
-                 : "n"(N) : "memory");
-  }
-}
-// The reads of conv_epilogue_issue_reads (EV 2 / 4: same offsets, same uniform choices) and the shift row of
-// conv_epilogue_channels (EV 4; a range-checked buffer read: zeros past C_out or without a table, as there), for pixel
-// blocks 0 .. 4 of a lane whose first pixel is mlane and first channel clane.
-template <int EV>
-__device__ __forceinline__ void pw_issue_reads(const ConvK& p, const int mlane, const int clane, u32x4 (&la)[kPwMI][1], u32x4 (&lb)[kPwMI][1],
-                                               u32x4 (&sh)[2]) {
-  static_assert(EV == 2 || EV == 4, "accumulate (+ mask) / residual");
-  const u32x4 kr = pw_rsrc(p.skip, p.skip ? p.skip_bytes : 0u);
-  const u32x4 ar = pw_rsrc(p.acc_src, p.acc_bytes);
-  const u32x4 br = pw_rsrc(p.bits, p.bits ? p.bits_bytes : 0u);
-  const bool do_acc = EV == 2 && p.accumulate, do_mask = EV == 2 && p.skip != nullptr;     // (uniform)
-  const bool do_bits = EV == 2 && p.bits != nullptr;                                       // (uniform; never with do_mask)
-  const int c0 = clane;
-#pragma unroll
-  for (int b = 0; b < kPwMI; ++b) {
-    const int m = mlane + b * 16;
-    int img, pix;
-    epi_pixel<false>(p, m, img, pix);
-    const bool ok = m < p.M && c0 < p.C_out;
-    const unsigned so = ok ? (unsigned)((img * p.skip_img_stride + pix * p.ld_skip + c0) * 2) : kOOB;
-    if constexpr (EV == 2) { la[b][0] = u32x4{0u, 0u, 0u, 0u}; lb[b][0] = u32x4{0u, 0u, 0u, 0u}; }
-    if constexpr (EV == 4) {
-      pw_load16(la[b][0], kr, so);
-    } else {
-      const unsigned ao = ok ? (unsigned)((img * p.acc_img_stride + pix * p.ld_acc + c0) * 2) : kOOB;
-      if (do_acc) pw_load16(la[b][0], ar, ao);
-      if (do_mask) pw_load16(lb[b][0], kr, so);
-      if (do_bits) { unsigned byte_; pw_load1(byte_, br, ok ? (unsigned)(m * p.bits_ld + (c0 >> 3)) : kOOB); lb[b][0].x = byte_; }
-    }
-  }
-  if constexpr (EV == 4) {
-    const u32x4 sr = pw_rsrc(p.shiftv, p.shiftv ? (unsigned)p.C_out * 4u : 0u);
-    pw_load16(sh[0], sr, (unsigned)c0 * 4u);             // (C_out % 8 == 0: a lane's eight channels are all in or all out)
-    pw_load16(sh[1], sr, (unsigned)c0 * 4u + 16u);
-  }
-}
-
-template <int C8>
+// MIH: pixel blocks (of 16) per HALF of the resident pixel tile (5: 160 pixels, 4: 128 where K = 448 leaves no room for more)
+template <int C8, int MIH>
 struct PwG {
+  static constexpr int PIX = 32 * MIH;                    // pixels of a tile
   static constexpr int KC = C8 / 4;                       // K steps of 32
-  static constexpr int KS = (C8 % 8 == 0) ? 2 : 1;        // K steps per ring slot (64-deep slots where K allows)
+  static constexpr int PIX_CH = (PIX * C8 + 63) / 64 * 64;
+  // ring slots: 64-deep (16 KB) where at least three fit beside the pixel tile, else 32-deep (8 KB): what counts is the
+  // bytes in flight against the DMA's latency, and a ring of two holds one slot in flight
+  static constexpr int ROOM = 160 * 1024 / 16 - PIX_CH;
+  static constexpr int KS = (C8 % 8 == 0 && ROOM / (kPwCol * 8) >= 3) ? 2 : 1;      // K steps per ring slot
   static constexpr int NSL = KC / KS;                     // slots per column tile
   static constexpr int C8S = 4 * KS;                      // 16-byte chunks per filter row of a slot
-  static constexpr int SLOT_CH = kPwCol * C8S;            // chunks per slot (16 or 8 KB)
+  static constexpr int SLOT_CH = kPwCol * C8S;            // chunks per slot
   static constexpr int PT = SLOT_CH / (64 * kRLW);        // pieces per loader wave and slot
-  static constexpr int PIX_CH = (kPwPix * C8 + 63) / 64 * 64;
-  static constexpr int NST_RAW = (160 * 1024 / 16 - PIX_CH) / SLOT_CH;
+  static constexpr int NST_RAW = ROOM / SLOT_CH;
   static constexpr int NST = NST_RAW > 8 ? 8 : NST_RAW;   // ring depth
   static constexpr int LDS_BYTES = (NST * SLOT_CH + PIX_CH) * 16;
   static_assert(KC % KS == 0 && NST >= 3 && (NST - 1) * PT < 64, "ring");
 };
 
-template <int C8, int EV>
-__global__ void __launch_bounds__(kPwThreads)
+// conv_pwres_kernel, third form (round 5).  What the first two taught (tools/pw_stamps.py, LAB_NOTES): with an 80-pixel tile the K
+// loop of a 128-channel column tile was paced by the FOUR LOADER WAVES (96 KB of filter = 24 LDS-DMA instructions each per
+// 120 MFMAs of a multiplying wave: 2.1 us against 1.3), and a second multiplying group that wrote one tile out while the first
+// multiplied the next made every K loop 3 us -- the SIMD's instruction ISSUE is shared, and the epilogue's ~300 vector
+// instructions per tile and wave need the slots the MFMAs leave.  So: ONE group of four multiplying waves, a pixel tile twice
+// as large (2 x MIH blocks: the filter bytes per MFMA halve, the loaders keep up), multiplied in two halves per K step so
+// that the fragment registers stay those of the small tile; the epilogue's reads AND its per-channel shift row issued
+// before the K loop.
+template <int C8, int MIH, int EV>
+__global__ void __launch_bounds__(kRThreads)
 conv_pwres_kernel(const ConvK p, const PwK q) {
-  using G = PwG<C8>;
-  constexpr int KC = G::KC, KS = G::KS, NSL = G::NSL, C8S = G::C8S, SLOT_CH = G::SLOT_CH, PT = G::PT, NST = G::NST, MI = kPwMI;
-  constexpr int NI = 2, NA = 1;
+  using G = PwG<C8, MIH>;
+  constexpr int KC = G::KC, KS = G::KS, NSL = G::NSL, C8S = G::C8S, SLOT_CH = G::SLOT_CH, PT = G::PT, NST = G::NST, PIX = G::PIX;
+  constexpr int MI = 2 * MIH, NI = 2, NA = 1;
+  // (EV 2: the relu mask comes from the SIGN BITS only -- the tensor-mask path is compiled out)
+  constexpr int EVC = EV, BMODE = EV == 2 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   u32x4* const ring = smem;                               // [NST][128 rows][C8S]
-  u32x4* const pix = smem + NST * SLOT_CH;                // [80 pixels][C8] (swizzled)
+  u32x4* const pix = smem + NST * SLOT_CH;                // [PIX pixels][C8] (swizzled)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = wave_id();
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
@@ -529,20 +477,20 @@ conv_pwres_kernel(const ConvK p, const PwK q) {
 
   // the pixel tile: pieces wave, wave + 8, ...; chunk ci = row ci / C8 (pixel m0 + row), slot ci % C8 holds source chunk slot ^ key(row)
   auto issue_pixels = [&](const int m0) {
-    for (int i = wave; i < q.npi; i += kPwThreads / 64) {
+    for (int i = wave; i < q.npi; i += kRThreads / 64) {
       const int ci = i * 64 + lane;
       const int row = ci / C8, cs = ci - row * C8;
       const int c = cs ^ rkey<C8>(row);
       const int m = m0 + row;
-      const bool ok = row < kPwPix && m < p.M;
+      const bool ok = row < PIX && m < p.M;
       const int img = (int)fast_div((unsigned)(ok ? m : 0), p.mg_hw, p.sh_hw);
       glds16(xr, pix + i * 64, ok ? (img * p.x_img_stride + (m - img * p.HW_out) * p.ldx + c * 8) * 2 : (int)kOOB);
     }
   };
 
-  if (wave >= kPwCW) {
+  if (wave >= kRCW) {
     // ------------------------------------------------------------------------------------------ loader waves
-    const int lw = wave - kPwCW;
+    const int lw = wave - kRCW;
     int wo[PT], chn[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
@@ -568,7 +516,7 @@ conv_pwres_kernel(const ConvK p, const PwK q) {
         if (++si_kc == NSL) { si_kc = 0; ++si_ct; }
         si_pos = si_pos == NST - 1 ? 0 : si_pos + 1;
       };
-      issue_pixels(pt * kPwPix);
+      issue_pixels(pt * PIX);
       const int ahead = NS < NST ? NS : NST;
       for (int i = 0; i < ahead; ++i) issue_slot();
       // the pixel tile and slot 0 have retired (this wave's share), then landed
@@ -598,24 +546,16 @@ conv_pwres_kernel(const ConvK p, const PwK q) {
   }
 
   // ---------------------------------------------------------------------------------------------- multiplying waves
-  // TWO GROUPS of four (waves 0-3 and 4-7: one wave of each per SIMD) that ALTERNATE column tiles: while one group multiplies
-  // column tile i, the other converts, masks and stores tile i - 1 -- the epilogue is ~300 vector instructions and 40 KB of
-  // memory traffic per tile and wave, which on four waves alone was a third of every tile's time (stamps: K loop 2.1 us,
-  // epilogue 1.1 us) with the matrix cores idle.  One barrier per ring slot for everyone: the multiplying group's sits in its K
-  // loop, the other group's between the pixel blocks of its epilogue (whose reads were issued before ITS K loop and whose
-  // stores nobody waits for, so it never holds a barrier up for memory).
-  // (EV 2: the relu mask comes from the SIGN BITS only -- the tensor-mask path is compiled out, 128 registers hold no 20 more)
-  constexpr int EVC = EV, BMODE = EV == 2 ? 2 : 1;
-  const int grp = wave >> 2, gw = wave & 3;
   const int lds0 = lds_addr(smem);
-  int EA[NI], Ep[MI];
+  // (pixel block f = rows 16 f + frow: every row key ignores multiples of 16, so its address is block 0's + 16 f rows -- one
+  // register for all the blocks)
+  int EA[NI], Ep0;
 #pragma unroll
-  for (int a = 0; a < NI; ++a) EA[a] = rencb<C8S>(32 * gw + 16 * a + frow, fch, lds0);
-#pragma unroll
-  for (int f = 0; f < MI; ++f) Ep[f] = rencb<C8>(16 * f + frow, fch, lds0 + NST * SLOT_CH * 16);
+  for (int a = 0; a < NI; ++a) EA[a] = rencb<C8S>(32 * wave + 16 * a + frow, fch, lds0);
+  Ep0 = rencb<C8>(frow, fch, lds0 + NST * SLOT_CH * 16);
 #ifdef MBX_I5_STAMPS
-  // debug build (tools/pw_stamps.py): [block][column tile (first 8)][K loop starts, K loop done, epilogue done] of the first unit
-  const bool stamp = p.stamps && (tid & 255) == 0 && blockIdx.x < 64;
+  // debug build (tools/pw_stamps.py): [block][column tile (first 8)][K loop starts, K loop done, epilogue issued] of the first unit
+  const bool stamp = p.stamps && tid == 0 && blockIdx.x < 64;
 #define MBXP_STAMP(ci, i) do { if (stamp && u == first && (ci) < 8) p.stamps[(blockIdx.x * 8 + (ci)) * 4 + (i)] = wall_clock64(); } while (0)
 #else
 #define MBXP_STAMP(ci, i) do { } while (0)
@@ -623,108 +563,117 @@ conv_pwres_kernel(const ConvK p, const PwK q) {
   for (int u = first; u < q.nunits; u += G_) {
     const int pt = u / q.NCS, cs_ = u - pt * q.NCS;
     const int ct0 = cs_ * q.ctper, ct1 = min(ct0 + q.ctper, q.nct);
-    const int nct = ct1 - ct0;
-    const int m0 = pt * kPwPix;
+    const int m0 = pt * PIX;
     issue_pixels(m0);
     wait_vmcnt<0>();
     lds_readback_wait(lds_readback_issue(pix + lane));
     raw_barrier();                                        // P
 #pragma unroll
     for (int a = 0; a < NI; ++a) asm volatile("" : "+v"(EA[a]));       // (opaque per unit: no hoisting of every K step's address)
-#pragma unroll
-    for (int f = 0; f < MI; ++f) asm volatile("" : "+v"(Ep[f]));
-    const int mlane = m0 + frow;
-    f32x4 acc[NI][MI];
-    u32x4 la[MI][NA], lb[MI][NA];
-    // the epilogue of this group's column tile CE (local index), its MI pixel blocks dealt over the NSL slot barriers of the
-    // tile the other group multiplies meanwhile (WITH = false: the unit's last tile -- no one multiplies, no barriers are left)
-#define PW_EPILOGUE(CE, WITH)                                                                                        \
-  do {                                                                                                               \
-    const int clane_e = (ct0 + (CE)) * kPwCol + 32 * gw + 8 * fch;                                                   \
-    float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];                                                                \
-    conv_epilogue_channels<EVC, NA>(p, clane_e, sc, sh, s1, s2);                                                     \
-    _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                                             \
-      _Pragma("unroll") for (int b = 0; b < MI; ++b)                                                                 \
-        if (b >= (MI * sl) / NSL && b < (MI * (sl + 1)) / NSL)                                                       \
-          conv_epilogue_finish<EVC, false, NI, MI, 1, BMODE>(p, acc, mlane, clane_e, b, *reinterpret_cast<u32x4 (*)[1][NA]>(&la[b]), \
-                                                      *reinterpret_cast<u32x4 (*)[1][NA]>(&lb[b]), sh, sc, s1, s2);  \
-      if (WITH) raw_barrier();                                                                                       \
-    }                                                                                                                \
-  } while (0)
+    asm volatile("" : "+v"(Ep0));
     int so = 0;                                           // byte offset of the ring position being read
-    for (int ci = 0; ci < nct; ++ci) {
-      if ((ci & 1) != grp) {
-        // ---- the other group multiplies column tile ci: this group's previous tile goes out (or, at the start, nothing does)
-        if (ci > 0) { PW_EPILOGUE(ci - 1, true); MBXP_STAMP(ci - 1, 2); }
-        else {
-#pragma unroll 1
-          for (int sl = 0; sl < NSL; ++sl) raw_barrier();
-        }
-        so += NSL * SLOT_CH * 16;                         // (the ring moved on by this tile's slots)
-        while (so >= NST * SLOT_CH * 16) so -= NST * SLOT_CH * 16;
-        continue;
-      }
-      const int clane = (ct0 + ci) * kPwCol + 32 * gw + 8 * fch;
-      MBXP_STAMP(ci, 0);
-      // the epilogue's reads (residual skip / accumulate source / mask), issued before the K loop: they land while the tile is
-      // multiplied (the multiplying waves issue no other vector-memory instruction)
-      conv_epilogue_issue_reads<EVC, false, NA, MI, BMODE>(p, mlane, clane, 0, la, lb);
+    const int mlane = m0 + frow;
+    for (int ct = ct0; ct < ct1; ++ct) {
+      const int clane = ct * kPwCol + 32 * wave + 8 * fch;
+      MBXP_STAMP(ct - ct0, 0);
+#ifdef MBX_I5_STAMPS
+      const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+      // the epilogue's reads (residual skip / accumulate source / sign bits) and its per-channel shift row, issued before the K loop:
+      // they land while the column tile is multiplied (the multiplying waves issue no other vector-memory instruction)
+      u32x4 la[MI][NA], lb[MI][NA];
+#ifdef MBX_I5_STAMPS
+      const bool epi_ = !(p.dbg & 16);                     // timing probe (wrong results): no epilogue memory traffic at all
+#else
+      constexpr bool epi_ = true;
+#endif
+      if (epi_) conv_epilogue_issue_reads<EVC, false, NA, MI, BMODE>(p, mlane, clane, 0, la, lb);
+      float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];
+      conv_epilogue_channels<EVC, NA>(p, clane, sc, sh, s1, s2);
+      f32x4 acc[NI][MI];
 #pragma unroll
       for (int a = 0; a < NI; ++a)
 #pragma unroll
         for (int f = 0; f < MI; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      bf16x8 wf[2][NI], pf[2][MI];
+      // HALF steps h = 2 s + half (K step s, pixel half): half 0 multiplies pixel blocks 0 .. MIH - 1, half 1 the rest, against
+      // the SAME filter fragments; software-pipelined like conv_resident_kernel's loop (the fragments of half step h + 1 are
+      // read while h is multiplied; the slot barrier sits in the read stream)
+      bf16x8 wf[2][NI], pf[2][MIH];
 #pragma unroll
       for (int a = 0; a < NI; ++a) wf[0][a] = rread<C8S>(EA[a] + so, 0);
 #pragma unroll
-      for (int f = 0; f < MI; ++f) pf[0][f] = rread<C8>(Ep[f], 0);
+      for (int f = 0; f < MIH; ++f) pf[0][f] = rread<C8>(Ep0 + f * (16 * C8 * 16), 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        const int j1 = (s + 1) % KS;
-        if (j1 == 0) {
+      for (int h = 0; h < 2 * KC; ++h) {
+        const int s = h >> 1, half = h & 1;
+        const int h1 = h + 1, s1_ = h1 >> 1, half1 = h1 & 1;
+        if (half1 == 0 && s1_ % KS == 0) {                  // the next half step opens a new slot (or ends the column tile)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done
           raw_barrier();                                        // B: the slot may be refilled; the next one is published
           so = so == (NST - 1) * SLOT_CH * 16 ? 0 : so + SLOT_CH * 16;
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < KC) {
+#ifdef MBX_I5_STAMPS
+        const bool rd_ = !(p.dbg & 4), mm_ = !(p.dbg & 8);       // timing probes (wrong results): no fragment reads / no MFMAs
+#else
+        constexpr bool rd_ = true, mm_ = true;
+#endif
+        if (h1 < 2 * KC && rd_) {
+          if (half1 == 0) {
 #pragma unroll
-          for (int a = 0; a < NI; ++a) wf[nxt][a] = rread<C8S>(EA[a] + so, j1);
+            for (int a = 0; a < NI; ++a) wf[s1_ & 1][a] = rread<C8S>(EA[a] + so, s1_ % KS);
+          }
 #pragma unroll
-          for (int f = 0; f < MI; ++f) pf[nxt][f] = rread<C8>(Ep[f], s + 1);
+          for (int f = 0; f < MIH; ++f) pf[h1 & 1][f] = rread<C8>(Ep0 + (MIH * half1 + f) * (16 * C8 * 16), s1_);
         }
+        if (mm_) {
 #pragma unroll
-        for (int f = 0; f < MI; ++f)
+        for (int f = 0; f < MIH; ++f)
 #pragma unroll
           for (int a = 0; a < NI; ++a)
-            acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], pf[cur][f], acc[a][f], 0, 0, 0);
-        if (s + 1 < KC) sched_interleave<NI + MI, NI * MI>();
+            acc[a][MIH * half + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][a], pf[h & 1][f], acc[a][MIH * half + f], 0, 0, 0);
+        }
+        if (h1 < 2 * KC) { if (half1 == 0) sched_interleave<NI + MIH, NI * MIH>(); else sched_interleave<MIH, NI * MIH>(); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      MBXP_STAMP(ci, 1);
+      MBXP_STAMP(ct - ct0, 1);
+#ifdef MBX_I5_STAMPS
+      if (stamp && u == first && ct - ct0 < 8) p.stamps[(blockIdx.x * 8 + (ct - ct0)) * 4 + 3] = __builtin_amdgcn_s_memtime() - clk0;   // shader cycles of the K loop
+#endif
+      if (epi_) conv_epilogue_finish<EVC, false, NI, MI, MI, BMODE>(p, acc, mlane, clane, 0, la, lb, sh, sc, s1, s2);
+      MBXP_STAMP(ct - ct0, 2);
     }
-    if (((nct - 1) & 1) == grp) { PW_EPILOGUE(nct - 1, false); MBXP_STAMP(nct - 1, 2); }      // the unit's last tile
   }
 #undef MBXP_STAMP
-#undef PW_EPILOGUE
 }
 
-template <int C8>
-int launch_pwres(const ConvK& k, const PwK& q, int grid, hipStream_t s) {
-  using G = PwG<C8>;
+int resident_cus();
+
+template <int C8, int MIH, int EV>
+int launch_pwres(const ConvK& k, PwK& q, hipStream_t s) {
+  using G = PwG<C8, MIH>;
   constexpr int lds = G::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "LDS");
-  static bool attr[2] = {false, false};
-  const int ev = k.epi == MBX_EPI_RESIDUAL ? 1 : 0;
-  if (!attr[ev]) {
-    if (ev) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwres_kernel<C8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwres_kernel<C8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr[ev] = true;
+  q.npt = (k.M + G::PIX - 1) / G::PIX;
+  q.nct = (k.C_out + kPwCol - 1) / kPwCol;
+  const int ncu = resident_cus();
+  int ncs = ncu / q.npt;                                  // column splits: as many units as fit one round of workgroups
+  if (ncs < 1) ncs = 1;
+  if (ncs > q.nct) ncs = q.nct;
+  q.ctper = (q.nct + ncs - 1) / ncs;
+  q.NCS = (q.nct + q.ctper - 1) / q.ctper;
+  q.nunits = q.npt * q.NCS;
+  q.npi = G::PIX_CH / 64;
+  int grid = q.nunits < ncu ? q.nunits : ncu;
+  if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;
+  if (k.dry) return MBX_OK;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwres_kernel<C8, MIH, EV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
   }
-  if (ev) hipLaunchKernelGGL((conv_pwres_kernel<C8, 4>), dim3(grid), dim3(kPwThreads), lds, s, k, q);
-  else hipLaunchKernelGGL((conv_pwres_kernel<C8, 2>), dim3(grid), dim3(kPwThreads), lds, s, k, q);
+  hipLaunchKernelGGL((conv_pwres_kernel<C8, MIH, EV>), dim3(grid), dim3(kRThreads), lds, s, k, q);
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
@@ -816,25 +765,24 @@ int mbx_launch_pwres(void* convk, hipStream_t s) {
   const bool res = k.epi == MBX_EPI_RESIDUAL, accm = k.epi == MBX_EPI_STORE && k.bits && !k.skip;     // (masks by the sign bits only)
   if (!res && !accm) return MBX_ERR_UNSUPPORTED;
   PwK q;
-  q.npt = (k.M + kPwPix - 1) / kPwPix;
-  q.nct = (k.C_out + kPwCol - 1) / kPwCol;
-  const int ncu = resident_cus();
-  int ncs = ncu / q.npt;
-  if (ncs < 1) ncs = 1;
-  if (ncs > q.nct) ncs = q.nct;
-  q.ctper = (q.nct + ncs - 1) / ncs;
-  q.NCS = (q.nct + q.ctper - 1) / q.ctper;
-  q.nunits = q.npt * q.NCS;
-  const int C8 = k.C_in / 8;
-  q.npi = (kPwPix * C8 + 63) / 64;
-  int grid = q.nunits < ncu ? q.nunits : ncu;
-  if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;
-#define MBX_PW(C8_)                                                   \
-  if (k.C_in == 8 * C8_) {                                           \
-    if (k.dry) return MBX_OK;                                        \
-    return launch_pwres<C8_>(k, q, grid, s);                         \
+  // (pixel tile 160 where the registers and LDS hold it: residual launches; 128 for the accumulate launch of 384 input
+  // channels -- three registers short at 160 -- and for K = 448, whose pixel tile would leave the ring no room)
+  if (res) {
+    switch (k.C_in) {
+      case 96: return launch_pwres<12, 5, 4>(k, q, s);
+      case 128: return launch_pwres<16, 5, 4>(k, q, s);
+      case 320: return launch_pwres<40, 5, 4>(k, q, s);
+      case 384: return launch_pwres<48, 5, 4>(k, q, s);
+      case 448: return launch_pwres<56, 4, 4>(k, q, s);
+      default: return MBX_ERR_UNSUPPORTED;
+    }
   }
-  MBX_PW(12) MBX_PW(16) MBX_PW(40) MBX_PW(48) MBX_PW(56)
-#undef MBX_PW
-  return MBX_ERR_UNSUPPORTED;
+  switch (k.C_in) {
+    case 96: return launch_pwres<12, 5, 2>(k, q, s);
+    case 128: return launch_pwres<16, 4, 2>(k, q, s);
+    case 320: return launch_pwres<40, 5, 2>(k, q, s);
+    case 384: return launch_pwres<48, 4, 2>(k, q, s);
+    case 448: return launch_pwres<56, 4, 2>(k, q, s);
+    default: return MBX_ERR_UNSUPPORTED;
+  }
 }

@@ -45,10 +45,18 @@ def run(name, H, W, Ci, Co, kind):
         if float(t[:, c, 0].max()) <= 0:
             break
         last = c
-        line += " [K +%.2f %.2f, out by +%.2f]" % (med(t[:, c, 0]) - t0, med(t[:, c, 1] - t[:, c, 0]), med(t[:, c, 2]) - t0)
+        kus = med(t[:, c, 1] - t[:, c, 0])
+        line += " [K +%.2f %.2f epi %.2f clk %.2f GHz]" % (med(t[:, c, 0]) - t0, kus, med(t[:, c, 2] - t[:, c, 1]), med(t[:, c, 3]) * 100.0 / 1e3 / max(kus, 1e-3))
     print(line, flush=True)
 
 
+if os.environ.get("PW_PROBE"):
+    import ctypes
+    for dbg in (0, 12, 16, 28):
+        os.environ["MBX_I5_DBG"] = str(dbg)
+        print("MBX_I5_DBG", dbg, "(4: no fragment reads, 8: no MFMAs, 16: no epilogue memory traffic)")
+        run("b17_up_384_1088", 17, 17, 384, 1088, "res")
+    sys.exit(0)
 run("b17_up_384_1088", 17, 17, 384, 1088, "res")
 run("b17_dg_320_1088", 17, 17, 320, 1088, "acc")
 run("b35_up_128_320", 35, 35, 128, 320, "res")
