@@ -723,8 +723,8 @@ inline void resident_groups(int C_out, int& NG, int& CPT, int& NB) {
 int mbx_resident_rows(int N) { return N; }
 
 // mbx_conv_desc.tile_config = 98: the RESIDENT-IMAGE launch (conv_resident_kernel).  MBX_ERR_UNSUPPORTED for anything but a
-// stride-1 convolution with "same" geometry (forward, or the data gradient of one) of 7 taps on a map of at most 17 x 17 = 289
-// pixels with C_in 128 / 160 / 192, C_out <= 192 (a multiple of 8) and a bf16 store epilogue with or without statistics, or
+// stride-1 convolution with "same" geometry (forward, or the data gradient of one) of 7 taps on a map of 65 .. 289 pixels
+// (17 x 17) with C_in 128 / 160 / 192, or of 3 taps on an 8 x 8 map with C_in 192 / 224 / 256; C_out a multiple of 8 and a bf16 store epilogue with or without statistics, or
 // the affine (+ relu) epilogue of a folded batch norm.
 int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s) {
   ConvK& k = *reinterpret_cast<ConvK*>(convk);
@@ -746,12 +746,17 @@ int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s) {
   for (int t = 0; t < RS; ++t) { q.dh[t] = t / k.S - k.pad_t; q.dw[t] = t % k.S - k.pad_l; q.dd[t] = q.dh[t] * q.W + q.dw[t]; }
   int grid = q.ntiles < resident_cus() ? q.ntiles : resident_cus();
   if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;
-#define MBX_RES(C8_, NB_, RS_)                                                                           \
-  if (C8 == C8_ && NB == NB_ && RS == RS_) {                                                             \
+#define MBX_RES(C8_, NB_, RS_, MI_, HWC_)                                                                \
+  if (C8 == C8_ && NB == NB_ && RS == RS_ && q.HW <= HWC_ && (HWC_ > 64 || q.HW == 64)) {                 \
     if (k.dry) return MBX_OK;                                                                            \
-    return launch_resident<C8_, NB_, RS_, 5, 289>(k, q, grid, s);                                        \
+    return launch_resident<C8_, NB_, RS_, MI_, HWC_>(k, q, grid, s);                                     \
   }
-  MBX_RES(16, 3, 7) MBX_RES(20, 3, 7) MBX_RES(20, 2, 7) MBX_RES(24, 3, 7)
+  // block8's 1x3 / 3x1 layers (model.py:53-57: 8 x 8 maps, 192 -> 224 -> 256 channels, forward and data gradient): one pixel
+  // block per multiplying wave, all three taps resident
+  MBX_RES(24, 4, 3, 1, 64) MBX_RES(28, 4, 3, 1, 64) MBX_RES(28, 3, 3, 1, 64) MBX_RES(32, 4, 3, 1, 64)
+  if (q.HW <= 64) return MBX_ERR_UNSUPPORTED;
+  // block17's 1x7 / 7x1 layers (model.py:33-37: 17 x 17 maps, 128 -> 160 -> 192 channels)
+  MBX_RES(16, 3, 7, 5, 289) MBX_RES(20, 3, 7, 5, 289) MBX_RES(20, 2, 7, 5, 289) MBX_RES(24, 3, 7, 5, 289)
 #undef MBX_RES
   return MBX_ERR_UNSUPPORTED;
 }

@@ -205,21 +205,29 @@ RESIDENT_TILE_CONFIG = 98                      # the resident-image launch for m
 
 
 def resident_applies(desc: ConvDesc, min_images=32):
-    """The resident-image launch by rule: a stride-1, same-size 1x7 / 7x1 convolution (forward or data gradient) on a map of at
-    most 17 x 17 pixels with C_in 128 / 160 / 192 (block17's branch layers, model.py:33-37): a tile = a whole image (staged in
-    LDS once) x a quarter of the output channels, where the implicit GEMM gathers every pixel row once per tap.  Plain bf16
-    store (+ statistics) or the affine epilogue; enough images to fill the chip (4 tiles per image).  MBX_RESIDENT=0 turns it
-    off (A/B).  The library has the last word (mbx_conv_supported)."""
+    """The resident-image launch by rule: a stride-1, same-size convolution with a ONE-DIMENSIONAL multi-tap filter on a small
+    map with many channels -- block17's 1x7 / 7x1 layers (17 x 17, C_in 128 / 160 / 192: model.py:33-37) and block8's 1x3 / 3x1
+    (8 x 8, C_in 192 / 224 / 256: model.py:53-57), forward or data gradient: a tile = a whole image (staged in LDS once) x a
+    quarter of the output channels, where the implicit GEMM gathers every pixel row once per tap.  Plain bf16 store
+    (+ statistics) or the affine epilogue; enough images to fill the chip (4 tiles per image).  MBX_RESIDENT=0 turns it off
+    (A/B).  The library has the last word: the rule asks mbx_conv_supported."""
     if os.environ.get("MBX_RESIDENT", "1") == "0":
         return False
-    if desc.R * desc.S != 7 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) or desc.accumulate or desc.skip \
-            or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial) or desc.bn_bwd_stats or desc.relu_bits:
-        return False
-    if desc.C_in not in (128, 160, 192) or desc.C_out > 192 or desc.C_out % 8:
+    if desc.R * desc.S not in (3, 7) or min(desc.R, desc.S) != 1 or desc.stride != 1 or desc.epilogue not in (EPI_STORE, EPI_AFFINE) \
+            or desc.accumulate or desc.skip or desc.rscale != 0.0 or (desc.epilogue == EPI_AFFINE and desc.stats_partial) \
+            or desc.bn_bwd_stats or desc.relu_bits:
         return False
     if desc.H_in != desc.H_out or desc.W_in != desc.W_out or not (64 <= desc.H_out * desc.W_out <= 289):
         return False
-    return desc.N >= int(os.environ.get("MBX_RESIDENT_MIN_IMAGES", min_images))
+    if desc.N < int(os.environ.get("MBX_RESIDENT_MIN_IMAGES", min_images)):
+        return False
+    if not desc.x or not desc.w or not desc.y:          # (a bare geometry probe, e.g. the engine's planning pass)
+        return desc.C_in in (128, 160, 192, 224, 256) and desc.C_out % 8 == 0
+    keep = desc.tile_config
+    desc.tile_config = RESIDENT_TILE_CONFIG
+    ok = _lib.lib().mbx_conv_supported(C.byref(desc)) == 0
+    desc.tile_config = keep
+    return ok
 
 
 PWRES_DEFAULT = "0"                            # (off until it beats the persistent tiles in the step: LAB_NOTES round 5)

@@ -20,6 +20,7 @@ SHAPES = [
     ("b35_up_1x1_128_320", 35, 35, 128, 320, 1, 1, 1, (0, 0), 10),
     ("b8_fused_1x1_2080_384", 8, 8, 2080, 384, 1, 1, 1, (0, 0), 10),
     ("b8_1x3_192_224", 8, 8, 192, 224, 1, 3, 1, (0, 1), 10),
+    ("b8_3x1_224_256", 8, 8, 224, 256, 3, 1, 1, (1, 0), 10),
     ("b8_up_1x1_448_2080", 8, 8, 448, 2080, 1, 1, 1, (0, 0), 10),
     ("stem_3x3_32_32_149", 149, 149, 32, 32, 3, 3, 1, (0, 0), 1),
     ("stem_3x3_32_64_147", 147, 147, 32, 64, 3, 3, 1, (1, 1), 1),
