@@ -23,12 +23,13 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
 ev.sort(key=lambda e: e.time_range.start)
-convs = [e for e in ev if "conv_igemm" in e.name]
+CONV = ("conv_igemm", "conv_direct", "conv_resident", "conv_stem", "conv_pwres")
+convs = [e for e in ev if any(k in e.name for k in CONV)]
 ops = [op for op in net.fwd if isinstance(op, ConvOp)]
 assert len(convs) == REP * len(ops), (len(convs), len(ops))
 other = {}
 for e in ev:
-    if "conv_igemm" not in e.name:
+    if not any(k in e.name for k in CONV):
         k = re.sub(r"<.*|\(.*", "", e.name)
         other[k] = other.get(k, 0.0) + float(e.device_time) / REP
 rows = {}
@@ -39,8 +40,8 @@ for i, e in enumerate(convs):
     r = rows.setdefault(key, [0.0, 0, ""])
     r[0] += float(e.device_time) / REP
     r[1] += 1
-    m = re.search(r"conv_igemm(\d)_kernel<([^>]*)>", e.name)
-    r[2] = ("i%s:" % m.group(1)) + m.group(2) if m else e.name[:30]
+    m = re.search(r"conv_(\w+?)_kernel<([^>]*)>", e.name)
+    r[2] = ("%s:" % m.group(1)) + m.group(2) if m else e.name[:30]
 tot = tf = 0.0
 print("%-58s %8s %5s %5s %3s | %8s %6s %5s | kernel" % ("layer", "M", "Cin", "K", "RS", "us", "TF/s", "x"))
 for (name, M, Ci, K, R, S), (us, n, kern) in rows.items():
