@@ -209,8 +209,12 @@ typedef struct {
      [R][stats_ld][2] of INT64 that stats_partial then points at (16 bytes per channel and row) and that must be ZERO at
      launch -- R rows whatever the tile shape (mbx_conv_stats_rows() = R), few enough for the consumer to reduce them itself
      (mbx_bn_apply_fused_mapped: no finalize launch), many enough that the adders of one address stay few.  The sums are
-     added as 64-bit integers in fixed point (units of 2^-20: |sum| < 8.8e12, resolution 1e-6): integer addition is
-     associative, so the table does not depend on the order in which the tiles arrive -- bit-reproducible statistics.
+     added as 64-bit integers in fixed point (units of 2^-20, resolution 1e-6): integer addition is associative, so the table
+     does not depend on the order in which the tiles arrive -- bit-reproducible statistics.  RANGE (round 5): a tile sum that
+     is not finite or not below 2^41 in magnitude POISONS its channel -- the sum-of-squares word is forced to INT64_MIN by a
+     signed atomic min, whatever arrives before or after -- and mbx_bn_apply_fused_mapped reports NaN mean / rstd for a
+     channel whose word is negative: out-of-range activations end in NaN (as the float32 rows' inf - inf would), never in
+     finite garbage.
      stats_ld (0: C_out): channels per row -- sibling convolutions of a batch-norm group add into channel slices of one
      table (stats_partial then points at the member's first channel).                                              */
   int32_t stats_rows_mod, stats_ld;
@@ -238,7 +242,16 @@ typedef struct {
    the same number, the network's first layer (3x3 / stride 2, C_in 8 = the packed RGB input, C_out <= 32; forward only).
    tile_config 97: the same scheme with WHOLE-WIDTH tiles for narrow maps (8..64 wide: block35's 35 x 35 layers; C_in 32 /
    48 / 64, C_out <= 64).  Same K order and MFMA grouping as the implicit-GEMM tiles: bit-identical outputs;
-   mbx_conv_stats_rows() = one row per workgroup. */
+   mbx_conv_stats_rows() = one row per workgroup.
+   tile_config 98 (round 5): the RESIDENT-IMAGE launch for stride-1, same-size convolutions with a one-dimensional multi-tap
+   filter on small maps with many channels -- 1x7 / 7x1 on maps of 65..289 pixels with C_in 128 / 160 / 192 (block17,
+   model.py:33-37) and 1x3 / 3x1 on 8 x 8 maps with C_in 192 / 224 / 256 (block8, model.py:53-57), forward or data gradient,
+   bf16 store with or without statistics or the affine epilogue: a tile = one whole image (staged in LDS once) x a quarter of
+   the output channels, the filter streamed per tap.  Bit-identical outputs; mbx_conv_stats_rows() = N (a row per image).
+   tile_config 99 (round 5): the PIXEL-RESIDENT POINTWISE launch (1x1, unit stride, unpadded, C_in 96 / 128 / 320 / 384 / 448)
+   for the residual epilogue (+ relu, + sign bits) or a store masked by relu sign bits (with or without an accumulate
+   source): a 160- / 128-pixel tile resident in LDS, the filter streamed per 128 output channels.  Bit-identical outputs; no
+   statistics.  (Built, tested and level with the persistent tiles at BATCH_SIZE 64: not chosen by the engine's rules.) */
 
 int mbx_conv_stats_rows(const mbx_conv_desc* desc /*HOST*/); /* rows of stats_partial */
 int mbx_conv(const mbx_conv_desc* desc /*HOST*/, mbx_stream_t stream);

@@ -130,8 +130,19 @@ def test_relu_bits_descriptor_rules(lib):
         want = -2 if cfg == 38 else 0
         assert ok(desc(ops.EPI_STORE, accumulate=1, tile_config=cfg)) == want, cfg
         assert ok(desc(ops.EPI_RESIDUAL, relu=1, rscale=0.1, tile_config=cfg, **skip)) == 0, cfg
-    for cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.SPLITK_FLAG + 4):
+    for cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG, ops.SPLITK_FLAG + 4):
         assert ok(desc(ops.EPI_STORE, tile_config=cfg)) != 0, cfg
+    # the pixel-resident pointwise launch (99): writes the bits beside a residual output, reads them as the mask of a store
+    # (with or without an accumulate source); nothing else -- no tensor mask, no plain store
+    assert ok(desc(ops.EPI_RESIDUAL, relu=1, rscale=0.1, tile_config=ops.PWRES_TILE_CONFIG, **skip)) == 0
+    assert ok(desc(ops.EPI_STORE, accumulate=1, tile_config=ops.PWRES_TILE_CONFIG)) == 0
+    assert ok(desc(ops.EPI_STORE, tile_config=ops.PWRES_TILE_CONFIG)) == 0
+    d = desc(ops.EPI_STORE, tile_config=ops.PWRES_TILE_CONFIG, **skip)
+    d.relu_bits = None
+    assert ok(d) == -2
+    d = desc(ops.EPI_STORE, tile_config=ops.PWRES_TILE_CONFIG)
+    d.relu_bits = None
+    assert ok(d) == -2
 
 
 def test_ctypes_structs_match_the_header(tmp_path):
