@@ -229,14 +229,14 @@ def _file_sha(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-def committed_traffic():
+def committed_traffic(pattern="r*_hbm_traffic_pmc.json"):
     """HBM bytes per launch of the dominant kernel class (conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel launches,
     weighted by their launch counts) from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- only if that profile was
     taken on THESE kernel sources (the file stamps the sha256 of csrc/conv.hip, conv5.hip and conv7.hip); a stale profile prints null."""
     import glob
     shas = {k: _file_sha(os.path.join(ROOT, "multibox_amd", "csrc", f)) for k, f in (("conv_hip_sha", "conv.hip"), ("conv5_hip_sha", "conv5.hip"), ("conv7_hip_sha", "conv7.hip"),
                                                                                   ("convd_hip_sha", "convd.hip"), ("convr_hip_sha", "convr.hip"), ("conv_common_h_sha", "conv_common.h"))}
-    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             j = json.load(open(pj))
             if any(j.get(k) != v for k, v in shas.items()):
@@ -373,6 +373,8 @@ def detect_leg(args, world, rank, pg):
             out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_stem_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                                "traffic": None, "launches_per_batch": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2)}
+            # HBM bytes per launch from the committed PMC passes of the detect forward (tools/collect_profiles.sh part d), if taken on these sources
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = committed_traffic("r*_detect_traffic_pmc.json")
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(20):

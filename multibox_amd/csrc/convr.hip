@@ -16,6 +16,12 @@
 // output element is the igemm kernels', so the results are bit-identical (tests/test_gpu_conv.py::test_conv_resident).
 // Epilogues: bf16 store (EV = 0), store + batch-norm statistics (EV = 1: statistics row = the image), affine + relu (EV = 3).
 #include "conv_common.h"
+#ifndef MBX_RES_EALL
+#define MBX_RES_EALL 0
+#endif
+#ifndef MBX_RES_PROBE
+#define MBX_RES_PROBE 0
+#endif
 
 namespace {
 
@@ -68,6 +74,22 @@ __device__ __forceinline__ bf16x8 rread(int Eb, int j) {
   return __builtin_bit_cast(bf16x8, *(lds_u32x4_cptr)(size_t)a);
 }
 
+// s_waitcnt vmcnt(k PT) for a k the unrolled caller folds to a constant
+template <int PT>
+__device__ __forceinline__ void wait_vmcnt_k(const int k) {
+  switch (k) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<PT>(); break;
+    case 2: wait_vmcnt<2 * PT>(); break;
+    case 3: wait_vmcnt<3 * PT>(); break;
+    case 4: wait_vmcnt<4 * PT>(); break;
+    case 5: wait_vmcnt<5 * PT>(); break;
+    case 6: wait_vmcnt<6 * PT>(); break;
+    case 7: wait_vmcnt<(7 * PT < 63 ? 7 * PT : 0)>(); break;
+    default: wait_vmcnt<0>(); break;
+  }
+}
+
 // LDS row 16 a + f of a filter slot holds output channel rperm(a, f) of the tile: blocks 2A and 2A + 1 leave a lane EIGHT
 // consecutive channels of one pixel (16-byte stores, conv_igemm3_kernel's order); a trailing unpaired block the plain order
 template <int NB>
@@ -108,6 +130,9 @@ __global__ void __launch_bounds__(kRThreads)
 conv_resident_kernel(const ConvK p, const ResK q) {
   using G = ResG<C8, NB, RS, MI>;
   constexpr int KC = G::KC, PT = G::PT, SLOTP = G::SLOTP, D = G::depth(HWC), DD = D < RS ? D : RS;
+  // taps per publication group: half the ring (the next group lands while this one is multiplied); everything resident: 4
+  constexpr int GR = D >= RS ? (RS < 4 ? RS : 4) : (D / 2 > 0 ? D / 2 : 1), G0 = GR < RS ? GR : RS;
+  static_assert(D >= RS || D >= 2 * GR || GR == 1, "two groups in the ring");
   constexpr int NP = NB / 2;                              // paired blocks
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   float* const red = reinterpret_cast<float*>(smem);      // [4 waves][16 NB][2]
@@ -161,29 +186,26 @@ conv_resident_kernel(const ConvK p, const ResK q) {
       issue_image(im);
 #pragma unroll
       for (int tap = 0; tap < DD; ++tap) issue_tap(tap);
-      wait_vmcnt<(DD - 1) * PT>();                        // the image and tap 0 have retired (this wave's share) ...
-      lds_readback_wait(lds_readback_issue(ring + (PT - 1) * (kRLW * 64) + lw * 64 + lane));   // ... and landed
-      raw_barrier();                                      // P: image + tap 0 published
+      // Taps are PUBLISHED IN GROUPS of GR (one barrier per group, not per tap: every barrier costs the multiplying waves a
+      // drain of their LDS queue and a rendezvous with the loaders' wait + read-back chain -- 0.25 us each by the probes of
+      // tools/res_stamps.py, seven of them a third of the 1x7 K loop).  The ring holds two groups: the next one is in flight
+      // while the current one is multiplied, and a group's slots are refilled behind the barrier that ends it.
+      wait_vmcnt_k<PT>(DD - G0);                          // the image and the first group have retired (this wave's share) ...
+      lds_readback_wait(lds_readback_issue(ring + ((G0 - 1) % D) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));   // ... and landed
+      raw_barrier();                                      // P: image + group 0 published
+      int issued = DD;
 #pragma unroll
-      for (int tap = 0; tap < RS; ++tap) {
-        if (tap + 1 < RS) {
-          // tap + 1 has retired: behind it this wave has issued the taps up to min(RS - 1, tap + D - 1)
-          const int newest = (tap + D - 1 < RS - 1) ? tap + D - 1 : RS - 1;
-          switch (newest - (tap + 1)) {                   // (folded: the loop is unrolled)
-            case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<PT>(); break;
-            case 2: wait_vmcnt<2 * PT>(); break;
-            case 3: wait_vmcnt<3 * PT>(); break;
-            case 4: wait_vmcnt<4 * PT>(); break;
-            case 5: wait_vmcnt<5 * PT>(); break;
-            case 6: wait_vmcnt<6 * PT>(); break;
-            case 7: wait_vmcnt<7 * PT>(); break;
-            default: wait_vmcnt<0>(); break;
-          }
-          lds_readback_wait(lds_readback_issue(ring + ((tap + 1) % D) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
+      for (int g0 = 0; g0 < RS; g0 += GR) {
+        const int e = g0 + GR < RS ? g0 + GR : RS;        // one past the group's last tap
+        if (e < RS) {
+          const int e2 = e + GR < RS ? e + GR : RS;       // the next group [e, e2) has retired: behind it, the taps up to issued - 1
+          wait_vmcnt_k<PT>(issued - e2);
+          lds_readback_wait(lds_readback_issue(ring + ((e2 - 1) % D) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
         }
-        raw_barrier();                                    // B_tap: slot tap % D is free, tap + 1 is published
-        if (tap + D < RS) issue_tap(tap + D);
+        raw_barrier();                                    // B: the group's slots are free, the next group is published
+#pragma unroll
+        for (int k2 = g0; k2 < e; ++k2)
+          if (issued < RS) { issue_tap(issued); ++issued; }
       }
       if constexpr (EV == 1) raw_barrier();               // the multiplying waves' statistics reduce
     }
@@ -202,7 +224,8 @@ conv_resident_kernel(const ConvK p, const ResK q) {
   // this lane's output pixels (fragment f of wave w = pixels 16 (w + 4 f) + frow) and the taps whose input pixel lies in the image
   // (bit `tap` of vm); the LDS row of every (tap, pixel block) is computed one tap AHEAD inside the K loop (nine VALU
   // operations in the shadow of the MFMAs; all taps up front were ~550 instructions between the image's issue and its first use)
-  int E[2][MI];
+  constexpr bool EALL = MBX_RES_EALL;                      // all taps' rows before the K loop (registers) or one tap ahead inside it
+  int E[EALL ? RS : 2][MI];
   int opix[MI], vm[MI];
 #pragma unroll
   for (int f = 0; f < MI; ++f) {
@@ -250,7 +273,12 @@ conv_resident_kernel(const ConvK p, const ResK q) {
         sh4[j] = (p.shiftv && c < ce) ? p.shiftv[c] : 0.f;
       }
     }
-    tap_rows(0, E[0]);
+    if constexpr (EALL) {
+#pragma unroll
+      for (int tap = 0; tap < RS; ++tap) tap_rows(tap, E[tap]);
+    } else {
+      tap_rows(0, E[0]);
+    }
     wait_vmcnt<0>();
     lds_readback_wait(lds_readback_issue(img + lane));
     raw_barrier();                                        // P
@@ -283,25 +311,30 @@ conv_resident_kernel(const ConvK p, const ResK q) {
     for (int s = 0; s < NS; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
       const int tap1 = (s + 1) / KC, j1 = (s + 1) % KC;
-      if (j1 == 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot (the last tap: of the image) are done
-        raw_barrier();                                        // B_tap: its slot may be refilled; tap + 1 is published
+      if (j1 == 0 && (tap1 % GR == 0 || tap1 == RS)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the group's slots (the last: of the image) are done
+        raw_barrier();                                        // B: the group's slots may be refilled; the next group is published
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (s % KC == 0 && s / KC + 1 < RS) tap_rows(s / KC + 1, E[(s / KC + 1) & 1]);     // the next tap's rows (used KC - 1 steps on)
-      if (s + 1 < NS) {
+      if constexpr (!EALL) { if (s % KC == 0 && s / KC + 1 < RS) tap_rows(s / KC + 1, E[(s / KC + 1) & 1]); }     // the next tap's rows (used KC - 1 steps on)
+      // (timing probes, wrong results, debug builds only: -DMBX_RES_PROBE=1 no fragment reads, 2 no MFMAs, 3 neither --
+      // compile-time, so that the straight-line schedule of the step stays what it is)
+      constexpr bool rd_ = !(MBX_RES_PROBE & 1), mm_ = !(MBX_RES_PROBE & 2);
+      if (s + 1 < NS && rd_) {
         const int so = (tap1 % D) * SLOTP * 16;
 #pragma unroll
         for (int a = 0; a < NB; ++a) wf[nxt][a] = rread<C8>(EA[a] + so, j1);
 #pragma unroll
-        for (int f = 0; f < MI; ++f) pf[nxt][f] = rread<C8>(E[tap1 & 1][f], j1);
+        for (int f = 0; f < MI; ++f) pf[nxt][f] = rread<C8>(E[EALL ? (tap1 < RS ? tap1 : 0) : (tap1 & 1)][f], j1);
       }
       // pixel-block-major: the fragment read LAST (pixel block MI - 1) is needed last in the next step
+      if (mm_) {
 #pragma unroll
       for (int f = 0; f < MI; ++f)
 #pragma unroll
         for (int a = 0; a < NB; ++a)
           acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], pf[cur][f], acc[a][f], 0, 0, 0);
+      }
       if (s + 1 < NS) sched_interleave<NR, NM>();
       __builtin_amdgcn_sched_barrier(0);
     }

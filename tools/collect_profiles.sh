@@ -4,6 +4,7 @@
 #           (separate --pmc runs, eager steps; tools/pmc_traffic.py applies the gfx950 FETCH_SIZE x2 correction)
 #   part b: SQ counters of every convolution kernel instantiation of the step (two --pmc passes), the grouped weight gradient
 #   part c: the 2000-step saturation stress, the 512x512 configuration
+#   part d: the detect leg: per-layer table + FETCH_SIZE / WRITE_SIZE passes (profiles/rNN_detect_traffic_pmc.json)
 # Counters never share a run with other trace domains than --kernel-trace.
 set -o pipefail
 tag=${1:-r04}
@@ -36,6 +37,13 @@ elif [ "$part" = "w" ]; then
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_avr --output-format csv -d $out/wg2 -o s -- python3 bench.py $B > $out/wg2.log 2>&1 || exit 9
   python tools/pmc_summary.py $out/wg2/s_counter_collection.csv | grep -A 6 "conv_wgrad_grouped" > $out/wgrad_l2_counters.txt 2>&1
   rm -rf $out/wg1 $out/wg2
+elif [ "$part" = "d" ]; then
+  # the detect leg (BASELINE config 4): per-layer table, FETCH_SIZE / WRITE_SIZE passes of the detect forward
+  python tools/detect_by_layer.py > $out/detect_by_layer.txt 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/df -o f -- python3 tools/bench_detect.py > $out/dpmc_f.log 2>&1 || exit 10
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/dw -o w -- python3 tools/bench_detect.py > $out/dpmc_w.log 2>&1 || exit 11
+  python tools/pmc_traffic.py $out/df/f_counter_collection.csv $out/dw/w_counter_collection.csv 35 $out/detect_traffic_pmc.json > $out/detect_pmc_traffic.txt 2>&1
+  rm -rf $out/df $out/dw
 elif [ "$part" = "c" ]; then
   MBX_DETERMINISTIC=1 python tools/side_stream_stress.py 2000 compare saturate > $out/saturation_stress.json 2> >(tee $out/saturation_stress.err >&2) || exit 7
   python bench.py --input-size 512 --k 7 --max-num-bboxes 100 --no-cpu-baseline --no-detect --no-configs > $out/bench_512.json 2> $out/bench_512.err

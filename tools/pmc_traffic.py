@@ -42,6 +42,7 @@ res["conv_hip_sha"] = hashlib.sha256(open(_conv, "rb").read()).hexdigest()[:16] 
 res["conv5_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv5.hip"), "rb").read()).hexdigest()[:16]
 res["conv7_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv7.hip"), "rb").read()).hexdigest()[:16]
 res["convd_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "convd.hip"), "rb").read()).hexdigest()[:16]
+res["convr_hip_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "convr.hip"), "rb").read()).hexdigest()[:16]
 res["conv_common_h_sha"] = hashlib.sha256(open(_conv.replace("conv.hip", "conv_common.h"), "rb").read()).hexdigest()[:16]
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res.items():

@@ -148,7 +148,7 @@ def main():
             if "pack_input" in e.name:
                 cur = []
                 steps.append(cur)
-            elif ("conv_igemm" in e.name or "conv_direct" in e.name or "conv_stem" in e.name) and "pair_kernel" not in e.name \
+            elif any(k_ in e.name for k_ in ("conv_igemm", "conv_direct", "conv_stem", "conv_resident", "conv_pwres")) and "pair_kernel" not in e.name \
                     and cur is not None:                       # (pair launches go through mbx_conv_pair: not tuned here)
                 cur.append(e)
         steps = [s_ for s_ in steps if len(s_) == n_calls]
