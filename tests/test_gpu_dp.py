@@ -25,7 +25,7 @@ def _build(torch, seed, pg=None, use_graph=True):
     # ranks and in the reference; the weight gradient's atomics are the one remaining noise and do not feed back.
     # (the same holds for the measured tile choice: another tile height regroups the BN partial sums)
     # MBX_DETERMINISTIC=1 also forbids pixel splits in the grouped weight gradient (one adder per dw element): the
-    # ranks cut the backward pass into 5 segments and the reference into 4, so the split plans would differ otherwise.
+    # ranks cut the backward pass into 3 segments and the reference into 1, so the split plans would differ otherwise.
     os.environ["MBX_DETERMINISTIC"] = "1"
     os.environ["MBX_AUTOTUNE"] = "0"
     net = Net(batch=4, input_size=299, k=5, mode="train", seed=seed)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     net, tr = _build(torch, seed=13, pg=dist.group.WORLD, use_graph=True)
-    assert tr.reducer.enabled and len(tr._segments) == 5      # four equal buckets, the last one cut once more (small tail)
+    assert tr.reducer.enabled and len(tr._segments) == 3      # two equal buckets, the last one cut once more (small tail): round 5's default
     tr.set_batch(*_batch(torch, rank))
     tr.step()
     torch.cuda.synchronize()
