@@ -740,6 +740,15 @@ class Net:
         self.tune_registry.append((repr(key), d, what))           # tools/tune_in_situ.py re-measures these inside a step
         if self.autotune:
             ops.autotune(d, key)
+            # a MEASURED exception to the launch rules below (tools/tune_by_trace.py writes one where a table tile beat the
+            # rule's launch inside the replayed step: e.g. the resident-image launch on block8's 8 x 8 maps at BATCH_SIZE 256,
+            # 1024 one-shot tiles in four rounds, each paying its operand landing)
+            over = ops._TUNED.get(repr(key) + "#norule") if os.environ.get("MBX_NO_RULE_EXCEPTIONS") != "1" else None
+            if over is not None:
+                keep = d.tile_config
+                d.tile_config = int(over)
+                if _lib.lib().mbx_conv_supported(C.byref(d)) != 0:
+                    d.tile_config, over = keep, None
             if os.environ.get("MBX_NO_I5") == "1" and d.tile_config > ops.I5_FLAG:   # A/B knob
                 d.tile_config = ops._TUNED.get(repr(key) + "#i3", 0)       # the best igemm3 tile the tuner saw, else the rule
             # The persistent igemm5 launch needs a whole CU per workgroup; in data-parallel runs RCCL's kernels hold CUs
@@ -755,7 +764,9 @@ class Net:
                 d.tile_config = {9: 7, 10: 2, 11: 5, 12: 2, 13: 8, 14: 1}.get(d.tile_config, d.tile_config)
             # few channels on a large map (the stem's 3x3 layers, forward and data gradient): the direct launch stages each
             # pixel patch once instead of gathering it nine times (by rule, not by the table; bit-identical outputs)
-            if ops.direct3_applies(d):
+            if over is not None:
+                pass
+            elif ops.direct3_applies(d):
                 d.tile_config, d.work_counter = ops.DIRECT3_TILE_CONFIG, None
                 _lib.check(_lib.lib().mbx_conv_supported(C.byref(d)), "direct 3x3 " + op.name)
             elif ops.directw_applies(d) and not (what == "fwd" and d.stats_partial and getattr(op, "group", None) is not None

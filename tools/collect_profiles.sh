@@ -18,11 +18,18 @@ if [ "$part" = "a" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-detect --no-roofline --no-configs > $out/bench_prof.json 2> $out/bench_prof.err || exit 2
   python tools/trace_by_layer.py $out/kt/kt_kernel_trace.csv > $out/by_layer.txt 2>&1
   cp $out/kt/kt_kernel_stats.csv $out/kernel_stats.csv
+  python tools/step_trace.py --csv $out/kt/kt_kernel_trace.csv $out/step_trace.tsv > $out/step_trace.txt 2>&1
   rm -rf $out/kt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pf -o f -- python3 bench.py $B > $out/pmc_f.log 2>&1 || exit 3
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pw -o w -- python3 bench.py $B > $out/pmc_w.log 2>&1 || exit 4
   python tools/pmc_traffic.py $out/pf/f_counter_collection.csv $out/pw/w_counter_collection.csv 3 $out/hbm_traffic_pmc.json > $out/pmc_traffic.txt 2>&1
   rm -rf $out/pf $out/pw
+elif [ "$part" = "t" ]; then
+  # the step trace alone (every kernel of the last complete step of a traced bench run, in launch order)
+  rocprofv3 --kernel-trace --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-detect --no-roofline --no-configs > $out/bench_trace.json 2> $out/bench_trace.err || exit 2
+  python tools/step_trace.py --csv $out/kt/kt_kernel_trace.csv $out/step_trace.tsv > $out/step_trace.txt 2>&1
+  rm -rf $out/kt
+  cat $out/step_trace.txt
 elif [ "$part" = "b" ]; then
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --output-format csv -d $out/sq1 -o s -- python3 bench.py $B > $out/sq1.log 2>&1 || exit 5
   python tools/pmc_summary.py $out/sq1/s_counter_collection.csv > $out/conv_sq_counters.txt 2>&1
@@ -42,7 +49,7 @@ elif [ "$part" = "d" ]; then
   python tools/detect_by_layer.py > $out/detect_by_layer.txt 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/df -o f -- python3 tools/bench_detect.py > $out/dpmc_f.log 2>&1 || exit 10
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/dw -o w -- python3 tools/bench_detect.py > $out/dpmc_w.log 2>&1 || exit 11
-  python tools/pmc_traffic.py $out/df/f_counter_collection.csv $out/dw/w_counter_collection.csv 35 $out/detect_traffic_pmc.json > $out/detect_pmc_traffic.txt 2>&1
+  python tools/pmc_traffic.py $out/df/f_counter_collection.csv $out/dw/w_counter_collection.csv 15 $out/detect_traffic_pmc.json > $out/detect_pmc_traffic.txt 2>&1
   rm -rf $out/df $out/dw
 elif [ "$part" = "c" ]; then
   MBX_DETERMINISTIC=1 python tools/side_stream_stress.py 2000 compare saturate > $out/saturation_stress.json 2> >(tee $out/saturation_stress.err >&2) || exit 7

@@ -1,8 +1,51 @@
 """Every kernel of one replayed training step, in launch order: start (us from the step's first kernel), duration, gap to
 the previous kernel, short name + template arguments.  ROCm tracer through torch.profiler (the timestamps of a rocprofv3
-kernel trace).  usage: python tools/step_trace.py [out.tsv] [--fine-tune]"""
+kernel trace).  usage: python tools/step_trace.py [out.tsv] [--fine-tune]
+       python tools/step_trace.py --csv x_kernel_trace.csv [out.tsv]     (the last step of a rocprofv3 --kernel-trace of bench.py:
+       rocprofv3 has not dropped events on this pool, torch.profiler's ROCm tracer does -- 636 of 745 kernels in round 5)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def short(nm):
+    nm = nm.replace("void ", "").replace("(anonymous namespace)::", "")
+    head = nm.split("(")[0]
+    return head[:90]
+
+
+def report(step, out):
+    """step: [(start_us, end_us, name)] of one training step in launch order."""
+    T0 = step[0][0]
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    with open(out, "w") as f:
+        prev = T0
+        for s, e, nm in step:
+            f.write("%.2f\t%.2f\t%.2f\t%s\n" % (s - T0, e - s, s - prev, short(nm)))
+            prev = e
+    cls = {}
+    for s, e, nm in step:
+        c = cls.setdefault(short(nm).split("<")[0], [0.0, 0])
+        c[0] += e - s
+        c[1] += 1
+    gaps = sorted(((b[0] - a[1], a[2][:40]) for a, b in zip(step, step[1:])), reverse=True)
+    print("step wall %.3f ms, kernel time %.3f ms, %d kernels; largest gap between two kernels %.1f us (after %s)" % (
+        (max(e for _, e, _ in step) - T0) / 1e3, sum(e - s for s, e, _ in step) / 1e3, len(step), gaps[0][0], gaps[0][1]))
+    if gaps[0][0] > 300.0:
+        print("WARNING: a gap of %.0f us -- the tracer dropped events; this table is incomplete" % gaps[0][0])
+    for k, (t, c) in sorted(cls.items(), key=lambda kv: -kv[1][0]):
+        print("  %-44s x%-4d %9.1f us  avg %6.2f" % (k[:44], c, t, t / c))
+
+
+if "--csv" in sys.argv:
+    import csv
+    args = [a for a in sys.argv[1:] if a != "--csv"]
+    rows = sorted(csv.DictReader(open(args[0])), key=lambda r: int(r["Start_Timestamp"]))
+    ev = [(int(r["Start_Timestamp"]) / 1e3, int(r["End_Timestamp"]) / 1e3, r["Kernel_Name"]) for r in rows]
+    starts = [i for i, e in enumerate(ev) if "pack_input_kernel" in e[2]]
+    # the last COMPLETE step: between the last two pack_input kernels (what follows the last one may include the bench's teardown)
+    report(ev[starts[-2]:starts[-1]], args[1] if len(args) > 1 else "gpurun_out/step_trace.tsv")
+    sys.exit(0)
+
 import numpy as np, torch
 import __graft_entry__ as g
 g.build()
@@ -35,30 +78,4 @@ for e in prof.events():
 ev.sort()
 starts = [i for i, e in enumerate(ev) if "pack_input_kernel" in e[2]]
 step = ev[starts[-1]:]
-T0 = step[0][0]
-
-
-def short(nm):
-    nm = nm.replace("void ", "").replace("(anonymous namespace)::", "")
-    head = nm.split("(")[0]
-    return head[:90]
-
-
-os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
-with open(out, "w") as f:
-    prev = T0
-    for s, e, nm in step:
-        f.write("%.2f\t%.2f\t%.2f\t%s\n" % (s - T0, e - s, s - prev, short(nm)))
-        prev = e
-cls = {}
-for s, e, nm in step:
-    c = cls.setdefault(short(nm).split("<")[0], [0.0, 0])
-    c[0] += e - s
-    c[1] += 1
-gaps = sorted(((b[0] - a[1], a[2][:40]) for a, b in zip(step, step[1:])), reverse=True)
-print("step wall %.3f ms, kernel time %.3f ms, %d kernels; largest gap between two kernels %.1f us (after %s)" % (
-    (max(e for _, e, _ in step) - T0) / 1e3, sum(e - s for s, e, _ in step) / 1e3, len(step), gaps[0][0], gaps[0][1]))
-if gaps[0][0] > 300.0:
-    print("WARNING: a gap of %.0f us -- the tracer dropped events; this table is incomplete" % gaps[0][0])
-for k, (t, c) in sorted(cls.items(), key=lambda kv: -kv[1][0]):
-    print("  %-44s x%-4d %9.1f us  avg %6.2f" % (k[:44], c, t, t / c))
+report(step, out)

@@ -19,7 +19,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 38, 39, 65)
+CANDIDATES = (2, 4, 5, 6, 9, 10, 12, 13, 14, 33, 34, 35, 36, 37, 38, 39, 65, 99)
 
 
 def main():
@@ -207,9 +207,12 @@ def main():
         print("step wall time: old table %s ms, new table %s ms" % (["%.3f" % w for w in walls["old"]], ["%.3f" % w for w in walls["new"]]))
         better = min(walls["new"]) < min(walls["old"]) and sum(walls["new"]) < sum(walls["old"])
         if changed and better and not args.dry:
+            rule = (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG, ops.PWRES_TILE_CONFIG)
             for key, cfg in new.items():
-                if cfg > ops.SPLITK_FLAG or cfg in (ops.DIRECT3_TILE_CONFIG, ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG):
+                if cfg > ops.SPLITK_FLAG or cfg in rule:
                     continue                                  # chosen by rule at net build (split-K, direct launches): not table entries
+                if cur_of[key] in rule:
+                    ops._TUNED[key + "#norule"] = cfg         # a table tile beat the rule's launch: the measured exception (Net._tune)
                 ops._TUNED[key] = cfg
                 if cfg > ops.I5_FLAG:
                     i3 = {c: t for c, t in times[key].items() if 0 < c <= ops.N_TILE_CONFIGS}
