@@ -32,6 +32,7 @@ struct ResK {
   int N, H, W, HW;                                        // images; map (input = output: stride 1, "same" geometry)
   int NG, CPT;                                            // channel groups per image, output channels per group (a multiple of 8)
   int ntiles;                                             // N * NG; tile t = image t / NG, group t % NG
+  int per;                                                // consecutive tiles per workgroup: the groups of ONE image where N * NG > CUs (its image staged once)
   int npi;                                                // 1 KB pieces of the image (+ its row of zeros)
   int dh[9], dw[9], dd[9];                                // tap (r, s) reads input pixel (oh + dh, ow + dw) = pixel index + dd: r - pad_t, s - pad_l, dh W + dw
 };
@@ -143,7 +144,7 @@ conv_resident_kernel(const ConvK p, const ResK q) {
   const int wave = wave_id();
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
-  const int first = xcd_remap((int)blockIdx.x, (int)gridDim.x), G_ = (int)gridDim.x;
+  const int first = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int frow = lane & 15, fch = lane >> 4;
 
   // the image: pieces wave, wave + 8, ... of 64 chunks each; chunk ci = pixel ci / C8, slot ci % C8 holds source chunk
@@ -173,41 +174,62 @@ conv_resident_kernel(const ConvK p, const ResK q) {
       rowch[i] = wv[i] ? rperm<NB>(row >> 4, row & 15) : 0;                       // channel within the tile
       wo[i] = (rowch[i] * RS * (8 * C8) + c * 8) * 2;
     }
-    for (int t = first; t < q.ntiles; t += G_) {
-      const int im = t / q.NG, g = t - im * q.NG;
-      const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
-      const int wbase = cb * RS * (8 * C8) * 2;
-      auto issue_tap = [&](const int tap) {
-        u32x4* dst = ring + (tap % D) * SLOTP + lw * 64;
+    // The taps of ALL tiles of this workgroup form ONE stream through the ring (tap T of the stream in slot T % D): behind the
+    // barrier that frees a group's slots the loaders go on into the NEXT tile's filter slice, so that a tile after the first
+    // finds its first group landed (BATCH_SIZE 256: the four channel groups of an image in one workgroup; by the stamps a tile
+    // after the first waits 0.1-0.3 us at its P barrier, against 1.5-2 us with the ring restarted per tile).  `base` = slot of the tile's tap 0.
+    int im_in = -1, base = 0;
+    const int t0 = first * q.per, t1 = min(t0 + q.per, q.ntiles);
+    for (int t = t0; t < t1; ++t) {
+      const int im = t / q.NG;
+      const bool last = t + 1 == t1;
+      auto issue_tap = [&](const int rel) {               // rel: tap index off this tile's tap 0 (>= RS: the next tile's)
+        const int tt = rel < RS ? t : t + 1, tap = rel < RS ? rel : rel - RS;
+        const int g = tt - (tt / q.NG) * q.NG;
+        const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
+        const int wbase = cb * RS * (8 * C8) * 2;
+        const int sl = D == RS ? tap : (base + rel) % D;
+        u32x4* dst = ring + sl * SLOTP + lw * 64;
 #pragma unroll
         for (int i = 0; i < PT; ++i)
           glds16(wr, dst + i * (kRLW * 64), (wv[i] && cb + rowch[i] < ce) ? wbase + wo[i] + tap * (8 * C8) * 2 : (int)kOOB);
       };
-      issue_image(im);
-#pragma unroll
-      for (int tap = 0; tap < DD; ++tap) issue_tap(tap);
+      auto slot_of = [&](const int rel) { return D == RS ? rel % RS : (base + rel) % D; };
       // Taps are PUBLISHED IN GROUPS of GR (one barrier per group, not per tap: every barrier costs the multiplying waves a
       // drain of their LDS queue and a rendezvous with the loaders' wait + read-back chain -- 0.25 us each by the probes of
       // tools/res_stamps.py, seven of them a third of the 1x7 K loop).  The ring holds two groups: the next one is in flight
       // while the current one is multiplied, and a group's slots are refilled behind the barrier that ends it.
-      wait_vmcnt_k<PT>(DD - G0);                          // the image and the first group have retired (this wave's share) ...
-      lds_readback_wait(lds_readback_issue(ring + ((G0 - 1) % D) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));   // ... and landed
+      if (t == t0) {
+        issue_image(im);
+#pragma unroll
+        for (int tap = 0; tap < DD; ++tap) issue_tap(tap);
+        wait_vmcnt_k<PT>(DD - G0);                        // the image and the first group have retired (this wave's share) ...
+      } else if (im != im_in) {
+        issue_image(im);                                  // (behind the D taps issued during the last tile: everything has to retire)
+        wait_vmcnt<0>();
+      } else {
+        wait_vmcnt_k<PT>(DD - G0);                        // the D taps issued during the last tile, less the first group
+      }
+      im_in = im;
+      lds_readback_wait(lds_readback_issue(ring + slot_of(G0 - 1) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));   // ... and landed
       raw_barrier();                                      // P: image + group 0 published
-      int issued = DD;
 #pragma unroll
       for (int g0 = 0; g0 < RS; g0 += GR) {
         const int e = g0 + GR < RS ? g0 + GR : RS;        // one past the group's last tap
+        // taps issued so far, off this tile's tap 0: DD + g0 -- in the workgroup's last tile no further than RS
         if (e < RS) {
           const int e2 = e + GR < RS ? e + GR : RS;       // the next group [e, e2) has retired: behind it, the taps up to issued - 1
-          wait_vmcnt_k<PT>(issued - e2);
-          lds_readback_wait(lds_readback_issue(ring + ((e2 - 1) % D) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
+          if (last) wait_vmcnt_k<PT>((DD + g0 < RS ? DD + g0 : RS) - e2);
+          else wait_vmcnt_k<PT>(DD + g0 - e2);
+          lds_readback_wait(lds_readback_issue(ring + slot_of(e2 - 1) * SLOTP + (PT - 1) * (kRLW * 64) + lw * 64 + lane));
         }
         raw_barrier();                                    // B: the group's slots are free, the next group is published
 #pragma unroll
         for (int k2 = g0; k2 < e; ++k2)
-          if (issued < RS) { issue_tap(issued); ++issued; }
+          if (DD + k2 < RS || !last) issue_tap(DD + k2);
       }
       if constexpr (EV == 1) raw_barrier();               // the multiplying waves' statistics reduce
+      if constexpr (D != RS) base = (base + RS) % D;
     }
     return;
   }
@@ -246,15 +268,18 @@ conv_resident_kernel(const ConvK p, const ResK q) {
   };
 #ifdef MBX_I5_STAMPS
   const bool stamp = p.stamps && tid == 0 && blockIdx.x < 64;      // debug build (tools/res_stamps.py): tile phases of the first tile
-#define MBXR_STAMP(i) do { if (stamp && t == first) p.stamps[(blockIdx.x * 8) * 4 + (i)] = wall_clock64(); } while (0)
+#define MBXR_STAMP(i) do { if (stamp && t == first * q.per + p.dbg) p.stamps[(blockIdx.x * 8) * 4 + (i)] = wall_clock64(); } while (0)
 #else
 #define MBXR_STAMP(i) do { } while (0)
 #endif
-  for (int t = first; t < q.ntiles; t += G_) {
+  int im_in = -1, base = 0;                               // base: ring slot of the tile's tap 0 (the loaders' stream)
+  for (int t = first * q.per, t1 = min(t + q.per, q.ntiles); t < t1; ++t) {
     const int im = t / q.NG, g = t - im * q.NG;
     const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
+    const bool newim = im != im_in;                       // (else: the image is in LDS already, and the last tile's stores may stay in flight)
+    im_in = im;
     MBXR_STAMP(0);
-    issue_image(im);
+    if (newim) issue_image(im);
     // per-channel scale / shift of the affine epilogue (folded batch norm, detect.py:313-326)
     float sc8[NP > 0 ? NP : 1][8], sh8[NP > 0 ? NP : 1][8], sc4[4], sh4[4];
     if constexpr (EV == 3) {
@@ -279,8 +304,10 @@ conv_resident_kernel(const ConvK p, const ResK q) {
     } else {
       tap_rows(0, E[0]);
     }
-    wait_vmcnt<0>();
-    lds_readback_wait(lds_readback_issue(img + lane));
+    if (newim) {
+      wait_vmcnt<0>();
+      lds_readback_wait(lds_readback_issue(img + lane));
+    }
     raw_barrier();                                        // P
     MBXR_STAMP(1);
     // (the rows are the same for every tile; opaque to the compiler here, or it hoists every K step's address out of the
@@ -301,9 +328,13 @@ conv_resident_kernel(const ConvK p, const ResK q) {
     // barrier B_tap sits in the READ stream -- in front of the first read of tap + 1, i.e. one step ahead of the MFMAs --
     // so the last step of a tap is multiplied behind it and covers the latency of the next tap's first reads.
     constexpr int NS = RS * KC, NR = NB + MI, NM = NB * MI;
+    int sofs[RS];                                         // byte offset of each tap's ring slot (compile-time where the ring holds all taps)
+#pragma unroll
+    for (int tap = 0; tap < RS; ++tap) sofs[tap] = (D == RS ? tap : (base + tap) % D) * (SLOTP * 16);
+    if constexpr (D != RS) base = (base + RS) % D;
     bf16x8 wf[2][NB], pf[2][MI];
 #pragma unroll
-    for (int a = 0; a < NB; ++a) wf[0][a] = rread<C8>(EA[a], 0);
+    for (int a = 0; a < NB; ++a) wf[0][a] = rread<C8>(EA[a] + sofs[0], 0);
 #pragma unroll
     for (int f = 0; f < MI; ++f) pf[0][f] = rread<C8>(E[0][f], 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +352,7 @@ conv_resident_kernel(const ConvK p, const ResK q) {
       // compile-time, so that the straight-line schedule of the step stays what it is)
       constexpr bool rd_ = !(MBX_RES_PROBE & 1), mm_ = !(MBX_RES_PROBE & 2);
       if (s + 1 < NS && rd_) {
-        const int so = (tap1 % D) * SLOTP * 16;
+        const int so = sofs[tap1 < RS ? tap1 : 0];
 #pragma unroll
         for (int a = 0; a < NB; ++a) wf[nxt][a] = rread<C8>(EA[a] + so, j1);
 #pragma unroll
@@ -779,6 +810,10 @@ int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s) {
   for (int t = 0; t < RS; ++t) { q.dh[t] = t / k.S - k.pad_t; q.dw[t] = t % k.S - k.pad_l; q.dd[t] = q.dh[t] * q.W + q.dw[t]; }
   int grid = q.ntiles < resident_cus() ? q.ntiles : resident_cus();
   if (k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;
+  // consecutive tiles per workgroup (BATCH_SIZE 256: the four channel groups of an image -- its image lands once, and the next
+  // group's filter slice while this one's outputs are stored)
+  q.per = (q.ntiles + grid - 1) / grid;
+  grid = (q.ntiles + q.per - 1) / q.per;
 #define MBX_RES(C8_, NB_, RS_, MI_, HWC_)                                                                \
   if (C8 == C8_ && NB == NB_ && RS == RS_ && q.HW <= HWC_ && (HWC_ > 64 || q.HW == 64)) {                 \
     if (k.dry) return MBX_OK;                                                                            \
