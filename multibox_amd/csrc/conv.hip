@@ -1429,6 +1429,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     static const unsigned long long sp = getenv("MBX_I5_STAMP_PTR") ? strtoull(getenv("MBX_I5_STAMP_PTR"), nullptr, 10) : 0ull;
     k.stamps = reinterpret_cast<unsigned long long*>(sp);
     k.dbg = getenv("MBX_I5_DBG") ? atoi(getenv("MBX_I5_DBG")) : 0;      // (read per call: tools switch it between launches)
+    k.stagger = getenv("MBX_STAGGER") ? atoi(getenv("MBX_STAGGER")) : 0;
   }
 #endif
   for (int c = 0; c < 4; ++c) { k.cls_m0[c] = 0; k.cls_hw[c] = 1; k.cls_w[c] = 1; }

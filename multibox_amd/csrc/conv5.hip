@@ -45,13 +45,22 @@ struct Ig5 {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int MY, int NW, int EV, int MODE>
-__global__ void __launch_bounds__(1024)
+// NLW: loader waves.  Eight by default (16 waves: 128 registers each).  FOUR for the epilogues that read as much as they
+// write (residual forward, accumulate + mask data gradient) on the large tiles: 12 waves leave each 168 registers, which
+// hold the WHOLE tile's epilogue reads -- issued before the K loop, landing while the tile is multiplied -- where the
+// 16-wave block holds a quarter and reads the rest one pixel block at a time behind the K loop (by the stamps of
+// tools/i5_stamps.py the rows of a 256 x 128 residual tile take 3.7 us that way against 1.1 us for a plain store: 16 KB in
+// flight per CU against the latency of HBM).  Each loader wave then carries two of the eight row octets of a piece.
+template <int MY, int NW, int EV, int MODE, int NLW = 8>
+__global__ void __launch_bounds__(512 + 64 * NLW)
 conv_igemm5_kernel(const ConvK p) {
   using G = Ig5<MY, NW>;
   constexpr bool PW = MODE == 1;
   constexpr int BM = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, MI = G::MI, NI = G::NI, STAGE = G::STAGE, NST = G::NST;
-  constexpr int NL = MY + NW;                                       // LDS-DMA instructions per loader wave and K step
+  constexpr int LV = 8 / NLW;                                       // row octets ("virtual loaders") per loader wave
+  constexpr int NL = LV * (MY + NW);                                // LDS-DMA instructions per loader wave and K step
+  static_assert(NLW == 8 || NLW == 4, "loader waves");
+  static_assert((NST - 2) * NL < 64, "vmcnt");
   constexpr int NBAR = (EV == 1 || EV == 6) ? 1 : 0;                             // barriers of one tile's epilogue (statistics reduce)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   float* const red = reinterpret_cast<float*>(smem + NST * STAGE);  // [WM][BN][2]
@@ -69,6 +78,15 @@ conv_igemm5_kernel(const ConvK p) {
   const int wave = wave_id();
   const int ntiles = p.tiles_m * p.tiles_n;
   const int first = xcd_remap(blockIdx.x, gridDim.x);               // tiles first, first + grid, ...
+#ifdef MBX_I5_STAMPS
+  // (probe, debug builds: do workgroups that start together stay in step -- equal K loops, then 256 epilogues sharing HBM -- and
+  // would a start offset of (first % 4) phases help?  Measured: no; every launch is longer by the largest offset, at BATCH_SIZE 64
+  // and 256 alike (tools/stagger_probe.sh, LAB_NOTES round 5): a tile's time is a property of its CU's memory path.)
+  if (p.stagger) {
+    const int n = (first & 3) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);        // 512 cycles = a quarter of a microsecond
+  }
+#endif
   const int nk = (p.Ktot + 63) >> 6;
   // nk > NST: the loaders read s_ids[j + 1] when they have issued the last K step of tile j, i.e. in iteration nk - NST of
   // tile j's K loop; the compute waves publish that id after the last barrier of tile j - 1 -- with nk == NST the read
@@ -81,34 +99,39 @@ conv_igemm5_kernel(const ConvK p) {
 
   if (wave >= 8) {
     // -------------------------------------------------------------------------------------------- loader waves
-    const int lw = wave - 8;
+    const int lw0 = wave - 8;                                       // row octets lw0, lw0 + NLW, ... of every piece
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
     const int r8 = lane >> 3;
     const int chunk = (lane & 7) ^ r8;                              // source chunk of this lane's slot (row & 7 == r8)
     // filter rows (64 i + 8 lw + r8) carry the key of the permuted fragment reads (conv_igemm3_kernel): bits 3-4 and 1 of the row
-    const int chunkw = (lane & 7) ^ (((lw & 3) << 1) | ((r8 >> 1) & 1));
+    int chunkw[LV];
+#pragma unroll
+    for (int v = 0; v < LV; ++v) chunkw[v] = (lane & 7) ^ ((((lw0 + NLW * v) & 3) << 1) | ((r8 >> 1) & 1));
     const int ldx2 = p.ldx * 2;
     // issue cursor: (tile, K step) two steps ahead of the compute waves; row state of THAT tile
     int t_i = first, it_i = 0, st_issue = 0, j_i = 0;               // j_i: index of the issue tile in this workgroup's sequence
-    int hb[MY], wb[MY], ro[MY], wo[NW];
+    int hb[LV][MY], wb[LV][MY], ro[LV][MY], wo[LV][NW];
     int kc = 0, kr = 0, ks = 0;
 #define MBX5_SETUP_TILE()                                                                                     \
   do {                                                                                                        \
     const int tn_ = t_i % p.tiles_n, tm_ = t_i / p.tiles_n;                                                   \
-    _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                          \
-      const int m = tm_ * BM + 64 * i + 8 * lw + r8;                                                          \
-      const bool mv = m < p.M;                                                                                \
-      int img, oh, ow;                                                                                        \
-      decode_pixel(p, mv ? (unsigned)m : 0u, img, oh, ow);                                                    \
-      hb[i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);                                                         \
-      wb[i] = ow * p.mul - p.pad_l;                                                                           \
-      ro[i] = (img * p.x_img_stride + (hb[i] * p.W_in + wb[i]) * p.ldx) * 2;                                  \
-      if (PW && !mv) ro[i] = (int)kOOB;                                                                       \
-    }                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                          \
-      const int n = tn_ * BN + 64 * i + 8 * lw + r8;                                                          \
-      wo[i] = n < p.C_out ? n * p.Ktot * 2 : -1;                                                              \
+    _Pragma("unroll") for (int v = 0; v < LV; ++v) {                                                          \
+      const int lw = lw0 + NLW * v;                                                                           \
+      _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                        \
+        const int m = tm_ * BM + 64 * i + 8 * lw + r8;                                                        \
+        const bool mv = m < p.M;                                                                              \
+        int img, oh, ow;                                                                                      \
+        decode_pixel(p, mv ? (unsigned)m : 0u, img, oh, ow);                                                  \
+        hb[v][i] = mv ? oh * p.mul - p.pad_t : -(1 << 24);                                                    \
+        wb[v][i] = ow * p.mul - p.pad_l;                                                                      \
+        ro[v][i] = (img * p.x_img_stride + (hb[v][i] * p.W_in + wb[v][i]) * p.ldx) * 2;                       \
+        if (PW && !mv) ro[v][i] = (int)kOOB;                                                                  \
+      }                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                        \
+        const int n = tn_ * BN + 64 * i + 8 * lw + r8;                                                        \
+        wo[v][i] = n < p.C_out ? n * p.Ktot * 2 : -1;                                                         \
+      }                                                                                                       \
     }                                                                                                         \
     kc = chunk * 8; kr = 0; ks = 0;                                                                           \
     while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
@@ -119,27 +142,31 @@ conv_igemm5_kernel(const ConvK p) {
 // wait + read-back behind the whole issue it cost 1.5 ms per step in round 2).
 #define MBX5_ISSUE_A()                                                                                        \
   do {                                                                                                        \
-    u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
     const bool kv = kr < p.R;                                                                                 \
-    if (PW) {                                                                                                 \
-      _Pragma("unroll") for (int i = 0; i < MY; ++i)                                                          \
-        glds16(xr, sp + i * 512, (kv && ro[i] >= 0) ? (ro[i] + kc * 2) : (int)kOOB);                          \
-    } else {                                                                                                  \
-      const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;                                                    \
-      _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                        \
-        const bool ok = kv && ((unsigned)(hb[i] + kr) < (unsigned)p.H_in) &&                                  \
-                        ((unsigned)(wb[i] + ks) < (unsigned)p.W_in);                                          \
-        glds16(xr, sp + i * 512, ok ? (ro[i] + toff) : (int)kOOB);                                            \
+    _Pragma("unroll") for (int v = 0; v < LV; ++v) {                                                          \
+      u32x4* sp = smem + st_issue * STAGE + (lw0 + NLW * v) * 64;                                             \
+      if (PW) {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < MY; ++i)                                                        \
+          glds16(xr, sp + i * 512, (kv && ro[v][i] >= 0) ? (ro[v][i] + kc * 2) : (int)kOOB);                  \
+      } else {                                                                                                \
+        const int toff = (kr * p.W_in + ks) * ldx2 + kc * 2;                                                  \
+        _Pragma("unroll") for (int i = 0; i < MY; ++i) {                                                      \
+          const bool ok = kv && ((unsigned)(hb[v][i] + kr) < (unsigned)p.H_in) &&                             \
+                          ((unsigned)(wb[v][i] + ks) < (unsigned)p.W_in);                                     \
+          glds16(xr, sp + i * 512, ok ? (ro[v][i] + toff) : (int)kOOB);                                       \
+        }                                                                                                     \
       }                                                                                                       \
     }                                                                                                         \
   } while (0)
 #define MBX5_ISSUE_B()                                                                                        \
   do {                                                                                                        \
-    u32x4* sp = smem + st_issue * STAGE + lw * 64;                                                            \
-    const int kb = (it_i * 64 + chunkw * 8) * 2;                      /* the filter lane's own K position */    \
-    const bool kvw = kb < p.Ktot * 2;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                            \
-      glds16(wr, sp + (MY + i) * 512, (kvw && wo[i] >= 0) ? (wo[i] + kb) : (int)kOOB);                        \
+    _Pragma("unroll") for (int v = 0; v < LV; ++v) {                                                          \
+      u32x4* sp = smem + st_issue * STAGE + (lw0 + NLW * v) * 64;                                             \
+      const int kb = (it_i * 64 + chunkw[v] * 8) * 2;                 /* the filter lane's own K position */    \
+      const bool kvw = kb < p.Ktot * 2;                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                          \
+        glds16(wr, sp + (MY + i) * 512, (kvw && wo[v][i] >= 0) ? (wo[v][i] + kb) : (int)kOOB);                \
+    }                                                                                                         \
     kc += 64;                                                                                                 \
     while (kc >= p.C_in) { kc -= p.C_in; if (++ks >= p.S) { ks = 0; ++kr; } }                                 \
     st_issue = st_issue == NST - 1 ? 0 : st_issue + 1;                                                        \
@@ -151,7 +178,7 @@ conv_igemm5_kernel(const ConvK p) {
   } while (0)
 #define MBX5_ISSUE() do { MBX5_ISSUE_A(); MBX5_ISSUE_B(); } while (0)
     // read-back of this lane's slot of the wave's LAST piece (filter piece NW - 1) of ring slot `st_pub`, returned
-#define MBX5_READBACK() lds_readback_wait(lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane))
+#define MBX5_READBACK() lds_readback_wait(lds_readback_issue(smem + st_pub * STAGE + (MY + NW - 1) * 512 + (lw0 + NLW * (LV - 1)) * 64 + lane))
 
     int st_pub = 0;                                                 // ring slot of the step published next
     if (t_i < ntiles) {
@@ -177,8 +204,8 @@ conv_igemm5_kernel(const ConvK p) {
 #endif
 #ifndef MBX_NO_PROBE_I5
         // the NEXT step (steps s+1 .. s+NST-2 are outstanding, + the MY pieces just issued) has retired: this wave's share
-        if (more) wait_vmcnt<(NST - 3) * NL + MY>(); else wait_vmcnt<0>();
-        const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (NL - 1) * 512 + lw * 64 + lane);
+        if (more) wait_vmcnt<(NST - 3) * NL + LV * MY>(); else wait_vmcnt<0>();
+        const unsigned probe = lds_readback_issue(smem + st_pub * STAGE + (MY + NW - 1) * 512 + (lw0 + NLW * (LV - 1)) * 64 + lane);
         if (more) MBX5_ISSUE_B();
         lds_readback_wait(probe);                                   // read-back returned: publish
 #else                                                               // (debug builds only: A/B of what the hand-off costs)
@@ -242,7 +269,8 @@ conv_igemm5_kernel(const ConvK p) {
     // epilogue it is EV 2 with the bf16-mask path compiled out; plain EV 2 here has the bits path compiled out: these
     // kernels have no registers for both.  The 256x128 / 128x256 residual tiles, which also write the bits: one block.)
     constexpr int EVC = EV == 7 ? 2 : EV, BMODE = EV == 7 ? 2 : EV == 2 ? 0 : 1;
-    constexpr int PRE_RAW = (EV == 4 && G::BM * G::BN >= 256 * 128) ? 1
+    constexpr int PRE_RAW = (NLW == 4 && (EV == 4 || EVC == 2)) ? MI                  // (12 waves: the whole tile)
+                            : (EV == 4 && G::BM * G::BN >= 256 * 128) ? 1
                             : (EV == 4 || EVC == 2 || EV == 6) ? 4 / (NA * (EVC == 2 ? 2 : 1)) : 0;
     constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
@@ -357,6 +385,36 @@ int launch5(ConvK& k, hipStream_t s) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, MODE>), dim3(grid), dim3(1024), G::LDS_BYTES, s, k);   \
   } while (0)
+  // Twelve-wave form (four loader waves, the whole tile's epilogue reads in flight across the K loop): pointwise launches with a
+  // residual or an accumulate (+ mask) epilogue on the tiles whose 16-wave form holds only part of them
+  constexpr bool kLW4 = (MY == 3 && NW == 2) || (MY == 4 && NW == 2) || (MY == 2 && NW == 4) || (MY == 2 && NW == 2);
+  // OFF by default: measured level (tools/i5_stamps.py, 256 x 128 residual tile of block17: rows 3.7 -> 1.7 us, K loop 5.7 -> 7.2 us;
+  // detect leg and training step unchanged) -- a CU's vector-memory path holds a fixed number of lines in flight, and what the
+  // epilogue's reads gain by starting early the operand feed behind them loses (LAB_NOTES round 5).  MBX_I5_LW4=1 selects it
+  // (read per call: the parity tests switch it).
+  const char* e4 = getenv("MBX_I5_LW4");
+  const int lw4 = (e4 && e4[0] == '1') ? 1 : 0;
+  if constexpr (kLW4) {
+    // (not: the 128 x 128 residual tile, whose reads all fit the 16-wave form; the bf16-mask epilogue on the 64 x 64 wave tiles: 6 spills)
+    if (lw4 && k.pw && (ev == 4 || ev == 7 || (ev == 2 && MY * NW < 8)) && !(ev == 4 && MY == 2 && NW == 2)) {
+      static bool attr4[8] = {};
+#define MBX5_LAUNCH4(EV)                                                                                      \
+  do {                                                                                                        \
+    if (!attr4[EV]) {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm5_kernel<MY, NW, EV, 1, 4>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);                    \
+      attr4[EV] = true;                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, 1, 4>), dim3(grid), dim3(768), G::LDS_BYTES, s, k);    \
+  } while (0)
+      if (ev == 4) MBX5_LAUNCH4(4);
+      else if (ev == 7) MBX5_LAUNCH4(7);
+      else if constexpr (MY * NW < 8) MBX5_LAUNCH4(2);
+#undef MBX5_LAUNCH4
+      MBX_LAUNCH_CHECK();
+      return MBX_OK;
+    }
+  }
 #define MBX5_EV(EV) case EV: if (k.pw) MBX5_LAUNCH(EV, 1); else MBX5_LAUNCH(EV, 0); break;
   switch (ev) {
     MBX5_EV(0) MBX5_EV(1) MBX5_EV(3) MBX5_EV(4)

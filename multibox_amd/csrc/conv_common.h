@@ -86,6 +86,7 @@ struct ConvK {
 #ifdef MBX_I5_STAMPS
   unsigned long long* stamps;          // debug build: wall_clock64() per tile phase of the first 8 tiles of 64 blocks
   int dbg;                             // debug build: MBX_I5_DBG timing probes (bit 0: compute waves idle, bit 1: loaders do not wait)
+  int stagger;                         // debug build: MBX_STAGGER -- workgroup w of a persistent launch starts (w % 4) * stagger quarter-microseconds late
 #endif
 };
 

@@ -15,8 +15,8 @@ from multibox_amd import build as B_
 B_.build(force=True)
 from multibox_amd import ops
 
-B = 64
-TILES = {33: "128x64", 34: "128x128", 35: "192x128", 36: "256x128", 37: "256x64"}
+B = int(os.environ.get("KB_B", "64"))
+TILES = {33: "128x64", 34: "128x128", 35: "192x128", 36: "256x128", 37: "256x64", 38: "128x192", 39: "128x256"}
 
 
 def run(name, H, W, Ci, Co, R, S, pt, pl, cfg, epi):
@@ -54,6 +54,8 @@ cfgs = [int(a) for a in sys.argv[1:]] or [33, 34, 35, 36, 37]
 for cfg in cfgs:
     for epi in ("store", "stats", "res"):
         run("b17_up_1x1_384_1088", 17, 17, 384, 1088, 1, 1, 0, 0, cfg, epi)
+    if os.environ.get("I5S_UP_ONLY"):
+        continue
     run("b17_fused_1x1_1088_320", 17, 17, 1088, 320, 1, 1, 0, 0, cfg, "stats")
     run("b17_1x7_128_160", 17, 17, 128, 160, 1, 7, 0, 3, cfg, "stats")
     run("m6a_3x3_256_256", 35, 35, 256, 256, 3, 3, 1, 1, cfg, "stats")
