@@ -7,6 +7,20 @@
 
 namespace {
 
+// Workgroups are dealt to the eight XCDs round-robin (b and b + 8 share one): logical id = a contiguous run per XCD, the mapping
+// of the convolution kernels' tiles (conv_common.h xcd_remap).  A row-wise kernel that walks its rows by LOGICAL id reads what
+// the producing convolution's tiles left in THIS XCD's L2 and leaves its output where the consuming convolution's tiles will
+// look for it: an XCD's L2 keeps what a kernel wrote across the kernel boundary (tools/l2_persist.hip: 32 MB read back by the
+// XCD that wrote it 6.2 us, by another 8.2 us).  MEASURED LEVEL on the training step (tools/xcd_rows_ab.sh: 14.64-14.66 vs
+// 14.61-14.65 ms; the 512 x 512 leg 37.70 vs 37.85): the convolutions' K loops are not paced by where their operands come
+// from (LAB_NOTES round 2: loaders that do not wait for their data run the same 0.43 us per step).  Off; MBX_XCD_ROWS=1.
+__device__ __forceinline__ int xcd_logical(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+inline int xcd_rows_on() { static const int v = [] { const char* e = getenv("MBX_XCD_ROWS"); return e ? atoi(e) : 0; }(); return v; }
+
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 constexpr int kT = 256;
@@ -425,17 +439,27 @@ __global__ void __launch_bounds__(kT)
 bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count, float eps, float decay,
                      const unsigned short* __restrict__ y, long long M, int C, const float* __restrict__ beta, int relu,
                      unsigned short* __restrict__ a, int ld_a, float* __restrict__ mean, float* __restrict__ rstd,
-                     float* __restrict__ mmean, float* __restrict__ mvar, const ChanMap map, float* __restrict__ thr) {
+                     float* __restrict__ mmean, float* __restrict__ mvar, const ChanMap map, float* __restrict__ thr, int xcd_rows) {
   extern __shared__ __attribute__((aligned(16))) float s_par[];          // [3][C]: mean, rstd, beta
   const int C8 = C >> 3;
   const int rpi = kT / C8 > 0 ? kT / C8 : 1;              // rows per sweep of the workgroup (C8 <= 256)
   const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
   const bool active = rr < rpi;
   const int c = vc << 3;
-  const long long step = (long long)gridDim.x * rpi;
+  // xcd_rows: every XCD owns an eighth of the rows (the eighth its convolution tiles cover) and ITS workgroups sweep it with
+  // the XCD's stride -- eight compact windows moving through the tensor; else one grid-strided sweep (rows interleaved over
+  // all XCDs at rpi-row granularity).  (A contiguous range per WORKGROUP measured 7 % slower on this kernel: 456 scattered
+  // streams instead of a window.)
+  long long step = (long long)gridDim.x * rpi, Mend = M;
   long long m = (long long)blockIdx.x * rpi + rr;
+  if (xcd_rows && gridDim.x >= 8) {
+    const int xcd = (int)blockIdx.x & 7, nx = ((int)gridDim.x - xcd + 7) >> 3;
+    const long long perx = ((M + 7) / 8 + rpi - 1) / rpi * rpi;
+    const long long lo = (long long)xcd * perx;
+    step = (long long)nx * rpi; m = lo + (long long)((int)blockIdx.x >> 3) * rpi + rr; Mend = lo + perx < M ? lo + perx : M;
+  }
   u32x4 first = u32x4{0u, 0u, 0u, 0u};
-  if (active && m < M) first = ld8(y + m * C + c);
+  if (active && m < Mend) first = ld8(y + m * C + c);
   for (int ch = threadIdx.x; ch < C; ch += kT) {
     // the rows are 64-bit fixed-point sums (2^-20 units) added by integer atomics: exact integer sum, then one conversion
     const longlong2* src = reinterpret_cast<const longlong2*>(part) + ch;
@@ -482,9 +506,9 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mu[j] = s_par[c + j]; rs[j] = s_par[C + c + j]; be[j] = s_par[2 * C + c + j]; }
   u32x4 cur = first;
-  for (; m < M; m += step) {
+  for (; m < Mend; m += step) {
     u32x4 nxt = u32x4{0u, 0u, 0u, 0u};
-    if (m + step < M) nxt = ld8(y + (m + step) * C + c);      // next row's load in flight behind this row's arithmetic
+    if (m + step < Mend) nxt = ld8(y + (m + step) * C + c);   // next row's load in flight behind this row's arithmetic
     float f[8];
     unpack8(cur, f);
 #pragma unroll
@@ -649,7 +673,8 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
   const int vc = threadIdx.x % C8, rr = threadIdx.x / C8;
   const bool active = rr < rpi;
   const int c = vc << 3;
-  const long long r0 = (long long)blockIdx.x * rpb;
+  // (fault bit 1: row slices dealt to the XCDs in contiguous runs, like the tiles of the data gradient that wrote da -- xcd_logical)
+  const long long r0 = (long long)((fault & 2) ? xcd_logical((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * rpb;
   long long nr = (r0 + rpb > M ? M : r0 + rpb) - r0;                           // rows of this workgroup's slice
   const int nrows = nr > 0 ? (int)nr : 0;
   // slice-relative buffer descriptors: 32-bit offsets, rows past the slice read zeros / are not stored
@@ -741,7 +766,7 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
     const unsigned sub = b % kObSub, n_sub = (G - sub + kObSub - 1) / kObSub, n_top = G < kObSub ? G : kObSub;
     s_timeout = 0;
     // fault injection (tests only, MBX_DEBUG_BARRIER_FAULT=1): workgroup 0 never arrives, everyone else times out
-    bool last = (fault && b == 0) ? false : atomicAdd(ctl + kObLine * (1 + sub), 1u) == n_sub - 1;
+    bool last = ((fault & 1) && b == 0) ? false : atomicAdd(ctl + kObLine * (1 + sub), 1u) == n_sub - 1;
     if (last) last = atomicAdd(ctl + kObLine * (1 + kObSub), 1u) == n_top - 1;
     if (last) {
       for (int r = 0; r < kObRel; ++r)
@@ -1750,7 +1775,7 @@ extern "C" int mbx_bn_bwd_onepass_mapped(const void* da, int ld_da, int relu, co
 #define MBX_OB(NV, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_bwd_onepass_kernel<NV, RELU>), dim3(g.G), dim3(kObT), lds, mbx_s(stream), (cus)da, ld_da,      \
                      (cus)y, (long long)M, C, mean, rstd, beta, dbeta, (us)dy, (float*)ws, g.rpi, g.rpb,               \
-                     (float)(1.0 / (double)M), spin_limit, fault, step_poison, cm, map_max)
+                     (float)(1.0 / (double)M), spin_limit, fault | (xcd_rows_on() << 1), step_poison, cm, map_max)
 #define MBX_OB_NV(NV) do { if (relu) MBX_OB(NV, true); else MBX_OB(NV, false); } while (0)
   if (g.nv <= 2) MBX_OB_NV(2);
   else if (g.nv <= 4) MBX_OB_NV(4);
@@ -2049,7 +2074,7 @@ extern "C" int mbx_bn_apply_fused_mapped(const void* stats_partial, int rows, in
   if (g > rows_blocks) g = rows_blocks;
   hipLaunchKernelGGL(bn_apply_rows_kernel, dim3((unsigned)g), dim3(kT), (size_t)3 * C * sizeof(float), mbx_s(stream),
                      reinterpret_cast<const float*>(stats_partial), rows, 1.0 / (double)count, eps, decay, (cus)y, (long long)M, C,
-                     beta, relu, (us)a, ld_a, mean, rstd, mmean, mvar, cm, relu_thr);
+                     beta, relu, (us)a, ld_a, mean, rstd, mmean, mvar, cm, relu_thr, xcd_rows_on());
   MBX_LAUNCH_CHECK();
   return MBX_OK;
 }
