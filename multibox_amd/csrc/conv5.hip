@@ -198,6 +198,9 @@ conv_igemm5_kernel(const ConvK p) {
       for (int it = 0; it < nk; ++it) {
         const bool more = t_i < ntiles;                             // anything left to issue (this or a later tile)?
         st_pub = st_pub == NST - 1 ? 0 : st_pub + 1;                // the NEXT step's slot
+#ifdef MBX_I5_STAMPS
+        if (p.dbg & 4) { raw_barrier(); continue; }                 // timing probe: the loaders issue nothing (the multiplying waves alone; wrong results)
+#endif
         if (more) MBX5_ISSUE_A();
 #ifdef MBX_I5_STAMPS
         if (p.dbg & 2) { if (more) MBX5_ISSUE_B(); raw_barrier(); continue; }   // timing probe: do not wait for the landing (wrong results)
@@ -258,6 +261,9 @@ conv_igemm5_kernel(const ConvK p) {
 #define MBX5_STAMP(i) do { } while (0)
 #endif
     MBX5_STAMP(0);                                                  // tile start
+#ifdef MBX_I5_STAMPS
+    const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();   // (core-clock counter: the clock the chip holds in the K loop)
+#endif
     // The epilogue's READS (residual skip / accumulate source / ReLU mask) are issued HERE, before the K loop: the compute
     // waves issue no other vector-memory instruction in the loop and never wait on vmcnt there, so the reads -- up to
     // 64 KB per tile, the HBM-bound half of a short-K tile's life -- land while the tile is multiplied; the epilogue then
@@ -310,6 +316,9 @@ conv_igemm5_kernel(const ConvK p) {
       raw_barrier();
     }
     MBX5_STAMP(1);                                                  // K loop done
+#ifdef MBX_I5_STAMPS
+    if (stamp) p.stamps[(blockIdx.x * 8 + tnum) * 4 + 3] = __builtin_amdgcn_s_memtime() - cyc0;
+#endif
     // ---------------------------------------------------------------- epilogue: straight from the accumulators
     if (fetcher) s_ids[(jt + 2) & 3] = tile_of(raw2);               // visible behind the next tile's K-loop barriers
     float s1[NA][8], s2[NA][8], sc[NA][8], sh[NA][8];

@@ -45,9 +45,12 @@ def run(name, H, W, Ci, Co, R, S, pt, pl, cfg, epi):
     med = lambda v: float(v.median()) if len(v) else float("nan")
     nk = (R * S * Ci + 63) // 64
     kl, ep = blk[:n, 1] - blk[:n, 0], blk[:n, 2] - blk[:n, 1]
+    raw = buf.cpu().reshape(64, 8, 4)[8].double()
+    cyc = raw[:n, 3]                                           # core-clock cycles of the K loop (+ the epilogue's pre-issued reads)
+    ghz = float((cyc / ((raw[:n, 1] - raw[:n, 0]) * 10.0)).median()) if n else float("nan")   # cycles per nanosecond
     gap = blk[1:n, 0] - blk[:n - 1, 2]
-    print("%-24s %-7s %-5s launch %6.1f us | tiles/block %d  K loop %.2f us (%d steps: %.2f us each)  rows %.2f us  stats+next %.2f us" % (
-        name, TILES[cfg], epi, a.elapsed_time(b) * 1e3, n, med(kl), nk, med(kl) / nk, med(ep), med(gap)), flush=True)
+    print("%-24s %-7s %-5s launch %6.1f us | tiles/block %d  K loop %.2f us (%d steps: %.2f us each)  rows %.2f us  stats+next %.2f us  | core clock in the K loop %.2f GHz" % (
+        name, TILES[cfg], epi, a.elapsed_time(b) * 1e3, n, med(kl), nk, med(kl) / nk, med(ep), med(gap), ghz), flush=True)
 
 
 cfgs = [int(a) for a in sys.argv[1:]] or [33, 34, 35, 36, 37]
