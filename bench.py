@@ -4,7 +4,8 @@ heads forward, on-device matching + loss, backward, RMSProp/EMA) on 299x299 synt
 5 aspect-ratio priors (P=646), BATCH_SIZE=64 per GPU, bf16 storage / fp32 accumulate.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...          (starts N ranks itself: launch_plan / spawn_ranks below)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the MFMA implicit-GEMM
 convolution, forward + data-gradient launches) from the kernels' begin/end timestamps over three extra
@@ -46,6 +47,53 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configurations (fine-tune, 512x512)")
     ap.add_argument("--config-steps", type=int, default=10)
     return ap.parse_args()
+
+
+def launch_plan(gpus, env, argv, visible_devices, script=None, port=None):
+    """What `--gpus N` means for THIS process (no GPU is touched here; decided before torch is imported):
+      ("run", None)        -- this process is a rank (or the single-GPU run): go on
+      ("spawn", [cmd...])  -- --gpus N > 1 and no rendezvous in the environment: start N ranks as a CHILD
+                              `python -m torch.distributed.run` (never exec: a process that may have initialised the GPU
+                              must not replace itself) and hand its exit code back
+      ("refuse", message)  -- the request cannot be honoured: WORLD_SIZE disagrees with --gpus, or fewer than N devices are
+                              visible.  A line labelled n_gpus: 1 under `--gpus 8` would be a void measurement."""
+    world_env = env.get("WORLD_SIZE")
+    if gpus < 1:
+        return "refuse", "--gpus must be >= 1 (got %d)" % gpus
+    if world_env is not None:
+        if int(world_env) != gpus:
+            return "refuse", ("WORLD_SIZE=%s (the launcher started that many ranks) but --gpus %d: refusing to print a line "
+                              "whose n_gpus does not match the request" % (world_env, gpus))
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if visible_devices < gpus:
+        return "refuse", "--gpus %d but only %d GPU(s) visible on this node: not starting ranks that would share a device" % (gpus, visible_devices)
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def spawn_ranks(cmd):
+    """Run the N-rank job as a child process; its stdout (rank 0's ONE JSON line) and stderr pass straight through."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL over xGMI needs it on this host driver
+    return subprocess.call(cmd, env=env)
+
+
+def visible_gpu_count():
+    """Devices visible to this process WITHOUT initialising the GPU (torch.cuda.device_count() does not, on this image)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
 
 
 def usable_cores():
@@ -502,6 +550,14 @@ def input_leg():
 
 def main():
     args = parse()
+    # --gpus N: start N ranks (one per GPU, RCCL) unless a launcher already did -- decided before anything touches the GPU
+    need_count = args.gpus > 1 and "WORLD_SIZE" not in os.environ
+    action, what = launch_plan(args.gpus, os.environ, sys.argv[1:], visible_gpu_count() if need_count else 0)
+    if action == "refuse":
+        print("bench.py: " + what, file=sys.stderr)
+        raise SystemExit(2)
+    if action == "spawn":
+        raise SystemExit(spawn_ranks(what))
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -527,6 +583,8 @@ def main():
         torch.distributed.all_reduce(ones)
         rccl = {"backend": torch.distributed.get_backend(pg), "ranks": torch.distributed.get_world_size(pg),
                 "allreduce_of_ones": int(ones)}
+    # the line's n_gpus is what --gpus asked for, and the process group really spans that many ranks
+    assert world == args.gpus and rccl["ranks"] == args.gpus and rccl["allreduce_of_ones"] == args.gpus, (world, args.gpus, rccl)
     from multibox_amd.engine import Net
     from multibox_amd.trainer import Trainer, decay_steps
     from multibox_amd import priors as PR
@@ -535,8 +593,11 @@ def main():
     B = args.batch
     ars = DEFAULT_ASPECT_RATIOS[args.k]
     priors = PR.priors_for_input_size(ars, args.input_size).astype(np.float32)
+    from multibox_amd.dist import bn_max_workgroups_for
+    # N>1: leave the CUs RCCL's channels can hold to the collectives of the bucket in flight (derived, not a constant)
+    bn_cap, bn_cap_why = bn_max_workgroups_for(world, torch.cuda.get_device_properties(local_rank).multi_processor_count)
     net = Net(batch=B, input_size=args.input_size, k=args.k, mode="train", fine_tune=args.fine_tune, seed=2,
-              bn_max_workgroups=192 if world > 1 else 0)     # N>1: leave CUs to the RCCL kernels of the bucket in flight
+              bn_max_workgroups=bn_cap)
     tr = Trainer(net, priors, max_num_bboxes=args.max_num_bboxes, location_loss_alpha=1000.0,
                  decay_steps_=decay_steps(56945, B * world, 4), use_graph=not args.no_graph, process_group=pg)
     images, gt, n = synthetic_batch(B, args.input_size, args.max_num_bboxes, seed=100 * rank)    # each rank its own shard
@@ -581,7 +642,8 @@ def main():
                    "allreduce_exposed_ms_worst_step": round(float(hi[2]), 3),
                    "buckets_bytes": [4 * (h - l) for _, l, h in tr._segments],
                    "last_bucket_carries": "beta gradients + step control block (%d bytes)" % (4 * (net.nBt + 8)),
-                   "weight_gradient_overlap_cus": tr.overlap_cus}
+                   "weight_gradient_overlap_cus": tr.overlap_cus,
+                   "grid_barrier_workgroup_cap": bn_cap, "cus_left_to_rccl": bn_cap_why}
     losses = tr.losses()
     # health over ALL ranks: matching status and grid-barrier timeouts of the last step (summed)
     health = torch.tensor([int(tr.match_status().max() != 0), net.barrier_timeouts()], dtype=torch.int32, device="cuda")

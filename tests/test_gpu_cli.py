@@ -270,3 +270,14 @@ def test_bench_contract_over_rccl(tmp_path):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["vs_baseline"] is None
     assert out["matching_ok"] and out["grid_barrier_timeouts"] == 0 and out["value"] > 0
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_refuses():
+    """`bench.py --gpus 2` where one device is visible: non-zero exit and a reason, no JSON line labelled with fewer GPUs."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, PYTHONPATH=ROOT))
+    assert r.returncode == 2 and "only 1 GPU" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

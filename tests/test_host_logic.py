@@ -274,3 +274,45 @@ def test_patch_meta_packing_matches_the_c_struct():
             m.restrictions[i] = float(rs[b][i])
     want = np.frombuffer(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)), dtype=np.uint8)
     assert got.shape == want.shape and bool((got == want).all())
+
+
+def test_bench_gpus_flag_starts_that_many_ranks_or_refuses():
+    """`bench.py --gpus N`: N > 1 without a rendezvous in the environment -> ONE child
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same argv>` on 127.0.0.1 (spawned, never exec'ed);
+    fewer visible devices than N, or a launcher's WORLD_SIZE that disagrees with --gpus -> refusal (exit code 2), never an
+    `n_gpus: 1` line under a larger request.  --gpus 1 and the driver's own torchrun form run as they always did."""
+    import bench
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert bench.launch_plan(1, {}, ["--gpus", "1"], 0) == ("run", None)
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, argv, 0) == ("run", None)        # the driver's torchrun form
+    act, cmd = bench.launch_plan(8, {}, argv, 8, script="/x/bench.py", port=29999)
+    assert act == "spawn"
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[cmd.index("/x/bench.py") + 1:] == argv                                               # same arguments for every rank
+    act, cmd = bench.launch_plan(2, {}, ["--gpus", "2"], 4)                                         # a free port is picked
+    assert act == "spawn" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    act, msg = bench.launch_plan(8, {}, argv, 1)
+    assert act == "refuse" and "only 1 GPU" in msg
+    act, msg = bench.launch_plan(8, {"WORLD_SIZE": "2"}, argv, 8)
+    assert act == "refuse" and "WORLD_SIZE=2" in msg
+    act, msg = bench.launch_plan(1, {"WORLD_SIZE": "4"}, ["--gpus", "1"], 8)
+    assert act == "refuse"
+    assert bench.launch_plan(0, {}, [], 8)[0] == "refuse"
+    # end to end on this GPU-less container: the refusal is an exit code and a message, and nothing JSON-like on stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "--gpus 2" in r.stderr and "{" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_grid_barrier_cap_is_derived_from_rccl_channels():
+    """the workgroup cap of the grid-barrier launches in a data-parallel run = CUs - RCCL's channels."""
+    from multibox_amd.dist import bn_max_workgroups_for, rccl_cu_reserve
+    assert bn_max_workgroups_for(1, 256, {})[0] == 0
+    assert bn_max_workgroups_for(8, 256, {}) == (192, {"reserve": 64, "source": "RCCL default channel ceiling (64)"})
+    assert bn_max_workgroups_for(8, 256, {"NCCL_MAX_NCHANNELS": "32"})[0] == 224
+    assert rccl_cu_reserve(256, {"NCCL_MAX_NCHANNELS": "junk"})[0] == 64
+    assert rccl_cu_reserve(256, {"NCCL_MAX_NCHANNELS": "512"})[0] == 128         # never more than half the chip

@@ -46,6 +46,7 @@ def main():
     from multibox_amd.engine import Net
     from multibox_amd.trainer import Trainer, decay_steps
     from multibox_amd.synth import synthetic_batch
+    from multibox_amd.dist import bn_max_workgroups_for
     import __graft_entry__ as g
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -74,7 +75,7 @@ def main():
     bbox_priors = PR.load_priors(args.priors)                     # train.py:368-370
     net = Net(batch=cfg.BATCH_SIZE, input_size=cfg.INPUT_SIZE, k=cfg.NUM_BBOXES_PER_CELL, mode="train",
               fine_tune=args.fine_tune, bn_decay=cfg.BATCHNORM_MOVING_AVERAGE_DECAY,
-              bn_max_workgroups=192 if world > 1 else 0)
+              bn_max_workgroups=bn_max_workgroups_for(world, torch.cuda.get_device_properties(local_rank).multi_processor_count)[0])
     tr = Trainer(net, bbox_priors, max_num_bboxes=cfg.MAX_NUM_BBOXES, location_loss_alpha=cfg.LOCATION_LOSS_ALPHA,
                  initial_learning_rate=cfg.INITIAL_LEARNING_RATE,
                  decay_steps_=decay_steps(cfg.NUM_TRAIN_EXAMPLES, cfg.BATCH_SIZE * world, cfg.NUM_EPOCHS_PER_DELAY),
