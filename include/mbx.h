@@ -210,11 +210,15 @@ typedef struct {
      launch -- R rows whatever the tile shape (mbx_conv_stats_rows() = R), few enough for the consumer to reduce them itself
      (mbx_bn_apply_fused_mapped: no finalize launch), many enough that the adders of one address stay few.  The sums are
      added as 64-bit integers in fixed point (units of 2^-20, resolution 1e-6): integer addition is associative, so the table
-     does not depend on the order in which the tiles arrive -- bit-reproducible statistics.  RANGE (round 5): a tile sum that
-     is not finite or not below 2^41 in magnitude POISONS its channel -- the sum-of-squares word is forced to INT64_MIN by a
-     signed atomic min, whatever arrives before or after -- and mbx_bn_apply_fused_mapped reports NaN mean / rstd for a
-     channel whose word is negative: out-of-range activations end in NaN (as the float32 rows' inf - inf would), never in
-     finite garbage.
+     does not depend on the order in which the tiles arrive -- bit-reproducible statistics.  RANGE (round 6): the table is
+     exact while a channel's GRAND TOTAL stays in range: |sum y| and sum y^2 over all N H W pixels below 2^42 = 4.4e12 (2^62
+     in fixed point; e.g. rms |y| < 1.5e4 on a 64 x 17 x 17 map, < 1.8e3 on 64 x 147 x 147).  Every adder (a pixel tile, a
+     workgroup, an image -- the launch knows how many add into one channel) is held to its share 2^42 / adders, so that
+     neither a row nor the consumer's sum over the rows can wrap; an adder whose sums are not finite or not below its share
+     POISONS the channel -- the sum-of-squares word is forced to INT64_MIN by a signed atomic min, and since the legitimate
+     adds are non-negative and total less than 2^62 it stays negative whatever arrives before or after -- and
+     mbx_bn_apply_fused_mapped reports NaN mean / rstd for a channel with a negative word or total: out-of-range activations
+     end in NaN (as the float32 rows' inf - inf would), never in finite garbage.
      stats_ld (0: C_out): channels per row -- sibling convolutions of a batch-norm group add into channel slices of one
      table (stats_partial then points at the member's first channel).                                              */
   int32_t stats_rows_mod, stats_ld;

@@ -1063,7 +1063,7 @@ constexpr int kSplitRows = 16;                        // pixels per workgroup of
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice_stride, int M, int C, int ldp,
                      unsigned short* __restrict__ y, int HW_out, long long y_img_stride, int ldy, float* __restrict__ stats,
-                     int stats_mod, int stats_ld) {
+                     int stats_mod, int stats_ld, float stats_cap) {
   __shared__ float red[kSplitRows][256][2];             // [row][channel][value | value^2] of the STORED values (C <= 256 per pass)
   const int m0 = blockIdx.x * kSplitRows, tid = threadIdx.x;
   for (int cb = 0; cb < C; cb += 256) {
@@ -1112,7 +1112,7 @@ splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slice
         for (int r = 0; r < kSplitRows; ++r) { x1 += red[r][tid][0]; x2 += red[r][tid][1]; }
         if (stats_mod) {                              // (fixed-point integer adds: stats_write, conv_common.h)
           unsigned long long* o = reinterpret_cast<unsigned long long*>(stats) + ((size_t)((int)blockIdx.x % stats_mod) * stats_ld + cb + tid) * 2;
-          stats_add_fixed(o, x1, x2);
+          stats_add_fixed(o, x1, x2, stats_cap);
         } else {
           float* o = stats + ((size_t)blockIdx.x * stats_ld + cb + tid) * 2;
           o[0] = x1;
@@ -1211,6 +1211,7 @@ template <int BM, int BN, int WNW, int WMW, int NSTG = 3>
 int launch_igemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.C_out + BN - 1) / BN;
+  k.stats_cap = stats_cap_for(k.tiles_m);               // one add per pixel tile and channel
   if (k.dry == 2) {
     g_capture.k = k; g_capture.bm = BM; g_capture.bn = BN; g_capture.wnw = WNW; g_capture.wmw = WMW; g_capture.nstg = NSTG;
     g_capture.ev = k.epi == MBX_EPI_STORE_F32 ? 5 : k.epi == MBX_EPI_RESIDUAL ? 4 : k.epi == MBX_EPI_AFFINE ? 3
@@ -1384,6 +1385,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   k.stats = d->stats_partial;
   if (d->stats_rows_mod < 0 || d->stats_rows_mod > 1024 || d->stats_ld < 0 || (d->stats_ld && d->stats_ld < d->C_out)) return MBX_ERR_INVALID_ARG;
   k.stats_mod = d->stats_rows_mod; k.stats_ld = d->stats_ld ? d->stats_ld : d->C_out;
+  k.stats_cap = 0.f;                                   // (set by the launcher that knows its adders per channel: stats_cap_for)
   k.bw_n = 0; k.bw_mod = 1;
   for (int i = 0; i < 4; ++i) { k.bw_cb[i] = 1 << 30; k.bw_ldy[i] = 0; k.bw_sld[i] = 0; k.bw_y[i] = nullptr; k.bw_thr[i] = nullptr; k.bw_stats[i] = nullptr; }
   if (d->bn_bwd_stats) {
@@ -1470,7 +1472,7 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     if (st != MBX_OK || dry) return st;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((k.M + kSplitRows - 1) / kSplitRows), dim3(256), 0, s, reinterpret_cast<const float*>(d->splitk_ws),
                        ksplit, slice, k.M, k.C_out, ldp, reinterpret_cast<unsigned short*>(k.y), k.HW_out,
-                       (long long)k.y_img_stride, k.ldy, k.stats, k.stats_mod, k.stats_ld);
+                       (long long)k.y_img_stride, k.ldy, k.stats, k.stats_mod, k.stats_ld, stats_cap_for((k.M + kSplitRows - 1) / kSplitRows));
     MBX_LAUNCH_CHECK();
     return MBX_OK;
   }

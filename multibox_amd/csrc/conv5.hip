@@ -367,6 +367,7 @@ int launch5(ConvK& k, hipStream_t s) {
   using G = Ig5<MY, NW>;
   k.tiles_m = (k.M + G::BM - 1) / G::BM;
   k.tiles_n = (k.C_out + G::BN - 1) / G::BN;
+  k.stats_cap = stats_cap_for(k.tiles_m);
   const int ntiles = k.tiles_m * k.tiles_n;
   static int ncu = 0;
   if (!ncu) {

@@ -59,6 +59,7 @@ struct ConvK {
   // 16-times larger bf16 tensor (skip is NULL then).  m = raster pixel index (never the parity walk: host check).
   unsigned char* bits; int bits_ld; unsigned bits_bytes;
   float* stats;
+  float stats_cap;                       // fixed-point rows: bound of ONE adder's |sums| (stats_cap_for(adders per channel), below)
   int stats_mod, stats_ld;               // stats_mod = R > 0: tile sums ADDED atomically into row (tile % R) of [R][stats_ld][2] (zero at launch); 0: a plain row per tile
   // EV = 6 (data gradients): BATCH-NORM BACKWARD statistics of the layers whose activation gradient this launch writes.
   // Output channels [bw_cb[i], bw_cb[i + 1]) belong to segment i: y = that layer's pre-BN output [M][bw_ldy] (pointer at the
@@ -127,21 +128,28 @@ __device__ __forceinline__ unsigned fast_div(unsigned m, unsigned magic, unsigne
 }
 // one channel's statistics sums of one tile (or of one workgroup) into the partial table: a plain float32 row per tile, or --
 // stats_mod rows whatever the tile count -- ADDED into row (tile mod stats_mod) of a table that is zero at launch.  The adds
-// are 64-bit INTEGER atomics on the sums in fixed point (2^-20 units: |sum| < 8.8e12, resolution 1e-6 -- the tile sums are
+// are 64-bit INTEGER atomics on the sums in fixed point (2^-20 units: |sum| < 4.4e12 IN TOTAL, resolution 1e-6 -- the tile sums are
 // float32 values of magnitude 1 .. 1e6): integer addition is associative, so the table does not depend on the order in which
 // the tiles arrive and the forward pass stays bit-reproducible (float atomics made it differ from run to run in the last
 // bits of every mean, which a chaotic network amplifies).  Fire and forget, performed at the memory side.
 constexpr float kStatsFix = 1048576.f;                  // 2^20
-// OUT OF RANGE.  The conversion is defined for |x| 2^20 < 2^63 only, and a row that sums a few hundred tiles
-// must stay below that as well: a tile sum that is not finite or not below kStatsMax (2^41: 2^61 in fixed point -- reachable:
-// `--fine_tune` straight after a fresh start feeds activations of ~1e16 into the training-mode head batch norms) POISONS
-// its channel instead of wrapping into finite garbage: the sum-of-squares word, never negative otherwise, is forced to the
-// most negative integer by a signed atomic MIN, which no later add of a legitimate (< 2^61) value can bring back above zero
-// and which wins whatever the order of arrival.  The consumer (bn_apply_rows_kernel) turns a negative word into NaN mean / rstd:
-// the activations, the loss and the matching status go non-finite exactly as with the float32 rows -- loud, not silent.
-constexpr float kStatsMax = 2199023255552.f;            // 2^41
-__device__ __forceinline__ void stats_add_fixed(unsigned long long* o, const float x1, const float x2) {
-  if (__builtin_fabsf(x1) < kStatsMax && __builtin_fabsf(x2) < kStatsMax) {          // (false for NaN / inf as well)
+// OUT OF RANGE (ADVICE rounds 4 and 5).  The conversion is defined for |x| 2^20 < 2^63 only -- and it is the TOTAL that must stay
+// in range, not the tile: a table word takes one add per adder of its row (tile rows / workgroups / images: 9 .. 5 400 of them),
+// and the consumer adds the rows once more in a bare int64.  So every adder's sums are held below
+//   ConvK::stats_cap = kStatsTotal / (adders of ONE channel over ALL rows)      (stats_cap_for(), set by every launcher)
+// which bounds the grand total of a channel by kStatsTotal = 2^42 (2^62 in fixed point: |sum y| and sum y^2 < 4.4e12 -- the
+// documented range of include/mbx.h) whatever the order of arrival, with no wrap anywhere: not in a row, not in the consumer.
+// A sum that is not finite or not below the cap POISONS its channel instead of wrapping into finite garbage: the sum-of-squares
+// word -- otherwise a sum of NON-NEGATIVE adds that stays below 2^62 -- is forced to the most negative integer by a signed
+// atomic MIN; the legitimate adds that arrive before or after it move it by less than 2^62 in all, so the word (and the
+// consumer's sum over the rows) stays NEGATIVE: sticky, and order-independent as a verdict.  The consumer
+// (bn_apply_rows_kernel) turns a negative word or a negative total into NaN mean / rstd: the activations, the loss and the
+// matching status go non-finite exactly as with the float32 rows -- loud, not silent.  (reachable: `--fine_tune` straight
+// after a fresh start feeds activations of ~1e16 into the training-mode head batch norms)
+constexpr float kStatsTotal = 4398046511104.f;          // 2^42
+__host__ __device__ __forceinline__ float stats_cap_for(long long adders) { return kStatsTotal / (float)(adders > 0 ? adders : 1); }
+__device__ __forceinline__ void stats_add_fixed(unsigned long long* o, const float x1, const float x2, const float cap) {
+  if (__builtin_fabsf(x1) < cap && __builtin_fabsf(x2) < cap) {                      // (false for NaN / inf as well)
     atomicAdd(o, (unsigned long long)__float2ll_rn(x1 * kStatsFix));
     atomicAdd(o + 1, (unsigned long long)__float2ll_rn(x2 * kStatsFix));
   } else {
@@ -151,7 +159,7 @@ __device__ __forceinline__ void stats_add_fixed(unsigned long long* o, const flo
 __device__ __forceinline__ void stats_write(const ConvK& p, const int tile_row, const int ch, const float x1, const float x2) {
   if (p.stats_mod) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + ((size_t)(tile_row % p.stats_mod) * p.stats_ld + ch) * 2;
-    stats_add_fixed(o, x1, x2);
+    stats_add_fixed(o, x1, x2, p.stats_cap);
   } else {
     float* o = p.stats + ((size_t)tile_row * p.stats_ld + ch) * 2;
     o[0] = x1;

@@ -870,6 +870,7 @@ int mbx_launch_directw(void* convk, int N, int H_out, hipStream_t s) {
   q.ntiles = N * q.tiles_h;
   q.npix = q.TH * k.W_out;
   const int grid = mbx_directw_grid(N, H_out, k.W_out);
+  k.stats_cap = stats_cap_for(grid);                       // one add per workgroup and channel
   if (k.dry) return MBX_OK;
   const int co = k.C_out <= 32 ? 32 : k.C_out <= 48 ? 48 : 64;
 #define MBX_DW(C8_, CO_) if (k.C_in == 8 * C8_ && co == CO_) return launch_directw<C8_, CO_>(k, q, grid, s);
@@ -897,6 +898,7 @@ int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
     if (nt >= (1L << 30)) return MBX_ERR_UNSUPPORTED;
     q.ntiles = (int)nt;
     if (k.dry) return MBX_OK;
+    k.stats_cap = stats_cap_for(mbx_direct3_grid(N, H_out, k.W_out));
     return launch_stem(k, q, mbx_direct3_grid(N, H_out, k.W_out), s);
   }
   if (k.R != 3 || k.S != 3 || k.mul != 1 || k.shift || (k.epi != MBX_EPI_STORE && k.epi != MBX_EPI_AFFINE) || k.accumulate || k.skip || k.bits ||
@@ -913,6 +915,7 @@ int mbx_launch_direct3(void* convk, int N, int H_out, hipStream_t s) {
   if (nt >= (1L << 30)) return MBX_ERR_UNSUPPORTED;
   q.ntiles = (int)nt;
   const int grid = mbx_direct3_grid(N, H_out, k.W_out);
+  k.stats_cap = stats_cap_for(grid);
   if (k.dry) return MBX_OK;
   const int co = k.C_out <= 32 ? 32 : k.C_out <= 48 ? 48 : 64;
   if (k.C_in == 32) {

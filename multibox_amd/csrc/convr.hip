@@ -802,6 +802,7 @@ int mbx_launch_resident(void* convk, int N, int H_out, hipStream_t s) {
   int NB;
   resident_groups(k.C_out, q.NG, q.CPT, NB);
   q.ntiles = N * q.NG;
+  k.stats_cap = stats_cap_for(N);                          // one add per image and channel
   const int C8 = k.C_in / 8, RS = k.R * k.S;
   if (k.C_in % 32 || q.HW > 289 || q.HW < 64) return MBX_ERR_UNSUPPORTED;
   q.npi = ((q.HW + 1) * C8 + 63) / 64;

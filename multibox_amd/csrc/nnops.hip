@@ -483,7 +483,9 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
     if (var < 0.0) var = 0.0;
     // a negative sum of squares = a tile sum was out of the fixed-point range or not finite (stats_add_fixed, conv_common.h):
     // the channel's statistics are NaN, as the float32 rows would have made them (inf - inf), never finite garbage
-    const bool poisoned = bad;
+    // (the producers bound every channel's grand total by 2^62 in fixed point, so neither a row nor this sum can wrap, and a
+    // poisoned row -- INT64_MIN plus less than 2^62 of legitimate adds -- keeps the total negative: stats_add_fixed)
+    const bool poisoned = bad || i2 < 0;
     if (poisoned) var = (double)__builtin_nanf("");
     const float fm = poisoned ? __builtin_nanf("") : (float)mu, fr = poisoned ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps)), be = beta[ch];
     s_par[ch] = fm; s_par[C + ch] = fr; s_par[2 * C + ch] = be;
