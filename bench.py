@@ -257,11 +257,15 @@ def traced_kernel_times(step_fn, steps=3):
             torch.cuda.synchronize()
         out = {}
         seen = 0
+        allk = [0.0, 0]
         for e in prof.events():
             if e.device_type != torch.autograd.DeviceType.CUDA:
                 continue
             seen += 1
             us = float(getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0))
+            if "Memcpy" not in e.name and "Memset" not in e.name:
+                allk[0] += us
+                allk[1] += 1
             for cls, keys in KERNEL_CLASSES:
                 if any(k in e.name for k in keys):
                     o = out.setdefault(cls, [0.0, 0])
@@ -270,6 +274,7 @@ def traced_kernel_times(step_fn, steps=3):
                     break
         if not seen or "igemm" not in out:
             return None
+        out["_all_kernels"] = allk                       # every kernel of the traced steps (optimiser launches included)
         return {c: (v[0] / steps * 1e-3, v[1] / float(steps)) for c, v in out.items()}
     except Exception:
         return None
@@ -311,6 +316,7 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     """(roofline of the dominant kernel, list of per-class rooflines).  Work (FLOPs / bytes) and launch counts come
     from timed_eager_pass(); times from traced_kernel_times() when the tracer is available (then `ms` is the tracer's and
     `event_ms` the HIP-event figure), else from the HIP events."""
+    classes = {c: o for c, o in classes.items() if not c.startswith("_")}
     for cls, o in classes.items():
         o["event_ms"] = o["ms"]
         o["traced_launches"] = None
@@ -680,6 +686,8 @@ def main():
                "kernels": {"igemm5_launches": sum(1 for _, d_, _ in net.tune_registry if 32 < d_.tile_config < 64),
                            "igemm7_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config == 65),
                            "split_k_launches": sum(1 for _, d_, _ in net.tune_registry if d_.tile_config > 128),
+                           "fused_conv_bn_apply_launches": net.fused_apply_launches,
+                           "fused_dgrad_bn_backward_launches": net.fused_bwd_launches, "bn_layers_without_a_backward_launch": net.fused_bwd_layers,
                            "bn_groups": len(net.bn_groups), "pair_launches": sum(int(g_.pair_fwd) + int(g_.pair_bwd) for g_ in net.bn_groups),
                            "fused_stem_pools": sum(1 for c_ in net.convs if getattr(c_, "fused_pool", None) is not None),
                            "backward_segments": len(tr._segments), "graphs": len(tr.graphs or []),
@@ -727,6 +735,10 @@ def main():
                 raise eager
             classes, pair_ms, plain_ms = eager
             out["roofline"], out["roofline_kernels"] = roofline_objects(classes, pair_ms, plain_ms, out["model_tflops"], traced=traced)
+            if traced is not None and "_all_kernels" in traced:
+                # every kernel of a replayed step + its eager optimiser launches, from the same trace
+                out["kernels_per_step"] = round(traced["_all_kernels"][1], 1)
+                out["kernel_time_ms_per_step"] = round(traced["_all_kernels"][0], 3)
         except Exception as e:      # evidence only; never fail the benchmark line on it
             out["roofline"] = {"error": repr(e)}
     if pg is not None:

@@ -160,6 +160,61 @@ typedef struct {
   float* stats[4]; int32_t stats_ld[4];
 } mbx_bn_bwd_stats;
 
+/* THE BATCH-NORM APPLY OF A TRAINING-MODE CONVOLUTION AS THE TAIL OF ITS OWN LAUNCH (round 6).  slim.conv2d in training mode
+ * (train.py:94-105: convolution, batch statistics, normalise + beta, relu) was two launches: the convolution, adding its
+ * tile sums into the fixed-point statistics rows (stats_rows_mod > 0), and mbx_bn_apply_fused_mapped.  With this table
+ * attached (mbx_conv_desc.bn_apply) the convolution's workgroups, when their last tile is stored, meet at a ONE-SHOT GRID
+ * BARRIER, reduce the rows of every channel themselves and normalise THE TILES THEY WROTE (read back from their own CU's L2):
+ * one launch, the same mean / rstd / relu threshold / moving statistics / activations bit for bit.
+ *   barrier: DEVICE, MBX_GRID_BARRIER_BYTES, 128-byte aligned, ZERO at launch, used by one launch per clearing.
+ *   The launch takes at most one workgroup per CU (max_workgroups caps it further); if its workgroups are NOT co-resident
+ *   (CUs held by another stream's kernels) the barrier times out: those workgroups write NaN activations and add 1 to
+ *   *step_poison (word [0] of the step control block: the optimiser then skips the step on every rank) -- the caller falls
+ *   back to the two-launch form.
+ * Persistent / one-tile-per-workgroup launches only (tile_config 33..39, 97, 98), bf16 STORE with statistics, y rows
+ * contiguous per image (y_img_stride = H_out W_out ldy), not a member of mbx_conv_pair; anything else: MBX_ERR_UNSUPPORTED. */
+#define MBX_GRID_BARRIER_BYTES 6400
+typedef struct {
+  void* barrier;
+  void* a; int32_t ld_a;                /* activation: a[m * ld_a + c], m = img * H_out * W_out + pixel (bf16)      */
+  const float* beta;                    /* [C_out]                                                                   */
+  float* mean; float* rstd;             /* [C_out] out: batch mean, 1 / sqrt(var + eps)                              */
+  float* moving_mean; float* moving_var;/* may be NULL; decay < 0: STORE mode (batch mean / biased variance), else
+                                           moving -= (1 - decay) (moving - batch)                                    */
+  float* relu_thr;                      /* may be NULL: mean - beta / rstd (relu) or -inf                            */
+  int32_t relu; float eps, decay;
+  float* step_poison;                   /* may be NULL                                                               */
+} mbx_bn_apply_desc;
+
+/* THE BATCH-NORM BACKWARD OF THE LAYERS A DATA GRADIENT FEEDS, AS THE TAIL OF THAT DATA-GRADIENT LAUNCH (round 6).  The
+ * convolution whose data gradient WRITES the activation gradient da of batch-norm layers (train.py:94-99 on the way back,
+ * train.py:263) finishes their backward itself: when a workgroup's last tile is stored it sweeps THE TILES IT WROTE (da back
+ * from its own CU's L2, y from memory) for its share of  sum g  and  sum g xhat  (g = da where the activation was positive:
+ * xhat + beta > 0 recomputed from y), adds them into the layers' accumulators (float atomics), meets the other workgroups at
+ * a ONE-SHOT GRID BARRIER, reads the totals and sweeps its tiles again to write
+ *   dy = rstd (g - mean g - xhat mean g xhat),   dbeta += sum g
+ * -- what mbx_bn_bwd_onepass computed in a launch of its own.  Output channels [c_begin[i], c_begin[i+1]) of the launch belong
+ * to entry i (at most 4: the gradient of a concat-buffer slice feeds several layers); y / dy / mean / rstd / beta / dbeta /
+ * acc are that layer's, AT THE ENTRY'S FIRST CHANNEL; acc = [MBX_BN_BWD_SLOTS][2][acc_ld] float32, ZERO at launch; c_begin
+ * ascending from 0 in multiples of 8; relu[i]: the layer has a relu behind its batch norm.  Every channel of da must be
+ * written by this launch alone (plain bf16 STORE, no accumulate / mask / sign bits / statistics, stride 1, rows of da
+ * contiguous per image).  barrier / step_poison / residency / time-out: as mbx_bn_apply_desc.  tile_config 33..39, 97, 98
+ * only; anything else: MBX_ERR_UNSUPPORTED.  Same mathematics as mbx_bn_bwd_onepass; like it, the float atomics make the
+ * last bits depend on the order of arrival.                                                                              */
+#define MBX_BN_BWD_SLOTS 8
+typedef struct {
+  void* barrier;
+  int32_t n;
+  int32_t c_begin[4];
+  const void* y[4]; int32_t ld_y[4];
+  void* dy[4]; int32_t ld_dy[4];
+  const float* mean[4]; const float* rstd[4]; const float* beta[4];
+  float* dbeta[4];
+  float* acc[4]; int32_t acc_ld[4];
+  int32_t relu[4];
+  float* step_poison;
+} mbx_bn_bwd_fused;
+
 typedef struct {
   /* input view */
   const void* x; int64_t x_img_stride; int32_t ldx;
@@ -233,6 +288,8 @@ typedef struct {
      the `skip` form (a NaN in the block output counts as positive here, as not positive there).  Not with the
      stride-2 data gradient, statistics, split-K, the direct launches (96 / 97) or mbx_conv_pair: MBX_ERR_UNSUPPORTED. */
   void* relu_bits; int32_t ld_bits;
+  const mbx_bn_apply_desc* bn_apply;      /* HOST, may be NULL: see above (round 6) */
+  const mbx_bn_bwd_fused* bn_bwd;         /* HOST, may be NULL: see above (round 6) */
 } mbx_conv_desc;
 #define MBX_CONV_TILE_CONFIGS 14
 /* tile_config 33..39: the persistent igemm5 launch (128x64, 128x128, 192x128, 256x128, 256x64, 128x192, 128x256 tiles; 128x192

@@ -1386,6 +1386,62 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
   if (d->stats_rows_mod < 0 || d->stats_rows_mod > 1024 || d->stats_ld < 0 || (d->stats_ld && d->stats_ld < d->C_out)) return MBX_ERR_INVALID_ARG;
   k.stats_mod = d->stats_rows_mod; k.stats_ld = d->stats_ld ? d->stats_ld : d->C_out;
   k.stats_cap = 0.f;                                   // (set by the launcher that knows its adders per channel: stats_cap_for)
+  k.fa = FusedApply{};
+  k.fa.bar = nullptr;
+  k.fb = FusedBwd{};
+  k.fb.bar = nullptr;
+  if (d->bn_bwd) {
+    // the BN backward of the layers this data gradient feeds as the tail of the launch (fused_bn.h)
+    const mbx_bn_bwd_fused* b = d->bn_bwd;
+    if (!b->barrier || (reinterpret_cast<uintptr_t>(b->barrier) & 127) || b->n < 1 || b->n > 4 || b->c_begin[0] != 0) return MBX_ERR_INVALID_ARG;
+    if (d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip || d->relu_bits || d->stats_partial || d->bn_bwd_stats || d->bn_apply ||
+        d->stride != 1 || d->C_out > 2048 || d->y_img_stride != (int64_t)d->H_out * d->W_out * d->ldy)
+      return MBX_ERR_UNSUPPORTED;
+    const int tc = d->tile_config;
+    if (!((tc > kI5Flag && tc <= kI5Flag + 7) || tc == kDirectWCfg || tc == kResidentCfg)) return MBX_ERR_UNSUPPORTED;
+    const long long Mll = (long long)d->N * d->H_out * d->W_out;
+    for (int i = 0; i < 4; ++i) k.fb.cb[i] = 1 << 30;
+    for (int i = 0; i < b->n; ++i) {
+      if (!b->y[i] || !b->dy[i] || !b->mean[i] || !b->rstd[i] || (b->relu[i] && !b->beta[i]) || !b->acc[i] ||
+          (reinterpret_cast<uintptr_t>(b->y[i]) & 15) || (reinterpret_cast<uintptr_t>(b->dy[i]) & 15) || b->ld_y[i] % 8 || b->ld_dy[i] % 8 ||
+          b->c_begin[i] % 8 || b->c_begin[i] >= d->C_out || (i && b->c_begin[i] <= b->c_begin[i - 1]) || b->acc_ld[i] <= 0)
+        return MBX_ERR_INVALID_ARG;
+      if (Mll * b->ld_y[i] >= (1LL << 31) || Mll * b->ld_dy[i] >= (1LL << 31)) return MBX_ERR_UNSUPPORTED;
+      k.fb.cb[i] = b->c_begin[i];
+      k.fb.y[i] = reinterpret_cast<const unsigned short*>(b->y[i]); k.fb.ldy[i] = b->ld_y[i];
+      k.fb.dy[i] = reinterpret_cast<unsigned short*>(b->dy[i]); k.fb.lddy[i] = b->ld_dy[i];
+      k.fb.mean[i] = b->mean[i]; k.fb.rstd[i] = b->rstd[i]; k.fb.beta[i] = b->beta[i]; k.fb.dbeta[i] = b->dbeta[i];
+      k.fb.acc[i] = b->acc[i]; k.fb.acc_ld[i] = b->acc_ld[i]; k.fb.relu[i] = b->relu[i];
+    }
+    static int fault = -1;
+    if (fault < 0) { const char* e = getenv("MBX_DEBUG_BARRIER_FAULT"); fault = (e && e[0] == '3') ? 1 : 0; }   // '3': the fused BACKWARD barriers
+    k.fb.n = b->n;
+    k.fb.bar = reinterpret_cast<unsigned*>(b->barrier);
+    k.fb.spin_limit = fault ? (1u << 10) : (1u << 22); k.fb.fault = fault; k.fb.step_poison = b->step_poison;
+    k.fb.inv_M = (float)(1.0 / (double)Mll);
+  }
+  if (d->bn_apply) {
+    // the layer's BN apply as the tail of this launch (fused_bn.h): fixed-point statistics rows, plain bf16 store, rows of y
+    // contiguous over the images; only the launches whose workgroups are all resident (checked per family below)
+    const mbx_bn_apply_desc* b = d->bn_apply;
+    if (!b->barrier || !b->a || !b->beta || !b->mean || !b->rstd || (reinterpret_cast<uintptr_t>(b->barrier) & 127) ||
+        (reinterpret_cast<uintptr_t>(b->a) & 15) || b->ld_a % 8 || b->ld_a < d->C_out)
+      return MBX_ERR_INVALID_ARG;
+    if (!d->stats_partial || d->stats_rows_mod < 1 || d->stats_rows_mod > 16 || d->epilogue != MBX_EPI_STORE || d->accumulate || d->skip ||
+        d->transposed || d->rscale != 0.f || d->C_out > 2048 || d->y_img_stride != (int64_t)d->H_out * d->W_out * d->ldy ||
+        (long long)d->N * d->H_out * d->W_out * b->ld_a >= (1LL << 31))
+      return MBX_ERR_UNSUPPORTED;
+    const int tc = d->tile_config;
+    if (!((tc > kI5Flag && tc <= kI5Flag + 7) || tc == kDirectWCfg || tc == kResidentCfg)) return MBX_ERR_UNSUPPORTED;
+    static int fault = -1;
+    if (fault < 0) { const char* e = getenv("MBX_DEBUG_BARRIER_FAULT"); fault = (e && e[0] == '2') ? 1 : 0; }   // '2': the FORWARD barriers
+    k.fa.bar = reinterpret_cast<unsigned*>(b->barrier);
+    k.fa.spin_limit = fault ? (1u << 10) : (1u << 22); k.fa.fault = fault; k.fa.step_poison = b->step_poison;
+    k.fa.a = reinterpret_cast<unsigned short*>(b->a); k.fa.ld_a = b->ld_a; k.fa.beta = b->beta;
+    k.fa.mean = b->mean; k.fa.rstd = b->rstd; k.fa.mmean = b->moving_mean; k.fa.mvar = b->moving_var; k.fa.thr = b->relu_thr;
+    k.fa.relu = b->relu; k.fa.eps = b->eps; k.fa.decay = b->decay;
+    k.fa.inv_count = 1.0 / (double)((long long)d->N * d->H_out * d->W_out);
+  }
   k.bw_n = 0; k.bw_mod = 1;
   for (int i = 0; i < 4; ++i) { k.bw_cb[i] = 1 << 30; k.bw_ldy[i] = 0; k.bw_sld[i] = 0; k.bw_y[i] = nullptr; k.bw_thr[i] = nullptr; k.bw_stats[i] = nullptr; }
   if (d->bn_bwd_stats) {

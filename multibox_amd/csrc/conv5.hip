@@ -95,7 +95,10 @@ conv_igemm5_kernel(const ConvK p) {
   // workgroup has its one tile by position and the counter could only say "none left" -- but the first fetch is a RETURNING
   // atomic on one address, 256 workgroups at once (~3 us), and its result used to be awaited in front of the first barrier:
   // 0.11 ms per step (MBX_I5_STATIC A/B, round 4).  Multi-round launches fetch it without waiting (below).
-  const bool queued = p.work_counter != nullptr && nk > NST && ntiles > (int)gridDim.x;        // (uniform)
+  // (a launch with the BN apply as its tail deals statically: every workgroup meets the others at the grid barrier anyway, and
+  // the tail re-derives the workgroup's tiles from its position)
+  const bool fused_tail = ((EV == 1) && p.fa.bar != nullptr) || ((EV == 0) && p.fb.bar != nullptr);         // (uniform)
+  const bool queued = p.work_counter != nullptr && nk > NST && ntiles > (int)gridDim.x && !fused_tail;        // (uniform)
 
   if (wave >= 8) {
     // -------------------------------------------------------------------------------------------- loader waves
@@ -224,9 +227,7 @@ conv_igemm5_kernel(const ConvK p) {
 #undef MBX5_ISSUE_A
 #undef MBX5_ISSUE
 #undef MBX5_SETUP_TILE
-    return;
-  }
-
+  } else {
   // ---------------------------------------------------------------------------------------------- compute waves
   constexpr int WN = G::WN;
   const int wn = wave % WN, wm = wave / WN;
@@ -358,6 +359,31 @@ conv_igemm5_kernel(const ConvK p) {
       // (no second barrier: `red` is rewritten only after the next tile's K loop, nk >= 1 barriers away)
     }
 #undef MBX5_STAMP
+  }
+  }  // compute waves
+  if constexpr (EV == 1) {
+    // ---------------------------------------------------------------------------- the layer's BN apply as the launch's tail
+    // (fused_bn.h): all sixteen waves; the ring is dead -- its first 12 C_out bytes hold the per-channel parameters
+    if (fused_tail) {
+      constexpr int NT = 512 + 64 * NLW;
+      const bool timed_out = fused_grid_meet<NT>(p.fa, reinterpret_cast<int*>(red + G::WM * BN * 2));
+      float* s_par = reinterpret_cast<float*>(smem);
+      fused_stats_to_lds<NT>(p.fa, p.stats, p.stats_mod, p.stats_ld, p.C_out, s_par, timed_out);
+      __syncthreads();
+      for (int t = first; t < ntiles; t += (int)gridDim.x)
+        fused_apply_region<NT>(p.fa, reinterpret_cast<const unsigned short*>(p.y), p.ldy, p.M, p.C_out, s_par,
+                               (t / p.tiles_n) * BM, BM, (t % p.tiles_n) * BN, BN);
+    }
+  }
+  if constexpr (EV == 0) {
+    // -------------------------------- data gradients: the BN backward of the layers whose activation gradient this launch wrote
+    if (fused_tail) {
+      constexpr int NT = 512 + 64 * NLW;
+      static_assert(NT * 64 + sizeof(FbShared) <= G::RING_BYTES, "the tail's reduce area fits the ring");
+      fused_bwd_tail<NT>(p, smem, [&](auto&& fn) {
+        for (int t = first; t < ntiles; t += (int)gridDim.x) fn((t / p.tiles_n) * BM, BM, (t % p.tiles_n) * BN, BN);
+      });
+    }
   }
 }
 

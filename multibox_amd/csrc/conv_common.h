@@ -2,6 +2,7 @@
 // weight gradients + host entry points; conv5.hip: the persistent igemm5 kernel).  gfx950 only.
 #pragma once
 #include "common.h"
+#include "grid_barrier.h"
 
 namespace {
 
@@ -70,6 +71,8 @@ struct ConvK {
   const unsigned short* bw_y[4];
   const float* bw_thr[4];
   float* bw_stats[4];
+  FusedApply fa;                       // fa.bar != NULL: the layer's BN apply runs as the tail of this launch (fused_bn.h)
+  FusedBwd fb;                         // fb.bar != NULL (data gradients): the BN backward of the layers it feeds runs as its tail
   int tiles_m, tiles_n;
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic-number division by HW_out / W_out
   int pw;                              // pointwise: R = S = 1, no padding, unit stride
@@ -559,3 +562,5 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvK& p, const f32x4
 }
 
 }  // namespace
+
+#include "fused_bn.h"

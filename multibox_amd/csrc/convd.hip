@@ -753,13 +753,52 @@ __device__ __forceinline__ void directw_body(const ConvK& p, const DirW& q, cons
       for (int w = 0; w < 8; ++w) { x1 += red[(w * CO + tid) * 2]; x2 += red[(w * CO + tid) * 2 + 1]; }
       stats_write(p, first, tid, x1, x2);
     }
+    // the layer's BN apply as the launch's tail (fused_bn.h): the tiles this workgroup stored, whole rows of the map
+    if (p.fa.bar != nullptr) {
+      const bool timed_out = fused_grid_meet<kDThreads>(p.fa, reinterpret_cast<int*>(red));
+      float* s_par = reinterpret_cast<float*>(smem);
+      fused_stats_to_lds<kDThreads>(p.fa, p.stats, p.stats_mod, p.stats_ld, p.C_out, s_par, timed_out);
+      __syncthreads();
+      const int HW = q.H_out * p.W_out;
+      for (int t = first; t < q.ntiles; t += G) {
+        const int img = t / q.tiles_h, th = t - img * q.tiles_h;
+        const int nr = min(q.TH, q.H_out - th * q.TH);
+        fused_apply_region<kDThreads>(p.fa, reinterpret_cast<const unsigned short*>(p.y), p.ldy, p.M, p.C_out, s_par,
+                                      img * HW + th * q.TH * p.W_out, nr * p.W_out, 0, p.C_out);
+      }
+    }
   }
+}
+
+template <int C8, int CO>
+constexpr int directw_lds_bytes() {
+  constexpr int NG = (9 * C8 + 3) / 4, WROW = 4 * NG + 1;
+  constexpr int PBUF = (kWMaxPix * C8 + kDThreads - 1) / kDThreads * kDThreads;
+  constexpr int WB = (CO * WROW + kDThreads - 1) / kDThreads * kDThreads;
+  return (WB + 2 * PBUF) * 16 + 8 * CO * 2 * 4;
+}
+
+// data gradients: the BN backward of the layers whose activation gradient a whole-width launch wrote, as its tail (fused_bn.h)
+template <int C8, int CO>
+__device__ __forceinline__ void directw_bwd_tail(const ConvK& p, const DirW& q, const int first, const int G) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  static_assert(kDThreads * 64 + sizeof(FbShared) <= directw_lds_bytes<C8, CO>(), "the tail's reduce area fits");
+  const int HW = q.H_out * p.W_out;
+  fused_bwd_tail<kDThreads>(p, smem, [&](auto&& fn) {
+    for (int t = first; t < q.ntiles; t += G) {
+      const int img = t / q.tiles_h, th = t - img * q.tiles_h;
+      fn(img * HW + th * q.TH * p.W_out, min(q.TH, q.H_out - th * q.TH) * p.W_out, 0, p.C_out);
+    }
+  });
 }
 
 template <int C8, int CO, int EV>
 __global__ void __launch_bounds__(kDThreads)
 conv_directw_kernel(const ConvK p, const DirW q) {
   directw_body<C8, CO, EV>(p, q, (int)blockIdx.x, (int)gridDim.x);
+  if constexpr (EV == 0) {
+    if (p.fb.bar != nullptr) directw_bwd_tail<C8, CO>(p, q, (int)blockIdx.x, (int)gridDim.x);
+  }
 }
 
 template <int C8, int CO>
@@ -869,7 +908,8 @@ int mbx_launch_directw(void* convk, int N, int H_out, hipStream_t s) {
   q.tiles_h = (H_out + q.TH - 1) / q.TH;
   q.ntiles = N * q.tiles_h;
   q.npix = q.TH * k.W_out;
-  const int grid = mbx_directw_grid(N, H_out, k.W_out);
+  int grid = mbx_directw_grid(N, H_out, k.W_out);
+  if ((k.fa.bar || k.fb.bar) && k.max_wg > 0 && grid > k.max_wg) grid = k.max_wg;    // (grid-barrier launches honour the caller's CU cap)
   k.stats_cap = stats_cap_for(grid);                       // one add per workgroup and channel
   if (k.dry) return MBX_OK;
   const int co = k.C_out <= 32 ? 32 : k.C_out <= 48 ? 48 : 64;

@@ -126,6 +126,22 @@ class Net:
         # (threshold loads, sums, cross-wave reduce, the atomics' acknowledgement -- all on the tail of a launch that has one
         # tile per CU) and 17 us where the 256 x 128 tile has no room for it: 15.98 -> 16.5 ms per step.
         self.bw_stats = self.atomic_stats and os.environ.get("MBX_BW_STATS", "0") == "1"
+        # ROUND 6: the BN apply of a training-mode convolution as the TAIL of the convolution's own launch (mbx_conv_desc.bn_apply,
+        # csrc/fused_bn.h): workgroups meet at a one-shot grid barrier, reduce the statistics rows themselves and normalise the
+        # tiles they wrote, read back from their own L2 -- no bn_apply_rows launch.  Where the library supports it (persistent
+        # igemm5 tiles, the whole-width direct and the resident-image launch; not batch-norm groups, split-K, the stem's fused
+        # pools).  Bit-identical to the two-launch form, which stays as the call-time fall-back (no_onepass: a grid barrier timed
+        # out) and behind MBX_FUSE_APPLY=0.
+        self.fuse_apply = self.atomic_stats and os.environ.get("MBX_FUSE_APPLY", "1") != "0"
+        self.fused_apply_launches = 0
+        # ... and the BN BACKWARD of a layer as the tail of the data-gradient launch(es) that WRITE its activation gradient
+        # (mbx_conv_desc.bn_bwd): wherever every channel of a batch-norm layer (group) has exactly one consumer and that is a
+        # stride-1 convolution whose data gradient is a persistent / one-tile-per-workgroup launch (_plan_fused_bwd).  The
+        # layer's own backward launch (mbx_bn_bwd_onepass) is then not issued.  Not in deterministic mode (float atomics);
+        # MBX_FUSE_BWD=0: off; the three-launch form stays the call-time fall-back (no_onepass).
+        self.fuse_bwd = (mode == "train" and not self.deterministic and not self.bw_stats and torch.device(device).type == "cuda"
+                         and os.environ.get("MBX_FUSE_BWD", "1") != "0")
+        self.fused_bwd_launches = self.fused_bwd_layers = 0
         # relu backward of the residual block outputs from SIGN BITS (mbx_conv_desc.relu_bits): the residual launch writes one
         # bit per element beside its bf16 output, the data gradient that applies the mask reads that byte per eight channels
         # instead of 16 bytes of the tensor -- its epilogue streams two tensors and a sixteenth instead of three.
@@ -599,12 +615,36 @@ class Net:
                     ws_floats += STATS_ROWS * sum(m.K for m in u) * 2
                 else:
                     op.bw_rows_off = lead.bw_rows_off
+        # fused data-gradient + BN-backward launches: accumulators per batch-norm unit, a grid-barrier control block per launch
+        self._plan_fused_bwd()
+        for op in self.convs:
+            op.fb_acc_off = op.fb_bar_off = -1
+        for op in self.convs:
+            u = op.fb_unit
+            if u is not None and op is u[0]:
+                ws_floats = (ws_floats + 31) // 32 * 32
+                op.fb_acc_off = ws_floats
+                ws_floats += ops.BN_BWD_SLOTS * 2 * sum(m.K for m in u)
+            if op.fb_segments is not None:
+                ws_floats = (ws_floats + 31) // 32 * 32
+                op.fb_bar_off = ws_floats
+                ws_floats += ops.GRID_BARRIER_BYTES // 4
+        ws_floats = (ws_floats + 31) // 32 * 32
         self.bn_ws = torch.zeros(max(ws_floats, 8), dtype=torch.float32, device=dev)
+        assert self.bn_ws.data_ptr() % 128 == 0 or torch.device(dev).type != "cuda"
         # ONE buffer cleared by one fill at the start of forward(): [work counters of the persistent launches | statistics rows]
         n_ctr = self.i5_counters.numel()
-        self._fwd_clear = torch.zeros(n_ctr + max(n_stats16, 4), dtype=torch.int32, device=dev)
+        # (+ the grid-barrier control blocks of the fused convolution + BN-apply launches: one per batch-norm convolution, 6.4 KB each)
+        n_stats16 = (max(n_stats16, 4) + 31) // 32 * 32
+        self._n_fwd_barriers = sum(1 for op in self.convs if op.kind == "bn") if self.fuse_apply else 0
+        self._fwd_barriers_used = 0
+        bar_words = ops.GRID_BARRIER_BYTES // 4
+        self._fwd_clear = torch.zeros(n_ctr + n_stats16 + self._n_fwd_barriers * bar_words + 32, dtype=torch.int32, device=dev)
         self.i5_counters = self._fwd_clear[:n_ctr]
-        self.stats16 = self._fwd_clear[n_ctr:].view(torch.float32)
+        self.stats16 = self._fwd_clear[n_ctr:n_ctr + n_stats16].view(torch.float32)
+        b0 = n_ctr + n_stats16
+        b0 += (-(self._fwd_clear.data_ptr() // 4 + b0)) % 32                      # 128-byte aligned control blocks
+        self._fwd_barrier_base = self._fwd_clear.data_ptr() + 4 * b0
         self.bn_thr = torch.zeros(max(self.nBt, 8), dtype=torch.float32, device=dev)    # relu threshold on y per channel (mbx_bn_apply_fused_mapped)
         self.bn_timeouts_total = torch.zeros((), dtype=torch.int64, device=dev)    # workgroups that gave up on a grid barrier, ever
         self.stats_scratch = torch.zeros(max(max_stats, 2), dtype=torch.float32, device=dev)
@@ -705,6 +745,125 @@ class Net:
         for X in self.fwd:
             if isinstance(X, ConvOp) and id(X) in conv_ok:
                 X.bw_segments = conv_ok[id(X)]
+
+    def _plan_fused_bwd(self):
+        """Which batch-norm layers (groups) have their backward run by the data gradient(s) that write their activation
+        gradient (mbx_conv_desc.bn_bwd), and which data gradients carry that tail.  A consumer convolution X is CONVERTIBLE
+        when it is a trainable stride-1 convolution with a data gradient whose input view is tiled exactly by outputs of
+        eligible batch-norm members (segments at multiples of 8 channels, at most 4), nothing else reads those channels,
+        and its data gradient is not one of the stem's direct launches; a unit is ELIGIBLE when every channel of every
+        member has exactly one consumer and that one is convertible.  Fixed point of the two.  Sets op.fb_unit (tuple of the
+        unit's members) on eligible layers and op.fb_segments on convertible consumers:
+        [(first channel relative to X's input view, member, first channel inside the member's output, channels)]."""
+        for op in self.convs:
+            op.fb_unit, op.fb_segments = None, None
+        if not self.fuse_bwd:
+            return
+        units = []
+        for op in self.convs:
+            if op.kind != "bn" or not op.trainable:
+                continue
+            g = op.group
+            if g is not None and op is not g.members[0]:
+                continue
+            mem = tuple([op] if g is None else g.members)
+            if sum(m.K for m in mem) <= 2048 and all(getattr(m, "fused_pool", None) is None for m in mem):
+                units.append(mem)
+        unit_of = {id(m): u for u in units for m in u}
+        pairs_ok = os.environ.get("MBX_FUSE_BWD_PAIRS", "1") != "0"
+
+        def member_at(buf, c):
+            for u in units:
+                for m in u:
+                    if m.out.buf is buf and m.out.ch_off <= c < m.out.ch_off + m.K:
+                        return m
+            return None
+
+        def readers(buf, lo, hi):
+            r = [o for o in self.fwd if o.x.buf is buf and o.x.ch_off < hi and o.x.ch_off + o.x.C > lo]
+            r += [o for o in self.fwd if isinstance(o, ConvOp) and o.skip is not None and o.skip.buf is buf and
+                  o.skip.ch_off < hi and o.skip.ch_off + o.skip.C > lo]
+            return r
+
+        def segments(X):
+            segs, c, end = [], X.x.ch_off, X.x.ch_off + X.x.C
+            while c < end:
+                m = member_at(X.x.buf, c)
+                if m is None:
+                    return None
+                n = min(end, m.out.ch_off + m.K) - c
+                segs.append((c - X.x.ch_off, m, c - m.out.ch_off, n))
+                c += n
+            if len(segs) > 4 or any(sg[0] % 8 for sg in segs):
+                return None
+            return segs
+
+        eligible = set(id(u) for u in units)
+        conv_ok = {}
+        while True:
+            conv_ok = {}
+            for X in self.fwd:
+                if not isinstance(X, ConvOp) or not X.need_dx or not X.trainable or X.stride != 1:
+                    continue
+                if X.x.img_stride != X.x.H * X.x.W * X.x.ld or X.Cin % 8:
+                    continue
+                if not pairs_ok and X.kind == "bn" and X.group is not None and len(X.group.members) == 2:
+                    continue
+                segs = segments(X)
+                if segs is None or any(id(unit_of[id(sg[1])]) not in eligible for sg in segs):
+                    continue
+                if len(readers(X.x.buf, X.x.ch_off, X.x.ch_off + X.x.C)) != 1:
+                    continue                                   # someone else reads (part of) these channels: accumulated gradient
+                dd = ops.ConvDesc()                               # (the fields ops.direct3_applies looks at, of X's data gradient)
+                dd.R, dd.S, dd.stride, dd.epilogue, dd.C_in, dd.C_out = X.R, X.S, 1, ops.EPI_STORE, X.K, X.Cin
+                dd.N, dd.H_in, dd.W_in, dd.H_out, dd.W_out = X.x.N, X.out.H, X.out.W, X.x.H, X.x.W
+                if ops.direct3_applies(dd):
+                    continue                                   # (the stem: the direct launch has no tail; its layers keep their own backward)
+                conv_ok[id(X)] = segs
+            drop = set()
+            for u in units:
+                if id(u) not in eligible:
+                    continue
+                for m in u:
+                    rd = readers(m.out.buf, m.out.ch_off, m.out.ch_off + m.K)
+                    covered = sorted((max(o.x.ch_off, m.out.ch_off), min(o.x.ch_off + o.x.C, m.out.ch_off + m.K)) for o in rd)
+                    tiled = bool(covered) and covered[0][0] == m.out.ch_off and covered[-1][1] == m.out.ch_off + m.K and \
+                        all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+                    if not tiled or any(id(o) not in conv_ok for o in rd):
+                        drop.add(id(u))
+            if not drop:
+                break
+            eligible -= drop
+        for u in units:
+            if id(u) in eligible:
+                for m in u:
+                    m.fb_unit = u
+        for X in self.fwd:
+            if isinstance(X, ConvOp) and id(X) in conv_ok:
+                X.fb_segments = conv_ok[id(X)]
+
+    def _fb_table(self, X):
+        """mbx_bn_bwd_fused of consumer X's data gradient (kept alive in self._keep_fb)."""
+        t = ops.BnBwdFused()
+        t.barrier = self.bn_ws.data_ptr() + 4 * X.fb_bar_off
+        t.n = len(X.fb_segments)
+        t.step_poison = self.step_ctl.data_ptr()
+        for i, (c_rel, m, c_in, n) in enumerate(X.fb_segments):
+            lead = m.fb_unit[0]
+            K_all = sum(q.K for q in m.fb_unit)
+            ko = m.y_view.ch_off                                         # the member's first channel inside the unit's [M, K_all] tensors
+            assert m.y_view.ld == K_all and m.dy_view.ld == K_all and lead.fb_acc_off >= 0
+            t.c_begin[i] = c_rel
+            t.y[i], t.ld_y[i] = m.y_view.buf.data_ptr() + 2 * (ko + c_in), K_all
+            t.dy[i], t.ld_dy[i] = m.dy_view.buf.data_ptr() + 2 * (ko + c_in), K_all
+            t.mean[i] = self.bn_mean.data_ptr() + 4 * (m.beta_off + c_in)
+            t.rstd[i] = self.bn_rstd.data_ptr() + 4 * (m.beta_off + c_in)
+            t.beta[i] = self.Bt.data_ptr() + 4 * (m.beta_off + c_in)
+            t.dbeta[i] = self.Btg.data_ptr() + 4 * (m.beta_off + c_in)
+            t.acc[i], t.acc_ld[i] = self.bn_ws.data_ptr() + 4 * (lead.fb_acc_off + ko + c_in), K_all
+            t.relu[i] = int(m.relu)
+        self._keep_fb = getattr(self, "_keep_fb", []) + [t]
+        return t
 
     def _bw_table(self, X):
         """mbx_bn_bwd_stats of consumer X's data gradient (kept alive in self._keep_bw)."""
@@ -886,14 +1045,37 @@ class Net:
 
                 if fpool is not None:
                     fpool.fused_fwd = True
+                # the layer's BN apply as the tail of the convolution launch (mbx_conv_desc.bn_apply), where the library has it
+                fd = ba = None
+                if use16 and self.fuse_apply and not S_ and torch.device(self.dev).type == "cuda" and out.img_stride == out.H * out.W * out.ld:
+                    ba = ops.BnApplyDesc()
+                    ba.barrier = self._fwd_barrier_base + ops.GRID_BARRIER_BYTES * self._fwd_barriers_used
+                    ba.a, ba.ld_a, ba.beta, ba.mean, ba.rstd = out.ptr, out.ld, beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+                    ba.relu_thr, ba.relu, ba.eps, ba.step_poison = thr.data_ptr(), int(op.relu), BN_EPS, self.step_ctl.data_ptr()
+                    fd = ops.ConvDesc.from_buffer_copy(d)
+                    fd.bn_apply = C.addressof(ba)
+                    fd.work_counter = None                   # (static deal: fused_bn.h)
+                    if l.mbx_conv_supported(C.byref(fd)) == 0:
+                        assert self._fwd_barriers_used < self._n_fwd_barriers
+                        self._fwd_barriers_used += 1
+                        self.fused_apply_launches += 1
+                        self._keep_ba = getattr(self, "_keep_ba", []) + [ba]
+                    else:
+                        fd = ba = None
 
                 def run(d=d, rows=rows, op=op, mean=mean, rstd=rstd, mm=mm, mv=mv, beta=beta, out=out, var=var, fpool=fpool,
-                        use16=use16, thr=thr, s16=s16):
+                        use16=use16, thr=thr, s16=s16, fd=fd, ba=ba):
                     s = st()
-                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     decay = self.bn_decay
                     if self.defer_moving:                    # store mode: batch variance -> bn_var, moving statistics untouched
                         mm, mv, decay = None, var, -1.0
+                    if fd is not None and not self.no_onepass:
+                        # ONE launch: convolution, grid barrier, statistics, normalise + beta + relu of the tiles each workgroup wrote
+                        ba.moving_mean, ba.moving_var, ba.decay = ops._p(mm), ops._p(mv), decay
+                        fd.max_workgroups = self.cu_cap or self.bn_max_wg
+                        _lib.check(l.mbx_conv(C.byref(fd), s), op.name + " + bn apply")
+                        return
+                    _lib.check(l.mbx_conv(C.byref(d), s), op.name)
                     if use16:
                         _lib.check(l.mbx_bn_apply_fused_mapped(s16.data_ptr(), STATS_ROWS, op.M, BN_EPS, decay, op.y_view.ptr, op.M,
                                                                op.K, beta.data_ptr(), int(op.relu), out.ptr, out.ld, None,
@@ -1170,7 +1352,14 @@ class Net:
                             _lib.check(l.mbx_bn_bwd_apply_mapped(da_ptr, da.ld, None, 0, int(op.relu), y_ptr, M, Kb,
                                                                  mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), self.m12.data_ptr(),
                                                                  dy_ptr, dmap, s), "bn_bwd_apply")
-            ddesc = None
+            if op.kind == "bn" and op.fb_unit is not None and pre is not None:
+                # this layer's backward runs as the tail of the data gradient(s) that wrote its activation gradient (their
+                # launches came earlier in this pass): nothing to launch here -- unless the trainer fell back (call time)
+                def pre(s, split=pre):
+                    if self.no_onepass:
+                        split(s)
+                self.fused_bwd_layers += 1
+            ddesc = fdesc = None
             if op.need_dx:
                 gx = self._gview(op.x)
                 acc, acc_src = self._claim(gx)
@@ -1191,6 +1380,17 @@ class Net:
                     if torch.device(self.dev).type != "cuda" or l.mbx_conv_supported(C.byref(alt)) == 0:
                         ddesc, mr.relu_bits = alt, bits
                 self._tune(op, ddesc, "dgrad")
+                if op.fb_segments is not None:
+                    # this data gradient writes the activation gradient of batch-norm layers whose backward it runs as its tail
+                    assert acc == 0 and acc_src is None and mr is None, op.name
+                    fdesc = ops.ConvDesc.from_buffer_copy(ddesc)
+                    fdesc.bn_bwd = C.addressof(self._fb_table(op))
+                    fdesc.work_counter = None
+                    if not (ops.I5_FLAG < fdesc.tile_config <= ops.I5_FLAG + 7 or fdesc.tile_config in (ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG)):
+                        # the measured table chose a non-persistent tile: a grid-barrier launch needs every workgroup resident
+                        fdesc.tile_config = ops.i5_tile_for(op.x.M, op.Cin, self.n_cus)
+                    _lib.check(l.mbx_conv_supported(C.byref(fdesc)), "data gradient + BN backward " + op.name)
+                    self.fused_bwd_launches += 1
                 if op.bw_segments is not None:
                     # this data gradient writes the activation gradient of batch-norm layers on the streaming backward: its
                     # epilogue adds their sums (a plain store by construction: _plan_bw_stats)
@@ -1219,10 +1419,16 @@ class Net:
             if grp is not None and ddesc is not None:
                 grp.dgrad_desc[grp.members.index(op)] = ddesc
 
-            def run(op=op, pre=pre, ddesc=ddesc, grp=grp):
+            op.fdesc = fdesc
+
+            def run(op=op, pre=pre, ddesc=ddesc, grp=grp, fdesc=fdesc):
                 s = st()
                 if pre is not None and not (op.kind == "bn" and self._probe_skip_bn_bwd):
                     pre(s)
+                if fdesc is not None and not self.no_onepass:
+                    fdesc.max_workgroups = self.cu_cap or self.bn_max_wg
+                    _lib.check(l.mbx_conv(C.byref(fdesc), s), "dgrad + bn backward " + op.name)
+                    return
                 if ddesc is not None:
                     if grp is not None and grp.pair_bwd:
                         # both members' data gradients in ONE launch, issued with the last member (first in backward order)
@@ -1236,7 +1442,7 @@ class Net:
             self.bwd_jobs.append(job)
         if torch.device(self.dev).type == "cuda" and os.environ.get("MBX_CONV_PAIR", "1") != "0":
             for grp in self.bn_groups:
-                if len(grp.members) == 2 and len(grp.dgrad_desc) == 2:
+                if len(grp.members) == 2 and len(grp.dgrad_desc) == 2 and not any(getattr(m, "fdesc", None) is not None for m in grp.members):
                     grp.pair_bwd = l.mbx_conv_pair(C.byref(grp.dgrad_desc[1]), C.byref(grp.dgrad_desc[0]), st()) == 0
         assert not self.pending_acc, "a residual block's input gradient was never written"
         self.bwd_launches = L

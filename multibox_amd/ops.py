@@ -36,7 +36,40 @@ class ConvDesc(C.Structure):
         ("stats_rows_mod", C.c_int32), ("stats_ld", C.c_int32),
         ("bn_bwd_stats", C.c_void_p),
         ("relu_bits", C.c_void_p), ("ld_bits", C.c_int32),
+        ("bn_apply", C.c_void_p),
+        ("bn_bwd", C.c_void_p),
     ]
+
+
+class BnApplyDesc(C.Structure):
+    """mbx_bn_apply_desc (include/mbx.h)."""
+    _fields_ = [("barrier", C.c_void_p), ("a", C.c_void_p), ("ld_a", C.c_int32), ("beta", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("relu_thr", C.c_void_p),
+                ("relu", C.c_int32), ("eps", C.c_float), ("decay", C.c_float), ("step_poison", C.c_void_p)]
+
+
+class BnBwdFused(C.Structure):
+    """mbx_bn_bwd_fused (include/mbx.h)."""
+    _fields_ = [("barrier", C.c_void_p), ("n", C.c_int32), ("c_begin", C.c_int32 * 4), ("y", C.c_void_p * 4), ("ld_y", C.c_int32 * 4),
+                ("dy", C.c_void_p * 4), ("ld_dy", C.c_int32 * 4), ("mean", C.c_void_p * 4), ("rstd", C.c_void_p * 4),
+                ("beta", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("acc", C.c_void_p * 4), ("acc_ld", C.c_int32 * 4),
+                ("relu", C.c_int32 * 4), ("step_poison", C.c_void_p)]
+
+
+GRID_BARRIER_BYTES = 6400                      # MBX_GRID_BARRIER_BYTES
+BN_BWD_SLOTS = 8                               # MBX_BN_BWD_SLOTS
+
+
+def i5_tile_for(M, C_out, n_cus=256):
+    """An igemm5 tile (tile_config) for a launch that must be PERSISTENT (a grid-barrier tail) where the measured table chose a
+    non-persistent tile: the tile with the most workgroups that still fit one round, else the least work per CU."""
+    best, best_key = None, None
+    for i, (bm, bn) in enumerate(I5_TILES):
+        t = -(-M // bm) * -(-C_out // bn)
+        key = (0, -t) if t <= n_cus else (1, -(-t // n_cus) * bm * bn)
+        if best_key is None or key < best_key:
+            best, best_key = I5_FLAG + 1 + i, key
+    return best
 
 
 class WgradJob(C.Structure):
@@ -156,6 +189,7 @@ def wgrad_overlap_cus():
 N_TILE_CONFIGS = 14
 I5_FLAG = 32                                   # tile_config 32 + t: persistent igemm5 launch (csrc/conv5.hip), tile t
 I5_TILE_CONFIGS = (33, 34, 35, 36, 37, 38, 39)     # 128x64, 128x128, 192x128, 256x128, 256x64, 128x192, 128x256
+I5_TILES = ((128, 64), (128, 128), (192, 128), (256, 128), (256, 64), (128, 192), (128, 256))
 I7_TILE_CONFIG = 65                            # persistent pointwise launch with the filter panel resident in LDS (csrc/conv7.hip)
 I7_COUNTERS = 32                               # its work counters: one int per 128-channel column tile
 SPLITK_FLAG = 128                              # tile_config 128 + S: split-K in S slices (float32 partials + reduce launch)

@@ -337,13 +337,15 @@ class Trainer:
             zs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(zs):
                 net.zero_grads()
+        if zs is None:
+            # FIRST (round 6): the fused convolution + BN-apply launches of the forward pass may raise the step control word
+            # (grid-barrier time-out), which this launch clears -- the step then is skipped like one whose backward barrier timed out
+            net.zero_grads()
         net.set_input(self.images)
         net.forward()
         self.loss.forward_backward(net.locs, net.logits, self.gt, self.n_gt)
         if zs is not None:
             torch.cuda.current_stream().wait_stream(zs)
-        else:
-            net.zero_grads()
 
     def _capture(self):
         """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture.  The warm-up pass is not a training

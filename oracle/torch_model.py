@@ -153,7 +153,10 @@ class Model:
             net = net + (self.force[s + "Conv2d_1x1"] - net).detach()
         return _tag(net, [s + "Conv2d_1x1"])
 
-    # The backbone in four stages (each also callable on its own for stage-wise gradient tests).
+    # The backbone as a chain of SEGMENTS (stem, Mixed_5b, each block35, Mixed_6a, each block17, Mixed_7a, each block8,
+    # Block8, Conv2d_7b_1x1): backbone() composes them; tests/test_gpu_model.py runs them one at a time, back to front, for
+    # the teacher-forced gradient check at BATCH_SIZE 64 (every segment boundary is a teacher-forcing point, so the chain
+    # rule may be cut there: one segment's autograd graph in memory instead of the whole network's).
     def stem(self, x):
         """model.py:92-117: images [B,3,S,S] -> MaxPool_5a_3x3."""
         c, P = self.conv, "InceptionResnetV2/"
@@ -165,56 +168,75 @@ class Model:
         net = c(net, P + "Conv2d_4a_3x3", 3, 1, "VALID")
         return self.max_pool(net, P + "MaxPool_5a_3x3")
 
-    def stage35(self, net):
-        """model.py:120-142: Mixed_5b + block35 x repeats[0]."""
-        c, P = self.conv, "InceptionResnetV2/"
-        Q = P + "Mixed_5b/"
+    def mixed_5b(self, net):
+        """model.py:120-141."""
+        c, Q = self.conv, "InceptionResnetV2/Mixed_5b/"
         b0 = c(net, Q + "Branch_0/Conv2d_1x1", 1)
         b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_5x5", 5)
         b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_0c_3x3", 3)
         b3 = c(self.avg_pool(net, Q + "Branch_3/AvgPool_0a_3x3", 3, "SAME"), Q + "Branch_3/Conv2d_0b_1x1", 1)
-        net = self.cat([b0, b1, b2, b3])
-        self.endpoints["Mixed_5b"] = net
+        return self.cat([b0, b1, b2, b3])
+
+    def mixed_6a(self, net):
+        """model.py:145-161."""
+        c, Q = self.conv, "InceptionResnetV2/Mixed_6a/"
+        b0 = c(net, Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
+        b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
+        return self.cat([b0, b1, self.max_pool(net, Q + "Branch_2/MaxPool_1a_3x3")])
+
+    def mixed_7a(self, net):
+        """model.py:164-185."""
+        c, Q = self.conv, "InceptionResnetV2/Mixed_7a/"
+        b0 = c(c(net, Q + "Branch_0/Conv2d_0a_1x1", 1), Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
+        b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
+        b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_1a_3x3", 3, 2, "VALID")
+        return self.cat([b0, b1, b2, self.max_pool(net, Q + "Branch_3/MaxPool_1a_3x3")])
+
+    def segments(self):
+        """[(endpoint name or None, callable)] whose composition is backbone() (model.py:67-196)."""
+        P = "InceptionResnetV2/"
+        segs = [("MaxPool_5a_3x3", self.stem), ("Mixed_5b", self.mixed_5b)]
         for i in range(1, self.repeats[0] + 1):
-            net = self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)
+            segs.append(("block35_10" if i == self.repeats[0] else None,
+                         lambda net, i=i: self.block(net, P + "Repeat/block35_%d/" % i, 0.17, True, 35)))
+        segs.append(("Mixed_6a", self.mixed_6a))
+        for i in range(1, self.repeats[1] + 1):
+            segs.append(("block17_20" if i == self.repeats[1] else None,
+                         lambda net, i=i: self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)))
+        segs.append(("Mixed_7a", self.mixed_7a))
+        for i in range(1, self.repeats[2] + 1):
+            segs.append((None, lambda net, i=i: self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)))
+        segs.append((None, lambda net: self.block(net, P + "Block8/", 1.0, False, 8)))          # model.py:188
+        segs.append(("Conv2d_7b_1x1", lambda net: self.conv(net, P + "Conv2d_7b_1x1", 1)))
+        return segs
+
+    def stage35(self, net):
+        """model.py:120-142: Mixed_5b + block35 x repeats[0]."""
+        for _, f in self.segments()[1:2 + self.repeats[0]]:
+            net = f(net)
         return net
 
     def stage17(self, net):
         """model.py:145-162: Mixed_6a + block17 x repeats[1]."""
-        c, P = self.conv, "InceptionResnetV2/"
-        Q = P + "Mixed_6a/"
-        b0 = c(net, Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
-        b1 = c(c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_0b_3x3", 3), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
-        net = self.cat([b0, b1, self.max_pool(net, Q + "Branch_2/MaxPool_1a_3x3")])
-        self.endpoints["Mixed_6a"] = net
-        for i in range(1, self.repeats[1] + 1):
-            net = self.block(net, P + "Repeat_1/block17_%d/" % i, 0.10, True, 17)
+        a = 2 + self.repeats[0]
+        for _, f in self.segments()[a:a + 1 + self.repeats[1]]:
+            net = f(net)
         return net
 
     def stage8(self, net):
         """model.py:164-192: Mixed_7a + block8 x repeats[2] + Block8 (no relu, scale 1) + Conv2d_7b_1x1."""
-        c, P = self.conv, "InceptionResnetV2/"
-        Q = P + "Mixed_7a/"
-        b0 = c(c(net, Q + "Branch_0/Conv2d_0a_1x1", 1), Q + "Branch_0/Conv2d_1a_3x3", 3, 2, "VALID")
-        b1 = c(c(net, Q + "Branch_1/Conv2d_0a_1x1", 1), Q + "Branch_1/Conv2d_1a_3x3", 3, 2, "VALID")
-        b2 = c(c(c(net, Q + "Branch_2/Conv2d_0a_1x1", 1), Q + "Branch_2/Conv2d_0b_3x3", 3), Q + "Branch_2/Conv2d_1a_3x3", 3, 2, "VALID")
-        net = self.cat([b0, b1, b2, self.max_pool(net, Q + "Branch_3/MaxPool_1a_3x3")])
-        self.endpoints["Mixed_7a"] = net
-        for i in range(1, self.repeats[2] + 1):
-            net = self.block(net, P + "Repeat_2/block8_%d/" % i, 0.20, True, 8)
-        net = self.block(net, P + "Block8/", 1.0, False, 8)          # model.py:188
-        return c(net, P + "Conv2d_7b_1x1", 1)
+        a = 3 + self.repeats[0] + self.repeats[1]
+        for _, f in self.segments()[a:]:
+            net = f(net)
+        return net
 
     def backbone(self, x):
         """model.py:67-196.  x [B,3,S,S]."""
-        net = self.stem(x)
-        self.endpoints["MaxPool_5a_3x3"] = net
-        net = self.stage35(net)
-        self.endpoints["block35_10"] = net
-        net = self.stage17(net)
-        self.endpoints["block17_20"] = net
-        net = self.stage8(net)
-        self.endpoints["Conv2d_7b_1x1"] = net
+        net = x
+        for name, f in self.segments():
+            net = f(net)
+            if name is not None:
+                self.endpoints[name] = net
         return net
 
     def heads(self, feat):

@@ -1329,3 +1329,189 @@ def test_wgrad_grouped_matches_reference_and_single_layer_api(T, deterministic):
             assert torch.equal(dw, dw0), "capped launch differs: " + name
             assert db is None or torch.equal(db, db0)
         assert grp.completed_ok()
+
+
+FUSED_APPLY_CASES = [
+    # (geometry, tile_config, max_workgroups): igemm5 tiles on block35 / block17 / block8 / Mixed shapes; ragged M and C_out; several
+    # tiles per workgroup (capped grids: the tail walks every tile the workgroup stored); the output a channel slice of a wider buffer
+    (("f17", 64, 17, 17, 1088, 320, 1, 1, 1, (0, 0, 0, 0)), 36, 0),
+    (("f17cap", 64, 17, 17, 1088, 320, 1, 1, 1, (0, 0, 0, 0)), 36, 48),
+    (("f35", 64, 35, 35, 320, 96, 1, 1, 1, (0, 0, 0, 0)), 35, 0),
+    (("f8", 64, 8, 8, 2080, 384, 1, 1, 1, (0, 0, 0, 0)), 34, 0),
+    (("f3x3", 5, 35, 35, 256, 256, 3, 3, 1, (1, 1, 1, 1)), 36, 0),
+    (("fragged", 3, 17, 17, 256, 200, 3, 3, 1, (1, 1, 1, 1)), 33, 7),
+    (("f7b", 8, 8, 8, 2080, 1536, 1, 1, 1, (0, 0, 0, 0)), 34, 0),
+    (("fw", 64, 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1)), 97, 0),
+    (("fw2", 7, 35, 35, 32, 48, 3, 3, 1, (1, 1, 1, 1)), 97, 0),
+    (("fr17a", 64, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), 98, 0),
+    (("fr17b", 64, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)), 98, 0),
+    (("fr17cap", 40, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)), 98, 50),
+    (("fr8", 64, 8, 8, 192, 224, 1, 3, 1, (0, 1, 0, 1)), 98, 0),
+    (("fr8b", 64, 8, 8, 224, 256, 3, 1, 1, (1, 0, 1, 0)), 98, 0),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_APPLY_CASES, ids=[c[0][0] for c in FUSED_APPLY_CASES])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv_fused_bn_apply_bit_identical(T, case, relu):
+    """Round 6: mbx_conv_desc.bn_apply -- the layer's BN apply as the TAIL of the convolution launch behind a
+    one-shot grid barrier (csrc/fused_bn.h) -- against the two launches it replaces (the same convolution, then
+    mbx_bn_apply_fused_mapped on the rows it added): y, the activation, mean, rstd, the relu threshold and the stored batch
+    variance are the SAME BITS; the moving-average form (decay >= 0) too; slices of wider buffers untouched outside; the barrier
+    did not time out (flag word 1 of the control block stays 0, the step control word stays 0)."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    g, cfg, cap = case
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    M = N * Ho * Wo
+    stream = torch.cuda.current_stream().cuda_stream
+    x, w = make_case(torch, g, seed=7)
+    wd = w.to(torch.bfloat16).cuda().contiguous()
+    gen = torch.Generator().manual_seed(9)
+    beta = (torch.randn(Co, generator=gen) * 0.3).cuda()
+    xb = ops.View.alloc(N, H, W, Ci)
+    xb.tensor().copy_(x.to(torch.bfloat16))
+    res = []
+    for fused in (False, True):
+        for decay in (-1.0, 0.9):
+            yb = ops.View.alloc(N, Ho, Wo, Co, zero=True)
+            a = ops.View.alloc(N, Ho, Wo, Co + 24, zero=True).slice(16, Co)
+            table = torch.zeros((8, Co, 2), dtype=torch.int64, device="cuda")
+            mean, rstd, thr = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+            mm, mv = torch.full((Co,), 0.25, device="cuda"), torch.full((Co,), 1.5, device="cuda")
+            bar = torch.zeros(ops.GRID_BARRIER_BYTES // 4 + 32, dtype=torch.int32, device="cuda")
+            boff = (-(bar.data_ptr() // 4)) % 32
+            ctl = torch.zeros(8, device="cuda")
+            d = ops.make_desc(xb, wd, Co, R, S, st, pads[0], pads[1], yb, stats=table, stats_rows_mod=8, stats_ld=Co)
+            d.tile_config, d.max_workgroups = cfg, cap
+            if fused:
+                ba = ops.BnApplyDesc()
+                ba.barrier = bar.data_ptr() + 4 * boff
+                ba.a, ba.ld_a, ba.beta, ba.mean, ba.rstd = a.ptr, a.ld, beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+                ba.moving_mean, ba.moving_var, ba.relu_thr = mm.data_ptr(), mv.data_ptr(), thr.data_ptr()
+                ba.relu, ba.eps, ba.decay, ba.step_poison = relu, 0.001, decay, ctl.data_ptr()
+                d.bn_apply = C.addressof(ba)
+                assert l.mbx_conv_supported(C.byref(d)) == 0
+                ops.conv(d)
+                torch.cuda.synchronize()
+                assert int(bar[boff + 1]) == 0 and float(ctl[0]) == 0.0, "grid barrier timed out"
+                assert int(bar[boff]) > 0                                    # (workgroup 0 recorded the grid size: the tail ran)
+            else:
+                assert l.mbx_conv_supported(C.byref(d)) == 0
+                ops.conv(d)
+                assert l.mbx_bn_apply_fused_mapped(table.data_ptr(), 8, M, 0.001, decay, yb.ptr, M, Co, beta.data_ptr(), relu, a.ptr, a.ld,
+                                                   None, mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), thr.data_ptr(),
+                                                   stream) == 0
+                torch.cuda.synchronize()
+            res.append((yb.tensor().clone(), a.buf.clone(), mean, rstd, thr, mm, mv, table.clone()))
+    for i in range(2):
+        s_, f_ = res[i], res[2 + i]
+        for k_, nm in enumerate(("y", "a (whole buffer)", "mean", "rstd", "relu_thr", "moving_mean", "moving_var", "rows")):
+            assert torch.equal(s_[k_].view(torch.int16 if s_[k_].dtype == torch.bfloat16 else s_[k_].dtype),
+                               f_[k_].view(torch.int16 if f_[k_].dtype == torch.bfloat16 else f_[k_].dtype)), (name, nm, i)
+    a_full = res[2][1].reshape(N, Ho, Wo, Co + 24)
+    assert float(a_full[..., :16].abs().max()) == 0 and float(a_full[..., 16 + Co:].abs().max()) == 0
+    assert bool(torch.isfinite(res[2][1].float()).all()) and float(res[2][1].float().abs().max()) > 0
+
+
+FUSED_BWD_CASES = [
+    # (forward geometry of consumer X, tile_config of its data gradient, max_workgroups, channel split of X's INPUT into BN layers)
+    # block17 "up" 384 -> 1088: its data gradient writes da of [b0 192 | 7x1 192] = two batch-norm layers; igemm5 256x128
+    (("b17up", 64, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), 36, 0, (192, 192)),
+    (("b17upcap", 16, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), 34, 20, (192, 192)),           # several tiles per workgroup
+    (("b8up", 64, 8, 8, 448, 2080, 1, 1, 1, (0, 0, 0, 0)), 33, 0, (192, 256)),
+    (("b35up", 16, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)), 35, 0, (32, 32, 64)),
+    (("b17_7x1", 64, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)), 98, 0, (160,)),                    # resident image
+    (("b17_1x7", 40, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), 98, 0, (128,)),
+    (("b8_3x1", 64, 8, 8, 224, 256, 3, 1, 1, (1, 0, 1, 0)), 98, 0, (224,)),
+    (("b35_3x3", 20, 35, 35, 48, 64, 3, 3, 1, (1, 1, 1, 1)), 97, 0, (48,)),                        # whole-width direct
+    (("b35_3x3b", 64, 35, 35, 32, 32, 3, 3, 1, (1, 1, 1, 1)), 97, 0, (32,)),                       # more tiles than workgroups
+    (("m6a", 6, 35, 35, 256, 256, 3, 3, 1, (1, 1, 1, 1)), 34, 0, (256,)),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_BWD_CASES, ids=[c[0][0] for c in FUSED_BWD_CASES])
+def test_conv_fused_bn_backward_matches_separate_launches(T, case):
+    """Round 6: mbx_conv_desc.bn_bwd -- the batch-norm backward of the layers whose activation gradient a
+    data gradient writes, as the TAIL of that data-gradient launch (csrc/fused_bn.h) -- against the launches it replaces: the
+    same data gradient, then mbx_bn_bwd_onepass per layer on the da it wrote.  da is the same bits; dy within one bf16 ulp
+    (the totals are float sums whose grouping differs: |dy - ref| <= 2^-7 |ref| + 2e-3 max|ref| -- the stated tolerance of
+    every bf16 output in this file) and d(beta) to rtol 1e-4; several layers per launch (channel segments of a concat buffer),
+    layers with and without relu, capped grids (several tiles per workgroup), the three kernel families."""
+    torch = T
+    import ctypes as C
+    from multibox_amd import ops, _lib
+    l = _lib.lib()
+    g, cfg, cap, split = case
+    name, N, H, W, Ci, Co, R, S, st, pads = g
+    assert sum(split) == Ci
+    Ho, Wo = out_hw(H, W, R, S, st, pads)
+    M = N * H * W                                       # pixels of X's input = rows of da / y / dy of the layers it feeds
+    stream = torch.cuda.current_stream().cuda_stream
+    x, w = make_case(torch, g, seed=11)
+    gen = torch.Generator().manual_seed(12)
+    dyX = bf16_round(torch, torch.randn(N, Ho, Wo, Co, generator=gen))
+    dyb = ops.View.alloc(N, Ho, Wo, Co)
+    dyb.tensor().copy_(dyX.to(torch.bfloat16))
+    wT = w.flip(1, 2).permute(3, 1, 2, 0).contiguous().to(torch.bfloat16).cuda()       # [Ci][R][S][Co]
+    # the layers X's input is made of: pre-BN outputs y (each layer's own [M, K] tensor), statistics, beta; odd layers without relu
+    layers = []
+    for i, K in enumerate(split):
+        y = (torch.randn(M, K, generator=gen) * 1.5 + 0.3).to(torch.bfloat16).cuda()
+        yf = y.float()
+        mean = yf.mean(0).contiguous()
+        rstd = (1.0 / torch.sqrt(yf.var(0, unbiased=False) + 0.001)).contiguous()
+        beta = (torch.randn(K, generator=gen) * 0.3).cuda()
+        layers.append(dict(K=K, y=y, mean=mean, rstd=rstd, beta=beta, relu=int(i % 2 == 0)))
+
+    def run(fused):
+        da = ops.View.alloc(N, H, W, Ci + 16, zero=True).slice(8, Ci)              # a channel slice of a wider gradient buffer
+        d = ops.make_desc(dyb, wT, Ci, R, S, st, R - 1 - pads[0], S - 1 - pads[1], da, transposed=1, rscale=(0.17 if R * S == 1 else 0.0))
+        d.tile_config, d.max_workgroups = cfg, cap
+        outs = [dict(dy=torch.zeros((M, L["K"]), dtype=torch.bfloat16, device="cuda"), dbeta=torch.zeros(L["K"], device="cuda")) for L in layers]
+        if fused:
+            t = ops.BnBwdFused()
+            bar = torch.zeros(ops.GRID_BARRIER_BYTES // 4 + 32, dtype=torch.int32, device="cuda")
+            boff = (-(bar.data_ptr() // 4)) % 32
+            ctl = torch.zeros(8, device="cuda")
+            accs = [torch.zeros((ops.BN_BWD_SLOTS, 2, L["K"]), device="cuda") for L in layers]
+            t.barrier, t.n, t.step_poison = bar.data_ptr() + 4 * boff, len(layers), ctl.data_ptr()
+            c0 = 0
+            for i, (L, o, a) in enumerate(zip(layers, outs, accs)):
+                t.c_begin[i] = c0
+                t.y[i], t.ld_y[i], t.dy[i], t.ld_dy[i] = L["y"].data_ptr(), L["K"], o["dy"].data_ptr(), L["K"]
+                t.mean[i], t.rstd[i], t.beta[i], t.dbeta[i] = L["mean"].data_ptr(), L["rstd"].data_ptr(), L["beta"].data_ptr(), o["dbeta"].data_ptr()
+                t.acc[i], t.acc_ld[i], t.relu[i] = a.data_ptr(), L["K"], L["relu"]
+                c0 += L["K"]
+            d.bn_bwd = C.addressof(t)
+            assert l.mbx_conv_supported(C.byref(d)) == 0
+            ops.conv(d)
+            torch.cuda.synchronize()
+            assert int(bar[boff + 1]) == 0 and float(ctl[0]) == 0.0 and int(bar[boff]) > 0, "grid barrier timed out / tail did not run"
+        else:
+            assert l.mbx_conv_supported(C.byref(d)) == 0
+            ops.conv(d)
+            c0 = 0
+            for L, o in zip(layers, outs):
+                K = L["K"]
+                assert l.mbx_bn_bwd_onepass_supported(M, K, 0) == 1
+                ws = torch.zeros(l.mbx_bn_bwd_onepass_workspace_bytes(K) // 4, device="cuda")
+                dav = da.slice(c0, K)
+                _lib.check(l.mbx_bn_bwd_onepass(dav.ptr, dav.ld, L["relu"], L["y"].data_ptr(), M, K, L["mean"].data_ptr(), L["rstd"].data_ptr(),
+                                                L["beta"].data_ptr(), o["dbeta"].data_ptr(), o["dy"].data_ptr(), ws.data_ptr(), 0, None, stream),
+                           "bn_bwd_onepass")
+                c0 += K
+            torch.cuda.synchronize()
+        return da.buf.clone(), outs
+    da0, ref = run(False)
+    da1, got = run(True)
+    assert torch.equal(da0.view(torch.int16), da1.view(torch.int16)), "da differs"
+    assert float(da1.float().abs().max()) > 0
+    for i, (r, o) in enumerate(zip(ref, got)):
+        assert bool(torch.isfinite(o["dy"].float()).all())
+        ok, msg = close(torch, o["dy"], r["dy"])
+        assert ok, "layer %d dy: %s" % (i, msg)
+        assert torch.allclose(o["dbeta"], r["dbeta"], rtol=1e-4, atol=1e-4 * float(r["dbeta"].abs().max())), "layer %d dbeta" % i
