@@ -1417,7 +1417,9 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     if (fault < 0) { const char* e = getenv("MBX_DEBUG_BARRIER_FAULT"); fault = (e && e[0] == '3') ? 1 : 0; }   // '3': the fused BACKWARD barriers
     k.fb.n = b->n;
     k.fb.bar = reinterpret_cast<unsigned*>(b->barrier);
-    k.fb.spin_limit = fault ? (1u << 10) : (1u << 22); k.fb.fault = fault; k.fb.step_poison = b->step_poison;
+    static int probe = -1;
+    if (probe < 0) { const char* e = getenv("MBX_FUSED_PROBE"); probe = e ? (atoi(e) & ~1) : 0; }
+    k.fb.spin_limit = fault ? (1u << 10) : (1u << 22); k.fb.fault = fault | probe; k.fb.step_poison = b->step_poison;
     k.fb.inv_M = (float)(1.0 / (double)Mll);
   }
   if (d->bn_apply) {
@@ -1436,7 +1438,9 @@ static int conv_impl(const mbx_conv_desc* d, mbx_stream_t stream, int dry) {
     static int fault = -1;
     if (fault < 0) { const char* e = getenv("MBX_DEBUG_BARRIER_FAULT"); fault = (e && e[0] == '2') ? 1 : 0; }   // '2': the FORWARD barriers
     k.fa.bar = reinterpret_cast<unsigned*>(b->barrier);
-    k.fa.spin_limit = fault ? (1u << 10) : (1u << 22); k.fa.fault = fault; k.fa.step_poison = b->step_poison;
+    static int probe = -1;                                  // MBX_FUSED_PROBE: timing probes of tools/fused_probe.py (WRONG results)
+    if (probe < 0) { const char* e = getenv("MBX_FUSED_PROBE"); probe = e ? (atoi(e) & ~1) : 0; }
+    k.fa.spin_limit = fault ? (1u << 10) : (1u << 22); k.fa.fault = fault | probe; k.fa.step_poison = b->step_poison;
     k.fa.a = reinterpret_cast<unsigned short*>(b->a); k.fa.ld_a = b->ld_a; k.fa.beta = b->beta;
     k.fa.mean = b->mean; k.fa.rstd = b->rstd; k.fa.mmean = b->moving_mean; k.fa.mvar = b->moving_var; k.fa.thr = b->relu_thr;
     k.fa.relu = b->relu; k.fa.eps = b->eps; k.fa.decay = b->decay;

@@ -366,21 +366,18 @@ conv_igemm5_kernel(const ConvK p) {
     // (fused_bn.h): all sixteen waves; the ring is dead -- its first 12 C_out bytes hold the per-channel parameters
     if (fused_tail) {
       constexpr int NT = 512 + 64 * NLW;
-      const bool timed_out = fused_grid_meet<NT>(p.fa, reinterpret_cast<int*>(red + G::WM * BN * 2));
-      float* s_par = reinterpret_cast<float*>(smem);
-      fused_stats_to_lds<NT>(p.fa, p.stats, p.stats_mod, p.stats_ld, p.C_out, s_par, timed_out);
-      __syncthreads();
-      for (int t = first; t < ntiles; t += (int)gridDim.x)
-        fused_apply_region<NT>(p.fa, reinterpret_cast<const unsigned short*>(p.y), p.ldy, p.M, p.C_out, s_par,
-                               (t / p.tiles_n) * BM, BM, (t % p.tiles_n) * BN, BN);
+      fused_apply_tail<NT>(p, smem, [&](auto&& fn) {
+        for (int t = first; t < ntiles; t += (int)gridDim.x) fn((t / p.tiles_n) * BM, BM, (t % p.tiles_n) * BN, BN);
+      });
     }
   }
-  if constexpr (EV == 0) {
+  if constexpr (EV == 0 && !(MY == 2 && NW == 3)) {       // (128 x 192: 96 accumulator registers leave no room for the tail: spills)
     // -------------------------------- data gradients: the BN backward of the layers whose activation gradient this launch wrote
     if (fused_tail) {
       constexpr int NT = 512 + 64 * NLW;
-      static_assert(NT * 64 + sizeof(FbShared) <= G::RING_BYTES, "the tail's reduce area fits the ring");
-      fused_bwd_tail<NT>(p, smem, [&](auto&& fn) {
+      static_assert(NT * 68 + sizeof(FbShared) <= G::RING_BYTES, "the tail's reduce area fits the ring");
+      static_assert(BM * BN <= 8 * kFbChunk * NT, "a lane's share of a tile is one chunk");
+      fused_bwd_tail<NT, true>(p, smem, [&](auto&& fn) {
         for (int t = first; t < ntiles; t += (int)gridDim.x) fn((t / p.tiles_n) * BM, BM, (t % p.tiles_n) * BN, BN);
       });
     }
@@ -410,6 +407,8 @@ int launch5(ConvK& k, hipStream_t s) {
   // affine / residual only)
   constexpr bool kNo2 = NW == 3;
   if ((ev == 6 && kNo6) || ((ev == 2 || ev == 7) && kNo2)) return MBX_ERR_UNSUPPORTED;
+  if (k.fb.bar && (ev != 0 || (MY == 2 && NW == 3))) return MBX_ERR_UNSUPPORTED;     // the BN-backward tail: plain store launches
+  if (k.fa.bar && ev != 1) return MBX_ERR_UNSUPPORTED;
   if (k.dry) return MBX_OK;                                         // mbx_conv_supported(): the checks above, no launch
   static bool attr[8][2] = {};
 #define MBX5_LAUNCH(EV, MODE)                                                                                 \

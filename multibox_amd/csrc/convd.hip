@@ -755,17 +755,13 @@ __device__ __forceinline__ void directw_body(const ConvK& p, const DirW& q, cons
     }
     // the layer's BN apply as the launch's tail (fused_bn.h): the tiles this workgroup stored, whole rows of the map
     if (p.fa.bar != nullptr) {
-      const bool timed_out = fused_grid_meet<kDThreads>(p.fa, reinterpret_cast<int*>(red));
-      float* s_par = reinterpret_cast<float*>(smem);
-      fused_stats_to_lds<kDThreads>(p.fa, p.stats, p.stats_mod, p.stats_ld, p.C_out, s_par, timed_out);
-      __syncthreads();
       const int HW = q.H_out * p.W_out;
-      for (int t = first; t < q.ntiles; t += G) {
-        const int img = t / q.tiles_h, th = t - img * q.tiles_h;
-        const int nr = min(q.TH, q.H_out - th * q.TH);
-        fused_apply_region<kDThreads>(p.fa, reinterpret_cast<const unsigned short*>(p.y), p.ldy, p.M, p.C_out, s_par,
-                                      img * HW + th * q.TH * p.W_out, nr * p.W_out, 0, p.C_out);
-      }
+      fused_apply_tail<kDThreads>(p, smem, [&](auto&& fn) {
+        for (int t = first; t < q.ntiles; t += G) {
+          const int img = t / q.tiles_h, th = t - img * q.tiles_h;
+          fn(img * HW + th * q.TH * p.W_out, min(q.TH, q.H_out - th * q.TH) * p.W_out, 0, p.C_out);
+        }
+      });
     }
   }
 }
@@ -782,9 +778,9 @@ constexpr int directw_lds_bytes() {
 template <int C8, int CO>
 __device__ __forceinline__ void directw_bwd_tail(const ConvK& p, const DirW& q, const int first, const int G) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  static_assert(kDThreads * 64 + sizeof(FbShared) <= directw_lds_bytes<C8, CO>(), "the tail's reduce area fits");
+  static_assert(kDThreads * 68 + sizeof(FbShared) <= directw_lds_bytes<C8, CO>(), "the tail's reduce area fits");
   const int HW = q.H_out * p.W_out;
-  fused_bwd_tail<kDThreads>(p, smem, [&](auto&& fn) {
+  fused_bwd_tail<kDThreads, false>(p, smem, [&](auto&& fn) {
     for (int t = first; t < q.ntiles; t += G) {
       const int img = t / q.tiles_h, th = t - img * q.tiles_h;
       fn(img * HW + th * q.TH * p.W_out, min(q.TH, q.H_out - th * q.TH) * p.W_out, 0, p.C_out);

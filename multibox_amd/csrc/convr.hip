@@ -474,22 +474,20 @@ conv_resident_kernel(const ConvK p, const ResK q) {
   if constexpr (EV == 1) {
     // the layer's BN apply as the launch's tail (fused_bn.h): all eight waves; LDS is dead -- parameters where the ring was
     if (p.fa.bar != nullptr) {
-      const bool timed_out = fused_grid_meet<kRThreads>(p.fa, reinterpret_cast<int*>(red));
-      float* s_par = reinterpret_cast<float*>(ring);
-      fused_stats_to_lds<kRThreads>(p.fa, p.stats, p.stats_mod, p.stats_ld, p.C_out, s_par, timed_out);
-      __syncthreads();
-      for (int t = first * q.per, t1 = min(t + q.per, q.ntiles); t < t1; ++t) {
-        const int im = t / q.NG, g = t - im * q.NG;
-        const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
-        fused_apply_region<kRThreads>(p.fa, reinterpret_cast<const unsigned short*>(p.y), p.ldy, p.M, p.C_out, s_par, im * q.HW, q.HW, cb, ce - cb);
-      }
+      fused_apply_tail<kRThreads>(p, ring, [&](auto&& fn) {
+        for (int t = first * q.per, t1 = min(t + q.per, q.ntiles); t < t1; ++t) {
+          const int im = t / q.NG, g = t - im * q.NG;
+          const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);
+          fn(im * q.HW, q.HW, cb, ce - cb);
+        }
+      });
     }
   }
   if constexpr (EV == 0) {
     // data gradients: the BN backward of the layers whose activation gradient this launch wrote, as its tail (fused_bn.h)
     if (p.fb.bar != nullptr) {
-      static_assert(kRThreads * 64 + sizeof(FbShared) <= (G::depth(HWC) * SLOTP + G::img_ch(HWC)) * 16, "the tail's reduce area fits ring + image");
-      fused_bwd_tail<kRThreads>(p, ring, [&](auto&& fn) {
+      static_assert(kRThreads * 68 + sizeof(FbShared) <= (G::depth(HWC) * SLOTP + G::img_ch(HWC)) * 16, "the tail's reduce area fits ring + image");
+      fused_bwd_tail<kRThreads, false>(p, ring, [&](auto&& fn) {
         for (int t = first * q.per, t1 = min(t + q.per, q.ntiles); t < t1; ++t) {
           const int im = t / q.NG, g = t - im * q.NG;
           const int cb = g * q.CPT, ce = min(cb + q.CPT, p.C_out);

@@ -131,16 +131,21 @@ class Net:
         # tiles they wrote, read back from their own L2 -- no bn_apply_rows launch.  Where the library supports it (persistent
         # igemm5 tiles, the whole-width direct and the resident-image launch; not batch-norm groups, split-K, the stem's fused
         # pools).  Bit-identical to the two-launch form, which stays as the call-time fall-back (no_onepass: a grid barrier timed
-        # out) and behind MBX_FUSE_APPLY=0.
-        self.fuse_apply = self.atomic_stats and os.environ.get("MBX_FUSE_APPLY", "1") != "0"
+        # out).  MEASURED LEVEL, so OFF by default (LAB_NOTES round 6: one box, alternating, 14.70 ms split / 14.78-14.80 fused;
+        # per launch a tail costs 5-8 us against 5-9 us for the apply launch it replaces -- waiting for the atomics'
+        # acknowledgement, the barrier's two memory-side round trips and the statistics read-back add up to what a kernel
+        # boundary in a replayed graph costs).  MBX_FUSE_APPLY=1 selects it: 114 fewer kernels per step.
+        self.fuse_apply = self.atomic_stats and os.environ.get("MBX_FUSE_APPLY", "0") == "1"
         self.fused_apply_launches = 0
         # ... and the BN BACKWARD of a layer as the tail of the data-gradient launch(es) that WRITE its activation gradient
         # (mbx_conv_desc.bn_bwd): wherever every channel of a batch-norm layer (group) has exactly one consumer and that is a
         # stride-1 convolution whose data gradient is a persistent / one-tile-per-workgroup launch (_plan_fused_bwd).  The
         # layer's own backward launch (mbx_bn_bwd_onepass) is then not issued.  Not in deterministic mode (float atomics);
-        # MBX_FUSE_BWD=0: off; the three-launch form stays the call-time fall-back (no_onepass).
+        # The three-launch form stays the call-time fall-back (no_onepass).  MEASURED LEVEL as well (14.70 -> 14.82 ms with both
+        # fusions, 725 -> 514 kernels; a tail on one tile per workgroup costs 9-15 us against the 9-15 us of the launch(es) it
+        # replaces, on several tiles more: _plan_fused_bwd's one-round rule): OFF by default, MBX_FUSE_BWD=1 selects it.
         self.fuse_bwd = (mode == "train" and not self.deterministic and not self.bw_stats and torch.device(device).type == "cuda"
-                         and os.environ.get("MBX_FUSE_BWD", "1") != "0")
+                         and os.environ.get("MBX_FUSE_BWD", "0") == "1")
         self.fused_bwd_launches = self.fused_bwd_layers = 0
         # relu backward of the residual block outputs from SIGN BITS (mbx_conv_desc.relu_bits): the residual launch writes one
         # bit per element beside its bf16 output, the data gradient that applies the mask reads that byte per eight channels
@@ -819,6 +824,10 @@ class Net:
                 dd.N, dd.H_in, dd.W_in, dd.H_out, dd.W_out = X.x.N, X.out.H, X.out.W, X.x.H, X.x.W
                 if ops.direct3_applies(dd):
                     continue                                   # (the stem: the direct launch has no tail; its layers keep their own backward)
+                # a tail walks its workgroup's tiles one after the other: on one tile it costs what the BN-backward launch costs, on
+                # several it costs more (block35 at BATCH_SIZE 64: 5 tails of 15-40 us for 3 launches of 17 us, +0.37 ms per step)
+                if ops.fused_tail_rounds(dd, self.n_cus) > int(os.environ.get("MBX_FUSE_BWD_MAX_ROUNDS", "1")):
+                    continue
                 conv_ok[id(X)] = segs
             drop = set()
             for u in units:
@@ -1388,6 +1397,8 @@ class Net:
                     fdesc.work_counter = None
                     if not (ops.I5_FLAG < fdesc.tile_config <= ops.I5_FLAG + 7 or fdesc.tile_config in (ops.DIRECTW_TILE_CONFIG, ops.RESIDENT_TILE_CONFIG)):
                         # the measured table chose a non-persistent tile: a grid-barrier launch needs every workgroup resident
+                        fdesc.tile_config = ops.i5_tile_for(op.x.M, op.Cin, self.n_cus)
+                    if l.mbx_conv_supported(C.byref(fdesc)) != 0:                      # (e.g. the 128 x 192 tile: no tail)
                         fdesc.tile_config = ops.i5_tile_for(op.x.M, op.Cin, self.n_cus)
                     _lib.check(l.mbx_conv_supported(C.byref(fdesc)), "data gradient + BN backward " + op.name)
                     self.fused_bwd_launches += 1

@@ -62,14 +62,30 @@ BN_BWD_SLOTS = 8                               # MBX_BN_BWD_SLOTS
 
 def i5_tile_for(M, C_out, n_cus=256):
     """An igemm5 tile (tile_config) for a launch that must be PERSISTENT (a grid-barrier tail) where the measured table chose a
-    non-persistent tile: the tile with the most workgroups that still fit one round, else the least work per CU."""
+    non-persistent tile: the tile with the most workgroups that still fit one round, else the fewest rounds (a tail walks a
+    workgroup's tiles one after the other), then the least work per CU."""
     best, best_key = None, None
     for i, (bm, bn) in enumerate(I5_TILES):
+        if (bm, bn) == (128, 192):
+            continue                                # (no grid-barrier tail on that tile: csrc/conv5.hip)
         t = -(-M // bm) * -(-C_out // bn)
-        key = (0, -t) if t <= n_cus else (1, -(-t // n_cus) * bm * bn)
+        key = (0, -t, 0) if t <= n_cus else (1, -(-t // n_cus), -(-t // n_cus) * bm * bn)
         if best_key is None or key < best_key:
             best, best_key = I5_FLAG + 1 + i, key
     return best
+
+
+def fused_tail_rounds(desc, n_cus=256):
+    """Tiles per workgroup of the persistent / one-tile-per-workgroup launch `desc` would be (resident image, whole-width direct,
+    else the igemm5 tile with the fewest rounds): what a grid-barrier tail walks serially.  Measured (LAB_NOTES round 6): a tail
+    on ONE tile costs about what the launch it replaces costs; on several tiles per workgroup it costs more."""
+    M = desc.N * desc.H_out * desc.W_out
+    if resident_applies(desc, min_images=1):
+        return -(-desc.N * 4 // n_cus)
+    if directw_applies(desc):
+        th = max(1, 256 // desc.W_out)
+        return -(-desc.N * -(-desc.H_out // th) // n_cus)
+    return min(-(-(-(-M // bm) * -(-desc.C_out // bn)) // n_cus) for bm, bn in I5_TILES if (bm, bn) != (128, 192))
 
 
 class WgradJob(C.Structure):
