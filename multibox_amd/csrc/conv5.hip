@@ -45,21 +45,17 @@ struct Ig5 {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// NLW: loader waves.  Eight by default (16 waves: 128 registers each).  FOUR for the epilogues that read as much as they
-// write (residual forward, accumulate + mask data gradient) on the large tiles: 12 waves leave each 168 registers, which
-// hold the WHOLE tile's epilogue reads -- issued before the K loop, landing while the tile is multiplied -- where the
-// 16-wave block holds a quarter and reads the rest one pixel block at a time behind the K loop (by the stamps of
-// tools/i5_stamps.py the rows of a 256 x 128 residual tile take 3.7 us that way against 1.1 us for a plain store: 16 KB in
-// flight per CU against the latency of HBM).  Each loader wave then carries two of the eight row octets of a piece.
-template <int MY, int NW, int EV, int MODE, int NLW = 8>
-__global__ void __launch_bounds__(512 + 64 * NLW)
+// (A TWELVE-wave form -- four loader waves carrying two row octets each, 168 registers per wave, the WHOLE tile's epilogue reads in
+// flight across the K loop -- was built in round 5, bit-identical, and measured level: rows 3.7 -> 1.7 us, K loop 5.7 -> 7.2 us;
+// removed in round 6, LAB_NOTES round 5.)
+template <int MY, int NW, int EV, int MODE>
+__global__ void __launch_bounds__(1024)
 conv_igemm5_kernel(const ConvK p) {
   using G = Ig5<MY, NW>;
   constexpr bool PW = MODE == 1;
   constexpr int BM = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, MI = G::MI, NI = G::NI, STAGE = G::STAGE, NST = G::NST;
-  constexpr int LV = 8 / NLW;                                       // row octets ("virtual loaders") per loader wave
+  constexpr int NLW = 8, LV = 1;                                    // loader waves; row octets per loader wave
   constexpr int NL = LV * (MY + NW);                                // LDS-DMA instructions per loader wave and K step
-  static_assert(NLW == 8 || NLW == 4, "loader waves");
   static_assert((NST - 2) * NL < 64, "vmcnt");
   constexpr int NBAR = (EV == 1 || EV == 6) ? 1 : 0;                             // barriers of one tile's epilogue (statistics reduce)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
@@ -276,8 +272,7 @@ conv_igemm5_kernel(const ConvK p) {
     // epilogue it is EV 2 with the bf16-mask path compiled out; plain EV 2 here has the bits path compiled out: these
     // kernels have no registers for both.  The 256x128 / 128x256 residual tiles, which also write the bits: one block.)
     constexpr int EVC = EV == 7 ? 2 : EV, BMODE = EV == 7 ? 2 : EV == 2 ? 0 : 1;
-    constexpr int PRE_RAW = (NLW == 4 && (EV == 4 || EVC == 2)) ? MI                  // (12 waves: the whole tile)
-                            : (EV == 4 && G::BM * G::BN >= 256 * 128) ? 1
+    constexpr int PRE_RAW = (EV == 4 && G::BM * G::BN >= 256 * 128) ? 1
                             : (EV == 4 || EVC == 2 || EV == 6) ? 4 / (NA * (EVC == 2 ? 2 : 1)) : 0;
     constexpr int PREB = PRE_RAW > MI ? MI : PRE_RAW;
     const int cl0 = wn * TN + fch * 8, mlane = m0 + wm * TM + frow, clane = n0 + cl0;
@@ -420,36 +415,6 @@ int launch5(ConvK& k, hipStream_t s) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, MODE>), dim3(grid), dim3(1024), G::LDS_BYTES, s, k);   \
   } while (0)
-  // Twelve-wave form (four loader waves, the whole tile's epilogue reads in flight across the K loop): pointwise launches with a
-  // residual or an accumulate (+ mask) epilogue on the tiles whose 16-wave form holds only part of them
-  constexpr bool kLW4 = (MY == 3 && NW == 2) || (MY == 4 && NW == 2) || (MY == 2 && NW == 4) || (MY == 2 && NW == 2);
-  // OFF by default: measured level (tools/i5_stamps.py, 256 x 128 residual tile of block17: rows 3.7 -> 1.7 us, K loop 5.7 -> 7.2 us;
-  // detect leg and training step unchanged) -- a CU's vector-memory path holds a fixed number of lines in flight, and what the
-  // epilogue's reads gain by starting early the operand feed behind them loses (LAB_NOTES round 5).  MBX_I5_LW4=1 selects it
-  // (read per call: the parity tests switch it).
-  const char* e4 = getenv("MBX_I5_LW4");
-  const int lw4 = (e4 && e4[0] == '1') ? 1 : 0;
-  if constexpr (kLW4) {
-    // (not: the 128 x 128 residual tile, whose reads all fit the 16-wave form; the bf16-mask epilogue on the 64 x 64 wave tiles: 6 spills)
-    if (lw4 && k.pw && (ev == 4 || ev == 7 || (ev == 2 && MY * NW < 8)) && !(ev == 4 && MY == 2 && NW == 2)) {
-      static bool attr4[8] = {};
-#define MBX5_LAUNCH4(EV)                                                                                      \
-  do {                                                                                                        \
-    if (!attr4[EV]) {                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm5_kernel<MY, NW, EV, 1, 4>),          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);                    \
-      attr4[EV] = true;                                                                                       \
-    }                                                                                                         \
-    hipLaunchKernelGGL((conv_igemm5_kernel<MY, NW, EV, 1, 4>), dim3(grid), dim3(768), G::LDS_BYTES, s, k);    \
-  } while (0)
-      if (ev == 4) MBX5_LAUNCH4(4);
-      else if (ev == 7) MBX5_LAUNCH4(7);
-      else if constexpr (MY * NW < 8) MBX5_LAUNCH4(2);
-#undef MBX5_LAUNCH4
-      MBX_LAUNCH_CHECK();
-      return MBX_OK;
-    }
-  }
 #define MBX5_EV(EV) case EV: if (k.pw) MBX5_LAUNCH(EV, 1); else MBX5_LAUNCH(EV, 0); break;
   switch (ev) {
     MBX5_EV(0) MBX5_EV(1) MBX5_EV(3) MBX5_EV(4)

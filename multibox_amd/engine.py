@@ -959,13 +959,9 @@ class Net:
     def _build_forward_launches(self):
         """Pre-bind every forward launch; returns a list of zero-argument callables."""
         L = []
-        self._fwd_launch_ops = []                                # the op behind every entry of L (head lanes, Net.forward)
         l = _lib.lib()
         st = lambda: torch.cuda.current_stream().cuda_stream
         for op in self.fwd:
-            while len(self._fwd_launch_ops) < len(L):
-                self._fwd_launch_ops.append(prev_op)
-            prev_op = op
             if isinstance(op, PoolOp):
                 if not getattr(op, "fused_fwd", False):          # (else: its producer's BN apply writes the pooled tensor)
                     L.append(op.forward)
@@ -1126,38 +1122,7 @@ class Net:
                     # every head's [M_g, head_ld] float32 output -> locations / logits in prior order (model.py:296-319): ONE launch
                     L.append(lambda: _lib.check(l.mbx_head_gather_all(self.head_table, len(self.heads), self.B, self.P,
                                                                       self.locs.data_ptr(), self.logits.data_ptr(), st()), "head_gather_all"))
-        while len(self._fwd_launch_ops) < len(L):
-            self._fwd_launch_ops.append(prev_op)
-        self._plan_head_lanes(L)
         return L
-
-    def _plan_head_lanes(self, L):
-        """The detection heads (model.py:227-319) are six independent chains off the 8 x 8 x 1536 map -- 8x8, 6x6, the stride-2
-        convolution and the 4x4 / 3x3 / 2x2 scales behind it, the pooled 1x1 -- about thirty launches of 5-30 us each, every one
-        alone on the chip when issued on one stream (0.27 ms of the training step at BATCH_SIZE 64).  Their forward launches are
-        dealt to two lanes of about equal length: the stride-2 convolution with the 4x4 / 3x3 / 2x2 scales behind it on the
-        caller's stream, the 8x8, 6x6 and pooled 1x1 scales on Net.side_stream, between a fork behind the last backbone launch
-        and a join in front of the gather launch (inside a graph capture: two parallel branches of the graph).  Every launch
-        keeps its own buffers (statistics rows, split-K workspace, work counters)."""
-        self._head_lanes = None
-        # OFF by default -- measured SLOWER (tools/lanes_ab.sh, same box): training step 14.71-14.80 -> 15.03-15.06 ms, fine-tune leg
-        # 4.53 -> 4.57-4.61, detect leg level.  One fork / join in the captured graph costs more than the ~0.14 ms the second
-        # lane hides: with parallel branches the graph's kernels no longer run back to back on one queue (LAB_NOTES round 5).
-        if torch.device(self.dev).type != "cuda" or os.environ.get("MBX_HEAD_LANES", "0") != "1":
-            return
-        if self.mode == "train" and not self.atomic_stats:
-            return                                               # (the float statistics rows of the plain mode are one shared scratch area)
-        idx = [i for i, op in enumerate(self._fwd_launch_ops) if getattr(op, "scope", getattr(op, "name", "")).startswith("Multibox/")]
-        if not idx or idx != list(range(idx[0], len(L))):
-            return
-        a, b = idx[0], len(L) - 1                                # L[b] = the gather launch: behind the join
-        lanes = [[], []]
-        for i in range(a, b):
-            op = self._fwd_launch_ops[i]
-            nm = getattr(op, "scope", None) or op.name
-            lanes[1 if ("/8x8/" in nm or "/6x6/" in nm or "/1x1/" in nm) else 0].append(L[i])
-        self._head_lanes = (a, b, lanes)
-        self.side_stream = torch.cuda.Stream()                   # (ONE extra stream: a process has four hardware queues by default)
 
     # ------------------------------------------------------------------- backward
     def _gview(self, v: View) -> View:
@@ -1520,23 +1485,7 @@ class Net:
     def forward(self):
         if self._i5_used or self.atomic_stats:
             self._fwd_clear.zero_()                # work counters (forward AND backward launches of this pass) + statistics rows
-        if getattr(self, "_head_lanes", None) is None:
-            for f in self.fwd_launches:
-                f()
-            return self.locs, self.logits
-        a, b, lanes = self._head_lanes
-        L = self.fwd_launches
-        for f in L[:a]:
-            f()
-        main, sd = torch.cuda.current_stream(), self.side_stream
-        sd.wait_stream(main)                                     # fork behind the backbone's last launch
-        with torch.cuda.stream(sd):
-            for f in lanes[1]:
-                f()
-        for f in lanes[0]:
-            f()
-        main.wait_stream(sd)                                     # join
-        for f in L[b:]:
+        for f in self.fwd_launches:
             f()
         return self.locs, self.logits
 

@@ -142,13 +142,34 @@ class _DecodePool:
         # the block lives in /dev/shm: size it from what is free there (the 64 MB default of many containers holds 40 slots,
         # not 160 -- a worker writing past it would die of SIGBUS, not fall back); fewer slots only mean more pictures
         # decoded in this process
+        # ... and every rank of the node (and every pool of a rank) sees the SAME free figure when they start together: the share
+        # is divided by the local world size, and the pages are RESERVED up front (posix_fallocate: tmpfs allocates lazily, so
+        # a block that merely fits at creation can still end in SIGBUS on a worker's first write -- ADVICE round 5); a block
+        # that cannot be reserved is halved until it can
+        import os as _os
+        sharers = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
         try:
             avail = shutil.disk_usage("/dev/shm").free
-            slots = min(int(slots), max(1, int(0.5 * avail) // int(slot_bytes)))
+            slots = min(int(slots), max(1, int(0.5 * avail / sharers) // int(slot_bytes)))
         except OSError:
             pass
-        self.slot_bytes, self.slots, self._closing = int(slot_bytes), int(slots), False
-        self.shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
+        self.slot_bytes, self._closing = int(slot_bytes), False
+        self._returned = set()                                  # slots close() has handed back (a late result() must not return them twice)
+        while True:
+            shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
+            try:
+                _os.posix_fallocate(shm._fd, 0, int(slots) * self.slot_bytes)
+                break
+            except (OSError, AttributeError):
+                shm.close()
+                shm.unlink()
+                if slots <= 1:
+                    shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes)     # (one slot, lazily: the old behaviour)
+                    slots = 1
+                    break
+                slots = max(1, int(slots) // 2)
+        self.slots = int(slots)
+        self.shm = shm
         self.free = queue.SimpleQueue()
         self.out = {}                                           # slot -> its decode future, until result() has taken it
         for i in range(int(slots)):
@@ -181,7 +202,8 @@ class _DecodePool:
         except Exception:                                       # a failed / cancelled decode: the slot comes back, the picture is decoded here
             hw = None
         if hw is None:                                          # larger than a slot
-            self._release(slot)
+            if slot not in self._returned:                      # (close() may have handed it back already)
+                self._release(slot)
             return decode_image_u8(jpeg_bytes)
         arr = np.ndarray((hw[0], hw[1], 3), np.uint8, buffer=self.shm.buf, offset=slot * self.slot_bytes)
         # views of `arr` keep it alive through .base; the bound method keeps THIS object -- and with it the mapping -- alive
@@ -206,6 +228,7 @@ class _DecodePool:
         self._closing = True
         for slot in list(self.out):
             self.out.pop(slot, None)
+            self._returned.add(slot)
             self.free.put(slot)
         if self.free.qsize() >= self.slots:
             self.shm.close()

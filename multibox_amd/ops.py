@@ -272,7 +272,15 @@ def resident_applies(desc: ConvDesc, min_images=32):
     if desc.N < int(os.environ.get("MBX_RESIDENT_MIN_IMAGES", min_images)):
         return False
     if not desc.x or not desc.w or not desc.y:          # (a bare geometry probe, e.g. the engine's planning pass)
-        return desc.C_in in (128, 160, 192, 224, 256) and desc.C_out % 8 == 0
+        # the library's own table (csrc/convr.hip mbx_launch_resident): three taps on an 8 x 8 map with C_in 192 / 224 / 256,
+        # seven taps on 65 .. 289 pixels with C_in 128 / 160 / 192 -- so that a planning pass never answers "resident" for a
+        # shape the launch then refuses (the 14 x 14 block8 maps of the 512 x 512 configuration: ADVICE round 5)
+        hw = desc.H_out * desc.W_out
+        if desc.C_out % 8:
+            return False
+        if desc.R * desc.S == 3:
+            return hw == 64 and desc.C_in in (192, 224, 256)
+        return 65 <= hw <= 289 and desc.C_in in (128, 160, 192)
     keep = desc.tile_config
     desc.tile_config = RESIDENT_TILE_CONFIG
     ok = _lib.lib().mbx_conv_supported(C.byref(desc)) == 0

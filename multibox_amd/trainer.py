@@ -113,10 +113,6 @@ class Trainer:
             if self.overlap_cus and not self.reducer.enabled:
                 n_segments, by_work = int(os.environ.get("MBX_WG_GROUPS", "8")), True
         self._side = None
-        # (the net's side stream where it has one: a process has four hardware queues by default)
-        self._zero_stream = None
-        if torch.device(net.dev).type == "cuda" and os.environ.get("MBX_ZERO_BESIDE", "0") == "1":
-            self._zero_stream = getattr(net, "side_stream", None) or torch.cuda.Stream()
         self.exposed_events = None                     # a list: step() brackets reducer.wait() with an event pair (bench.py)
         self._segments = self._make_segments(n_segments, tail_params=tail, by_work=by_work)
 
@@ -328,24 +324,14 @@ class Trainer:
     # ---------------------------------------------------------------------------- step
     def _front(self):
         net = self.net
-        # the step's clearing launch (gradient buffer, BN-backward accumulators, control block: 0.23 GB, 39 us) touches nothing
-        # the forward pass or the loss reads or writes: it CAN run beside them on its own stream, joined in front of the backward
-        # pass (MBX_ZERO_BESIDE=1) -- measured 0.4 ms SLOWER per step (tools/lanes_ab.sh): a fork / join in the captured graph
-        # costs more than the launch it hides.  Off.
-        zs = self._zero_stream if os.environ.get("MBX_ZERO_BESIDE", "0") == "1" else None
-        if zs is not None:
-            zs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(zs):
-                net.zero_grads()
-        if zs is None:
-            # FIRST (round 6): the fused convolution + BN-apply launches of the forward pass may raise the step control word
-            # (grid-barrier time-out), which this launch clears -- the step then is skipped like one whose backward barrier timed out
-            net.zero_grads()
+        # the step's clearing launch FIRST (round 6): the fused convolution + BN-apply launches of the forward pass may raise the
+        # step control word (grid-barrier time-out), which this launch clears -- the step then is skipped like one whose backward
+        # barrier timed out.  (Beside the forward pass on a stream of its own it measured 0.4 ms SLOWER: a fork / join in the
+        # captured graph costs more than the 39 us it hides -- LAB_NOTES round 5; removed.)
+        net.zero_grads()
         net.set_input(self.images)
         net.forward()
         self.loss.forward_backward(net.locs, net.logits, self.gt, self.n_gt)
-        if zs is not None:
-            torch.cuda.current_stream().wait_stream(zs)
 
     def _capture(self):
         """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture.  The warm-up pass is not a training

@@ -778,16 +778,13 @@ def test_conv_split_k(T, g, S):
                                # such launches now deal their tiles statically even when a counter is given
                                ("e5", 16, 35, 35, 192, 208, 1, 1, 1, (0, 0, 0, 0)), ("e6", 16, 35, 35, 256, 64, 1, 1, 1, (0, 0, 0, 0))],
                          ids=["1x1", "1x7", "3x3", "1x1_many_tiles", "nk3", "nk4"])
-@pytest.mark.parametrize("lw4", ["0", "1"], ids=["16waves", "12waves"])
-def test_igemm5_epilogues_bit_identical(T, g, lw4, monkeypatch):
+def test_igemm5_epilogues_bit_identical(T, g):
     """Every epilogue of the persistent igemm5 launch (statistics, frozen-BN affine, residual, accumulate + ReLU mask,
-    plain scaled store) against the igemm3 launch of the same descriptor: same arithmetic in the same order.
-    (lw4 = MBX_I5_LW4: the opt-in twelve-wave form of the pointwise residual / accumulate tiles.)"""
+    plain scaled store) against the igemm3 launch of the same descriptor: same arithmetic in the same order."""
     torch = T
     import ctypes as C
     from multibox_amd import ops, _lib
     l = _lib.lib()
-    monkeypatch.setenv("MBX_I5_LW4", lw4)
     name, N, H, W, Ci, Co, R, S, st, pads = g
     x, w = make_case(torch, g, seed=21)
     gen = torch.Generator().manual_seed(22)
@@ -865,11 +862,8 @@ def test_igemm5_epilogues_bit_identical(T, g, lw4, monkeypatch):
 @pytest.mark.parametrize("g", [("b1", 3, 17, 17, 384, 1088, 1, 1, 1, (0, 0, 0, 0)), ("b2", 4, 35, 35, 128, 320, 1, 1, 1, (0, 0, 0, 0)),
                                ("b3", 5, 8, 8, 448, 2080, 1, 1, 1, (0, 0, 0, 0)), ("b4", 2, 17, 17, 96, 72, 3, 3, 1, (1, 1, 1, 1))],
                          ids=["block17_up", "block35_up", "block8_up", "3x3_cout72"])
-@pytest.mark.parametrize("lw4", ["0", "1"], ids=["16waves", "12waves"])
-def test_conv_relu_sign_bits(T, g, lw4, monkeypatch):
-    """(lw4: MBX_I5_LW4 -- the twelve-wave form of the persistent residual / accumulate tiles, the whole tile's epilogue reads
-    issued before the K loop; opt-in, same bits.)
-    mbx_conv_desc.relu_bits (round 4).  WRITE: the residual + relu launch stores, beside y, one bit per element = (y > 0),
+def test_conv_relu_sign_bits(T, g):
+    """mbx_conv_desc.relu_bits (round 4).  WRITE: the residual + relu launch stores, beside y, one bit per element = (y > 0),
     eight channels to a byte, 32 channels to a 4-byte store, in a [M, ld_bits] table wider than 4 ceil(C_out / 32) (zeros for
     the channels past C_out, bytes outside untouched) -- y itself is bit-identical to the launch without the table.  READ: the accumulate (+ scale) launch masked by those bits equals,
     bit for bit, the same launch masked by the bf16 tensor (`skip`).  Every tile family: the library's pick and the other
@@ -879,7 +873,6 @@ def test_conv_relu_sign_bits(T, g, lw4, monkeypatch):
     import ctypes as C
     from multibox_amd import ops, _lib
     l = _lib.lib()
-    monkeypatch.setenv("MBX_I5_LW4", lw4)
     name, N, H, W, Ci, Co, R, S, st, pads = g
     x, w = make_case(torch, g, seed=31)
     gen = torch.Generator().manual_seed(32)
