@@ -468,7 +468,7 @@ def detect_leg(args, world, rank, pg):
     return out
 
 
-def config_leg(args, fine_tune, input_size, k, max_num_bboxes, label):
+def config_leg(args, fine_tune, input_size, k, max_num_bboxes, label, env=None):
     """One more single-GPU BASELINE configuration beside the headline, same build, same timing rules (inputs resident,
     barrier-free single rank, --config-steps timed steps after 3 warm-up steps): `--fine_tune` at BATCH_SIZE 64 (BASELINE
     config 1's semantics at the headline's batch: the like-for-like partner of cpu_baseline) or the 512x512 / k=7 /
@@ -481,7 +481,16 @@ def config_leg(args, fine_tune, input_size, k, max_num_bboxes, label):
     from multibox_amd.synth import synthetic_batch, DEFAULT_ASPECT_RATIOS
     B = args.batch
     priors = PR.priors_for_input_size(DEFAULT_ASPECT_RATIOS[k], input_size).astype(np.float32)
-    net = Net(batch=B, input_size=input_size, k=k, mode="train", fine_tune=fine_tune, seed=2)
+    old_env = {k_: os.environ.get(k_) for k_ in (env or {})}
+    os.environ.update(env or {})                   # (engine switches are read when the network is built)
+    try:
+        net = Net(batch=B, input_size=input_size, k=k, mode="train", fine_tune=fine_tune, seed=2)
+    finally:
+        for k_, v_ in old_env.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
     tr = Trainer(net, priors, max_num_bboxes=max_num_bboxes, location_loss_alpha=1000.0, decay_steps_=decay_steps(56945, B, 4),
                  use_graph=not args.no_graph)
     images, gt, n = synthetic_batch(B, input_size, max_num_bboxes, seed=0)
@@ -499,10 +508,14 @@ def config_leg(args, fine_tune, input_size, k, max_num_bboxes, label):
     out = {"workload": label, "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": args.config_steps,
            "batch": B, "predictions": net.P, "algorithmic_tflop_per_step": round(gflop * B * 1e-3, 3),
            "model_tflops": round(gflop * B * 1e-3 / dt, 1), "matching_ok": int(tr.match_status().max()) == 0,
-           "grid_barrier_timeouts": net.barrier_timeouts(), "total_loss_finite": bool(np.isfinite(losses[3]))}
+           "grid_barrier_timeouts": net.barrier_timeouts(), "total_loss_finite": bool(np.isfinite(losses[3])),
+           "fused_conv_bn_apply_launches": net.fused_apply_launches, "fused_dgrad_bn_backward_launches": net.fused_bwd_launches,
+           "bn_layers_without_a_backward_launch": net.fused_bwd_layers}
     if not args.no_roofline:
         try:
             traced = traced_kernel_times(tr.step)
+            if traced is not None and "_all_kernels" in traced:
+                out["kernels_per_step"] = round(traced["_all_kernels"][1], 1)
             classes, pair_ms, plain_ms = timed_eager_pass(tr.run_eager_once, ["mbx_conv"])
             d = classes["igemm"]
             ms = traced["igemm"][0] if traced else d["ms"]
@@ -770,9 +783,15 @@ def main():
                 ("fine_tune", True, 299, 5, 13, "train.py --fine_tune (frozen backbone, heads train: BASELINE config 1's semantics), "
                                                 "299x299, k=5, BATCH_SIZE=%d" % args.batch),
                 ("s512_k7_g100", False, 512, 7, 100, "full train step at BASELINE config 5's geometry on one GPU: 512x512, k=7, "
-                                                     "MAX_NUM_BBOXES=100, BATCH_SIZE=%d" % args.batch)):
+                                                     "MAX_NUM_BBOXES=100, BATCH_SIZE=%d" % args.batch),
+                # the headline configuration once more with round 6's FUSED launches (convolution + BN apply, data gradient + BN
+                # backward behind in-kernel grid barriers: MBX_FUSE_APPLY=1 MBX_FUSE_BWD=1) -- built, bit-identical / parity-tested,
+                # measured level and therefore OFF in `value`: this leg is the A/B on the driver's own box
+                ("fused_launches", False, 299, 5, 13, "the headline step with the fused conv + BN launches ON (MBX_FUSE_APPLY=1 "
+                                                      "MBX_FUSE_BWD=1; off in `value`), BATCH_SIZE=%d" % args.batch)):
             try:
-                cfgs[key] = config_leg(args, ft, S_, k_, G_, label)
+                cfgs[key] = config_leg(args, ft, S_, k_, G_, label,
+                                       env={"MBX_FUSE_APPLY": "1", "MBX_FUSE_BWD": "1"} if key == "fused_launches" else None)
             except Exception as e:
                 cfgs[key] = {"error": repr(e)}
         out["configs"] = cfgs

@@ -458,14 +458,46 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
     const long long lo = (long long)xcd * perx;
     step = (long long)nx * rpi; m = lo + (long long)((int)blockIdx.x >> 3) * rpi + rr; Mend = lo + perx < M ? lo + perx : M;
   }
-  u32x4 first = u32x4{0u, 0u, 0u, 0u};
-  if (active && m < Mend) first = ld8(y + m * C + c);
-  for (int ch = threadIdx.x; ch < C; ch += kT) {
+  // The lane's first kRowsAhead rows of y are loaded BEFORE the prologue (they do not depend on the statistics): their way from
+  // the Infinity Cache overlaps the rows' round trip, and with <= kRowsAhead rows per lane -- every layer of the 17 x 17 and
+  // 8 x 8 stages at BATCH_SIZE 64 -- the sweep behind the prologue is arithmetic and stores (round 6; one row ahead before).
+  constexpr int kRowsAhead = 4;
+  u32x4 pre[kRowsAhead];
+#pragma unroll
+  for (int i = 0; i < kRowsAhead; ++i) {
+    const long long mi = m + i * step;
+    pre[i] = (active && mi < Mend) ? ld8(y + mi * C + c) : u32x4{0u, 0u, 0u, 0u};
+  }
+  // The rows were ADDED at the memory side (atomics): reading them back misses the L2 -- a round trip of ~1 us each.  With the
+  // usual eight rows ALL the loads of a lane's channels (two channels per pass: C <= 512 in one pass) are issued back to back
+  // and waited for once; as a rolled loop of four-row batches per channel a 320-channel layer took four round trips in a row,
+  // half of the launch (round 6).  Any other row count: the batched loop.
+  for (int chb = threadIdx.x; chb < C; chb += 2 * kT) {
+   longlong2 w0[8], w1[8];
+   const bool two = chb + kT < C;
+   const float be0 = beta[chb], be1 = beta[two ? chb + kT : chb];          // (in flight with the rows)
+   if (rows == 8) {
+     const longlong2* a0 = reinterpret_cast<const longlong2*>(part) + chb;
+     const longlong2* a1 = reinterpret_cast<const longlong2*>(part) + (two ? chb + kT : chb);
+#pragma unroll
+     for (int r = 0; r < 8; ++r) { w0[r] = a0[(size_t)r * C]; w1[r] = a1[(size_t)r * C]; }
+   }
+   for (int half = 0; half < (two ? 2 : 1); ++half) {
+    const int ch = chb + half * kT;
     // the rows are 64-bit fixed-point sums (2^-20 units) added by integer atomics: exact integer sum, then one conversion
     const longlong2* src = reinterpret_cast<const longlong2*>(part) + ch;
     long long i1 = 0, i2 = 0;
     bool bad = false;
     int r = 0;
+    if (rows == 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const longlong2 v = half ? w1[q] : w0[q];
+        i1 += v.x; i2 += v.y;
+        bad |= v.y < 0;
+      }
+      r = 8;
+    }
     for (; r + 3 < rows; r += 4) {                        // four rows' loads in flight
       const longlong2 v0 = src[(size_t)(r + 0) * C], v1 = src[(size_t)(r + 1) * C], v2 = src[(size_t)(r + 2) * C], v3 = src[(size_t)(r + 3) * C];
       i1 += (v0.x + v1.x) + (v2.x + v3.x);
@@ -487,7 +519,7 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
     // poisoned row -- INT64_MIN plus less than 2^62 of legitimate adds -- keeps the total negative: stats_add_fixed)
     const bool poisoned = bad || i2 < 0;
     if (poisoned) var = (double)__builtin_nanf("");
-    const float fm = poisoned ? __builtin_nanf("") : (float)mu, fr = poisoned ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps)), be = beta[ch];
+    const float fm = poisoned ? __builtin_nanf("") : (float)mu, fr = poisoned ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps)), be = half ? be1 : be0;
     s_par[ch] = fm; s_par[C + ch] = fr; s_par[2 * C + ch] = be;
     if (blockIdx.x == 0) {
       mean[ch] = fm; rstd[ch] = fr;
@@ -500,6 +532,7 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
         if (mvar) mvar[ch] -= (1.0f - decay) * (mvar[ch] - (float)var);
       }
     }
+   }
   }
   __syncthreads();
   if (!active) return;
@@ -507,18 +540,28 @@ bn_apply_rows_kernel(const float* __restrict__ part, int rows, double inv_count,
   float mu[8], rs[8], be[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mu[j] = s_par[c + j]; rs[j] = s_par[C + c + j]; be[j] = s_par[2 * C + c + j]; }
-  u32x4 cur = first;
-  for (; m < Mend; m += step) {
-    u32x4 nxt = u32x4{0u, 0u, 0u, 0u};
-    if (m + step < Mend) nxt = ld8(y + (m + step) * C + c);   // next row's load in flight behind this row's arithmetic
+  auto finish = [&](const long long mi, const u32x4 v) {
     float f[8];
-    unpack8(cur, f);
+    unpack8(v, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float v = (f[j] - mu[j]) * rs[j] + be[j];
-      f[j] = relu ? relu_f(v) : v;
+      const float t = (f[j] - mu[j]) * rs[j] + be[j];
+      f[j] = relu ? relu_f(t) : t;
     }
-    st8(a + m * ld_a + c, pack8(f));
+    st8(a + mi * ld_a + c, pack8(f));
+  };
+  u32x4 cur = u32x4{0u, 0u, 0u, 0u};
+  const long long mrest = m + kRowsAhead * step;
+  if (mrest < Mend) cur = ld8(y + mrest * C + c);           // (the rest of a long sweep: in flight behind the first rows' arithmetic)
+#pragma unroll
+  for (int i = 0; i < kRowsAhead; ++i) {
+    const long long mi = m + i * step;
+    if (mi < Mend) finish(mi, pre[i]);
+  }
+  for (m = mrest; m < Mend; m += step) {
+    u32x4 nxt = u32x4{0u, 0u, 0u, 0u};
+    if (m + step < Mend) nxt = ld8(y + (m + step) * C + c);   // next row's load in flight behind this row's arithmetic
+    finish(m, cur);
     cur = nxt;
   }
 }
@@ -807,7 +850,11 @@ bn_bwd_onepass_kernel(const unsigned short* __restrict__ da, int ld_da, const un
     const float t1 = (active ? sred[c + j] : 0.f) + poison;
     m1[j] = t1 * inv_M;
     m2[j] = (active ? sred[C + c + j] : 0.f) * inv_M;
-    if (blockIdx.x == 0 && rr == 0 && dbeta) dbeta[c + j] += t1;
+    // d(beta) += sum g, by workgroup 0: a fire-and-forget atomic add (one adder per address: the same float as `+=`).  As
+    // `dbeta[c + j] += t1` it compiled to eight load -> wait -> add -> store round trips IN A ROW on workgroup 0's first lanes --
+    // and a launch ends when its last workgroup does: 4-6 us on the tail of every one of the step's 141 launches (round 6,
+    // seen in the ISA: eight `s_waitcnt vmcnt(0)` behind the barrier).
+    if (blockIdx.x == 0 && rr == 0 && dbeta) atomicAdd(dbeta + c + j, t1);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -1488,19 +1535,40 @@ rmsprop_ema_kernel(float* __restrict__ w, const float* __restrict__ g, float* __
   // Either non-zero: the step is NOT applied -- no update, no EMA, nothing written (uniform branch).
   if (skip_ctl && (skip_ctl[0] != 0.f || skip_ctl[1] != 0.f)) return;
   float sq = 0.f;
-  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
-    float wi = w[i];
+  auto one = [&](float wi, const float gi_, float& msi, float& momi, float& emai) -> float {     // one element; returns the new weight
     sq += wi * wi;
-    if (ema) { const float e = ema[i]; ema[i] = e - (1.0f - ema_decay) * (e - wi); }
+    if (ema) emai = emai - (1.0f - ema_decay) * (emai - wi);
     if (trainable) {
-      const float gi = g[i] + wd * wi;
-      const float m = decay * ms[i] + (1.0f - decay) * gi * gi;
-      ms[i] = m;
+      const float gi = gi_ + wd * wi;
+      const float m = decay * msi + (1.0f - decay) * gi * gi;
+      msi = m;
       float step = lr * gi / sqrtf(m + eps);
-      if (mom) { step = momentum * mom[i] + step; mom[i] = step; }
+      if (mom) { step = momentum * momi + step; momi = step; }
       wi -= step;
-      w[i] = wi;
     }
+    return wi;
+  };
+  // 16-byte accesses where every stream is 16-byte aligned (the flat parameter buffers are; round 6: the 4-byte form streamed
+  // 1.8 GB per step at 5.5 TB/s), element by element otherwise
+  const bool vec = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ms) |
+                     reinterpret_cast<uintptr_t>(mom) | reinterpret_cast<uintptr_t>(ema)) & 15) == 0 && (reinterpret_cast<uintptr_t>(wb) & 7) == 0;
+  const long long n4 = vec ? n / 4 : 0;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n4; i += (long long)gridDim.x * kT) {
+    float4 wv = reinterpret_cast<const float4*>(w)[i];
+    float4 ev = ema ? reinterpret_cast<const float4*>(ema)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), mv = gv, ov = gv;
+    if (trainable) { gv = reinterpret_cast<const float4*>(g)[i]; mv = reinterpret_cast<const float4*>(ms)[i]; if (mom) ov = reinterpret_cast<const float4*>(mom)[i]; }
+    wv.x = one(wv.x, gv.x, mv.x, ov.x, ev.x); wv.y = one(wv.y, gv.y, mv.y, ov.y, ev.y);
+    wv.z = one(wv.z, gv.z, mv.z, ov.z, ev.z); wv.w = one(wv.w, gv.w, mv.w, ov.w, ev.w);
+    if (ema) reinterpret_cast<float4*>(ema)[i] = ev;
+    if (trainable) { reinterpret_cast<float4*>(ms)[i] = mv; if (mom) reinterpret_cast<float4*>(mom)[i] = ov; reinterpret_cast<float4*>(w)[i] = wv; }
+    if (wb) reinterpret_cast<uint2*>(wb)[i] = make_uint2(pack2bf(wv.x, wv.y), pack2bf(wv.z, wv.w));
+  }
+  for (long long i = 4 * n4 + (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    float msi = trainable ? ms[i] : 0.f, momi = (trainable && mom) ? mom[i] : 0.f, emai = ema ? ema[i] : 0.f;
+    const float wi = one(w[i], trainable ? g[i] : 0.f, msi, momi, emai);
+    if (ema) ema[i] = emai;
+    if (trainable) { ms[i] = msi; if (mom) mom[i] = momi; w[i] = wi; }
     if (wb) wb[i] = (unsigned short)f2bf(wi);
   }
   if (reg_loss && wd != 0.f) {

@@ -241,15 +241,11 @@ class Trainer:
         self.fold_skipped(stop_requested=bool(stop), barrier_timeouts=t)
         if stop:
             return {"stop": True, "fallback": False}
-        if m:
-            raise RuntimeError("bipartite matching failed on %d rank(s) (non-finite predictions or n_gt > P)" % m)
-        if w:
-            for g in self.wgrad_groups:
-                g.reset()
-            raise RuntimeError("grouped weight gradient: %d launch group(s) did not process all their work items "
-                               "(queue heads re-uploaded)" % w)
         out = {"stop": bool(stop), "fallback": False}
         if t:
+            # (FIRST: a timed-out barrier of a fused convolution + BN-apply launch poisons the ACTIVATIONS, so the same step's
+            # matching saw non-finite predictions -- a consequence of the time-out, not an error of its own; the step was not
+            # applied either way)
             self._timeouts_seen = net.barrier_timeouts()
             if net.no_onepass:
                 raise RuntimeError("batch-norm backward: %d grid-barrier timeout(s) AFTER the fall-back to the three-launch form" % t)
@@ -261,6 +257,14 @@ class Trainer:
                   "the affected steps were NOT applied; continuing with the three-launch BN backward" % (self.global_step, t),
                   file=sys.stderr)
             out["fallback"] = True
+            return out
+        if m:
+            raise RuntimeError("bipartite matching failed on %d rank(s) (non-finite predictions or n_gt > P)" % m)
+        if w:
+            for g in self.wgrad_groups:
+                g.reset()
+            raise RuntimeError("grouped weight gradient: %d launch group(s) did not process all their work items "
+                               "(queue heads re-uploaded)" % w)
         return out
 
     # ------------------------------------------------------------------ segments / buckets

@@ -179,12 +179,19 @@ print("SECOND_CHECK", h["fallback"], tr.global_step)
 """
 
 
-def test_barrier_timeout_falls_back_in_process(torch_cuda):
+@pytest.mark.parametrize("fault,extra", [("1", {"MBX_AUTOTUNE": "0"}),
+                                         ("2", {"MBX_FUSE_APPLY": "1", "MBX_RESIDENT_MIN_IMAGES": "1"}),
+                                         ("3", {"MBX_FUSE_BWD": "1", "MBX_RESIDENT_MIN_IMAGES": "1"})],
+                         ids=["bn_backward_launch", "fused_conv_bn_apply", "fused_dgrad_bn_backward"])
+def test_barrier_timeout_falls_back_in_process(torch_cuda, fault, extra):
     """MBX_DEBUG_BARRIER_FAULT=1 makes workgroup 0 of every one-launch BN backward skip its arrival: all others time
     out (bounded spin), set the flag, poison their outputs AND raise the step control word, so the optimiser does not
     apply the step (parameters and EMA shadows untouched).  The host check then switches the trainer to the three-launch
-    BN backward in the same process and the next step trains normally."""
-    env = dict(os.environ, MBX_DEBUG_BARRIER_FAULT="1", MBX_AUTOTUNE="0")
+    BN backward in the same process and the next step trains normally.
+    (round 6) = 2 / 3: the same fault in the grid barriers of the FUSED launches -- convolution + BN apply (the forward pass:
+    NaN activations, so the matching of that step fails too, which the health check attributes to the time-out) and data gradient
+    + BN backward (the resident-image launches of block17 at this batch size) -- same verdict, same fall-back to the split launches."""
+    env = dict(os.environ, MBX_DEBUG_BARRIER_FAULT=fault, **extra)
     r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out = r.stdout

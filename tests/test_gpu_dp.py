@@ -26,10 +26,21 @@ def _build(torch, seed, pg=None, use_graph=True):
     # (the same holds for the measured tile choice: another tile height regroups the BN partial sums)
     # MBX_DETERMINISTIC=1 also forbids pixel splits in the grouped weight gradient (one adder per dw element): the
     # ranks cut the backward pass into 3 segments and the reference into 1, so the split plans would differ otherwise.
+    # (put back afterwards: this also runs in the pytest process itself -- left set, every later test module ran
+    # deterministic and un-tuned without saying so, which is how the fused-launch tests of round 6 found it)
+    old = {k_: os.environ.get(k_) for k_ in ("MBX_DETERMINISTIC", "MBX_AUTOTUNE")}
     os.environ["MBX_DETERMINISTIC"] = "1"
     os.environ["MBX_AUTOTUNE"] = "0"
-    net = Net(batch=4, input_size=299, k=5, mode="train", seed=seed)
-    return net, Trainer(net, pri, max_num_bboxes=13, use_graph=use_graph, process_group=pg)
+    try:
+        net = Net(batch=4, input_size=299, k=5, mode="train", seed=seed)
+        tr = Trainer(net, pri, max_num_bboxes=13, use_graph=use_graph, process_group=pg)
+    finally:
+        for k_, v_ in old.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+    return net, tr
 
 
 def _batch(torch, rank, B=4):

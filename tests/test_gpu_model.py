@@ -648,10 +648,14 @@ def test_full_depth_backward_teacher_forced(B):
     teacher-forced bf16-emulating oracle on the same weights, batch and matching: cosine >= 0.9995 and relative L2 error
     <= 3e-2; whole gradient cosine >= 0.9998, relative L2 <= 2e-2.  Two documented exceptions: the betas of Conv2d_2b_3x3
     and Conv2d_4a_3x3, the layers in front of a 3x3/2 max pool -- their da is sparse (16 % non-zero, routed by the pool)
-    and d(beta) = sum(da * mask) cancels heavily, so a 1.4 % random error of da (measured, tools/stem_grad_probe.py: da
-    itself agrees to cosine 0.9999, and sum(engine da * mask) reproduces the engine's d(beta)) becomes 3-18 % of the
-    small sum: cosine >= 0.98, relative L2 <= 0.25 there.  Measured at batch 8: median cosine 0.99993, 5th percentile
-    0.99983, whole gradient 0.999887 / 1.5 %."""
+    and d(beta) = sum(da * mask) over N x H x W pixels cancels heavily, so the 1.4 % element-wise error the engine's bf16
+    gradients carry at the bottom of the network (measured, tools/stem_grad_probe.py: da itself agrees with the oracle's
+    float32 gradient to cosine 0.9999, and sum(engine da * mask) reproduces the engine's d(beta)) is a RANDOM error of
+    0.014 sqrt(sum g^2) on a sum that may be far smaller: 3-18 % of it at batch 8, 60 % on some channels at batch 64.
+    For these two the bound is the noise model itself, per channel: |d(beta) - oracle| <= 6 x 0.014 x sqrt(sum g^2), g the
+    oracle's own masked activation gradient (a wrong mask or a lost term would miss it by orders of magnitude: sum |g| is
+    ~400 sqrt(sum g^2) there).  Measured at batch 8: median cosine 0.99993, 5th percentile 0.99983, whole gradient
+    0.999887 / 1.5 %."""
     import os
     import torch
     import __graft_entry__ as g
@@ -698,10 +702,20 @@ def test_full_depth_backward_teacher_forced(B):
     assert int(ml.status.max()) == 0 and net.barrier_timeouts() == 0
     match = ml.match.cpu().numpy()
     # ---- the oracle, continuing from the engine's activations at every layer boundary, same matching; segment by segment
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    # host threads for the oracle: the cores this process may really use (affinity mask AND cgroup CPU quota -- the affinity mask
+    # alone lists every core of the host on the GPU box: a hundred threads on a 16-core share crawl)
+    ncore = len(os.sched_getaffinity(0))
+    try:
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q_ != "max":
+            ncore = max(1, min(ncore, int(float(q_) / float(p_))))
+    except Exception:
+        pass
+    torch.set_num_threads(ncore)
     P = {k_: v.clone().requires_grad_(True) for k_, v in P0.items()}
     force = _LazyActivations(net)
     m = Model(P, k=5, bn_training=True, q=q_bf16, force=force)
+    pool_fed = ("InceptionResnetV2/Conv2d_2b_3x3/BatchNorm/beta", "InceptionResnetV2/Conv2d_4a_3x3/BatchNorm/beta")
     segs = m.segments()
     # value of every segment's INPUT: the images, the stem's pooled output, then the forced tensor at each boundary
     # (Mixed_5b / 6a / 7a outputs are concatenations of forced branch outputs and an exact max-pool of a forced tensor:
@@ -732,10 +746,17 @@ def test_full_depth_backward_teacher_forced(B):
         else:
             xin = bounds[i].requires_grad_(True)
         bounds[i] = None
+        m.keep_acts = i == 0                   # (the stem: the two pool-fed layers' activations and their gradients, for the noise bound)
         out = segs[i][1](xin)
         out.backward(gup)
         gup = None if i == 0 else xin.grad
         del out, xin
+    noise = {}
+    for n in pool_fed:
+        act = m.acts[n[:-len("/BatchNorm/beta")]]
+        gmask = act.grad * (act.detach() > 0)
+        noise[n] = torch.sqrt((gmask.double() ** 2).sum((0, 2, 3))).float()
+    m.acts.clear()
     names = [n for n in net.param_index if n.endswith(("/weights", "/biases", "/beta"))]
     gq = {n: P[n].grad for n in names}
     assert all(gq[n] is not None for n in names)
@@ -744,12 +765,13 @@ def test_full_depth_backward_teacher_forced(B):
     med = np.median([float(gq[n].norm()) for n in names])
     big = [n for n in names if float(gq[n].norm()) > 1e-3 * med]
     assert len(big) > 0.95 * len(names), (len(big), len(names))
-    pool_fed = ("InceptionResnetV2/Conv2d_2b_3x3/BatchNorm/beta", "InceptionResnetV2/Conv2d_4a_3x3/BatchNorm/beta")
     worst = min((_cos(ge[n], gq[n]), n) for n in big if n not in pool_fed)
     for n in big:
         c, e = _cos(ge[n], gq[n]), rel_l2(ge[n], gq[n])
         if n in pool_fed:
-            assert c >= 0.98 and e <= 0.25, (n, c, e)
+            err = (ge[n] - gq[n]).abs()
+            bound = 6 * 0.014 * noise[n] + 1e-4 * float(gq[n].abs().max())
+            assert bool((err <= bound).all()), (n, c, e, float((err / bound).max()))
         else:
             assert c >= 0.9995 and e <= 3e-2, (n, c, e, worst)
     whole_e = torch.cat([ge[n].reshape(-1) for n in names])
