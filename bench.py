@@ -357,7 +357,7 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
             "traced_complete": bool(traced_ok), "incomplete_trace": (None if traced_ok else incomplete), "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
             "ms_per_step": round(d["ms"], 3),
             "timing": ("kernel begin/end timestamps of 3 real (graph-replayed) steps, recorded live by the ROCm tracer via "
-                       "torch.profiler: the timestamps of a rocprofv3 kernel trace (profiles/r05_bench_b64_kernel_stats.csv)"
+                       "torch.profiler: the timestamps of a rocprofv3 kernel trace (profiles/r06_bench_b64_kernel_stats.csv)"
                        if traced is not None else
                        "HIP events around every launch of one eager pass minus one measured marker cost per interval "
                        "(tracer unavailable or its trace incomplete: traced_complete)"),

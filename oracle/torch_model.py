@@ -55,6 +55,7 @@ class Model:
         100-layer network (the bf16-emulating and the float32 oracle agree only to cosine ~0.5 there)."""
         self.force = force
         self.keep_acts, self.acts = False, {}          # debugging: keep every BN convolution's output (and its gradient)
+        self.conv_io = {}                              # ... and (input, pre-BN output with .grad) of every convolution
         self.P, self.k, self.q = params, k, (q or (lambda t: t))
         self.repeats = repeats              # model.py:142,162,187 use (10, 20, 9); smaller = reduced-depth test net
         self.bn_training = bn_training
@@ -79,6 +80,10 @@ class Model:
             pl, pr = _same(x.shape[3], kw, stride)
             x = F.pad(x, (pl, pr, pt, pb))
         y = F.conv2d(x, w.permute(0, 3, 1, 2), stride=stride)
+        if self.keep_acts and y.requires_grad:
+            # debugging: the convolution's own input and output (+ its gradient dy), for the noise bounds of cancelling sums
+            y.retain_grad()
+            self.conv_io[scope] = (x.detach(), y)
         if bias:
             y = y + self.P[scope + "/biases"].view(1, -1, 1, 1)
         if bn:
