@@ -328,14 +328,20 @@ class Trainer:
     # ---------------------------------------------------------------------------- step
     def _front(self):
         net = self.net
-        # the step's clearing launch FIRST (round 6): the fused convolution + BN-apply launches of the forward pass may raise the
-        # step control word (grid-barrier time-out), which this launch clears -- the step then is skipped like one whose backward
-        # barrier timed out.  (Beside the forward pass on a stream of its own it measured 0.4 ms SLOWER: a fork / join in the
-        # captured graph costs more than the 39 us it hides -- LAB_NOTES round 5; removed.)
-        net.zero_grads()
+        # The step's clearing launch (gradient buffer, BN-backward accumulators, control block: 0.23 GB) touches nothing the forward
+        # pass or the loss reads or writes.  With the fused convolution + BN-apply launches (MBX_FUSE_APPLY=1) it comes FIRST: their
+        # grid barriers may raise the step control word in the forward pass, which this launch clears -- the step is then skipped
+        # like one whose backward barrier timed out.  Otherwise behind the loss, where it measured 38 us against 56 us at the top
+        # of the step (behind the optimiser's 1.8 GB of writes).  (Beside the forward pass on a stream of its own: 0.4 ms SLOWER,
+        # a fork / join in the captured graph costs more than it hides -- LAB_NOTES round 5; removed.)
+        first = net.fuse_apply
+        if first:
+            net.zero_grads()
         net.set_input(self.images)
         net.forward()
         self.loss.forward_backward(net.locs, net.logits, self.gt, self.n_gt)
+        if not first:
+            net.zero_grads()
 
     def _capture(self):
         """Warm up eagerly once (lazy module loads, hipFuncSetAttribute), then capture.  The warm-up pass is not a training
