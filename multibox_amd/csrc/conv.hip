@@ -1151,6 +1151,7 @@ int pick_cfg(long M, int C_out) {
 
 
 constexpr int kNumCfgs = 14;
+static_assert(kGbCtlWords * 4 == MBX_GRID_BARRIER_BYTES && kFbSlots == MBX_BN_BWD_SLOTS, "include/mbx.h and csrc/grid_barrier.h agree");
 constexpr int kI5Flag = 32;      // mbx_conv_desc.tile_config = 32 + t: igemm5 tile t (conv5.hip), persistent launch
 constexpr int kI7Cfg = 65;       // mbx_conv_desc.tile_config = 65: igemm7 (conv7.hip), persistent pointwise launch with the filter panel in LDS
 constexpr int kDirectCfg = 96;   // mbx_conv_desc.tile_config = 96: the direct 3x3 launch (convd.hip)

@@ -161,9 +161,17 @@ def test_ctypes_structs_match_the_header(tmp_path):
     hdr = {"shift": "shift", "stats_partial": "stats_partial"}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mbx.h"', 'int main(void) {',
            '  printf("sizeof_desc %zu\\n", sizeof(mbx_conv_desc));', '  printf("sizeof_job %zu\\n", sizeof(mbx_wgrad_job));',
-           '  printf("sizeof_bw %zu\\n", sizeof(mbx_bn_bwd_stats));']
+           '  printf("sizeof_bw %zu\\n", sizeof(mbx_bn_bwd_stats));',
+           '  printf("sizeof_ba %zu\\n", sizeof(mbx_bn_apply_desc));', '  printf("sizeof_fb %zu\\n", sizeof(mbx_bn_bwd_fused));',
+           '  printf("barrier_bytes %d\\n", MBX_GRID_BARRIER_BYTES);', '  printf("bwd_slots %d\\n", MBX_BN_BWD_SLOTS);']
     for f in fields:
         src.append('  printf("%s %%zu\\n", offsetof(mbx_conv_desc, %s));' % (f, hdr.get(f, f)))
+    # (round 6) the tables of the fused launches: every field of both
+    ba_names = {"moving_mean": "moving_mean", "moving_var": "moving_var"}
+    for f, _ in ops.BnApplyDesc._fields_:
+        src.append('  printf("ba.%s %%zu\\n", offsetof(mbx_bn_apply_desc, %s));' % (f, ba_names.get(f, f)))
+    for f, _ in ops.BnBwdFused._fields_:
+        src.append('  printf("fb.%s %%zu\\n", offsetof(mbx_bn_bwd_fused, %s));' % (f, f))
     src += ['  return 0;', '}']
     c = tmp_path / "layout.c"
     c.write_text("\n".join(src))
@@ -173,8 +181,14 @@ def test_ctypes_structs_match_the_header(tmp_path):
     assert int(out["sizeof_desc"]) == C.sizeof(ops.ConvDesc)
     assert int(out["sizeof_job"]) == C.sizeof(ops.WgradJob)
     assert int(out["sizeof_bw"]) == C.sizeof(_lib.BnBwdStats)
+    assert int(out["sizeof_ba"]) == C.sizeof(ops.BnApplyDesc) and int(out["sizeof_fb"]) == C.sizeof(ops.BnBwdFused)
+    assert int(out["barrier_bytes"]) == ops.GRID_BARRIER_BYTES and int(out["bwd_slots"]) == ops.BN_BWD_SLOTS
     for f in fields:
         assert int(out[f]) == getattr(ops.ConvDesc, f).offset, f
+    for f, _ in ops.BnApplyDesc._fields_:
+        assert int(out["ba." + f]) == getattr(ops.BnApplyDesc, f).offset, f
+    for f, _ in ops.BnBwdFused._fields_:
+        assert int(out["fb." + f]) == getattr(ops.BnBwdFused, f).offset, f
 
 
 def test_no_kernel_uses_scratch_memory(tmp_path):
