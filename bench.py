@@ -231,7 +231,7 @@ def timed_eager_pass(run, entry_points=None):
 # (the pair launch runs two igemm3 problems in one grid; the split-K reduce launch is the epilogue of its igemm3 slices)
 # (... and conv_direct3_kernel is the same convolution -- forward + data gradient of the stem's 3x3 layers -- as a direct launch)
 KERNEL_CLASSES = (("igemm", ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel",
-                             "conv_direct3_kernel", "conv_directw_kernel", "conv_resident_kernel", "conv_stem_kernel", "splitk_reduce_kernel")), ("wgrad", ("conv_wgrad",)),
+                             "conv_direct3_kernel", "conv_directw_kernel", "conv_resident_kernel", "conv_pwres_kernel", "conv_stem_kernel", "splitk_reduce_kernel")), ("wgrad", ("conv_wgrad",)),
                   ("bn_fwd", ("bn_finalize_kernel", "bn_finalize_parts_kernel", "bn_apply_kernel", "bn_apply_fused_kernel",
                               "bn_apply_rows_kernel", "bn_apply_maxpool3s2_kernel")), ("bn_bwd", ("bn_bwd_",)))
 
@@ -298,7 +298,7 @@ def committed_traffic(pattern="r*_hbm_traffic_pmc.json"):
             if any(j.get(k) != v for k, v in shas.items()):
                 continue
             n = mb = 0.0
-            for kern in ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel", "conv_direct3_kernel", "conv_directw_kernel", "conv_resident_kernel", "conv_stem_kernel"):
+            for kern in ("conv_igemm3_kernel", "conv_igemm3_pair_kernel", "conv_igemm5_kernel", "conv_igemm7_kernel", "conv_direct3_kernel", "conv_directw_kernel", "conv_resident_kernel", "conv_pwres_kernel", "conv_stem_kernel"):
                 if kern in j:
                     n += j[kern]["calls"]
                     mb += j[kern]["calls"] * j[kern]["MB_per_launch"]
@@ -350,7 +350,7 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
-    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_stem_kernel (convolution on MFMA: forward + data-gradient launches)",
+    main = {"bound": "mfma", "kernel": "conv_igemm3_kernel (+ pair, split-K slices and their reduce) + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_pwres_kernel + conv_stem_kernel (convolution on MFMA: forward + data-gradient launches)",
             "achieved": round(ach, 2) if traced_ok else None, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if traced_ok else None, "traffic": traffic, "traffic_source": src,
             "launches_per_step": d["calls"], "traced_launches_per_step": (round(tl, 2) if tl is not None else None),
@@ -433,7 +433,7 @@ def detect_leg(args, world, rank, pg):
             classes, pair_ms, _ = timed_eager_pass(one, ["mbx_conv"])
             d = classes["igemm"]
             ach = d["work"] / (d["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_stem_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm3_kernel + conv_igemm5_kernel + conv_igemm7_kernel + conv_direct3_kernel + conv_directw_kernel + conv_resident_kernel + conv_pwres_kernel + conv_stem_kernel (forward, folded-BN epilogue)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                                "traffic": None, "launches_per_batch": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2)}
             # HBM bytes per launch from the committed PMC passes of the detect forward (tools/collect_profiles.sh part d), if taken on these sources

@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import re
 
 import numpy as np
 import torch
@@ -776,6 +777,7 @@ class Net:
                 units.append(mem)
         unit_of = {id(m): u for u in units for m in u}
         pairs_ok = os.environ.get("MBX_FUSE_BWD_PAIRS", "1") != "0"
+        only = re.compile(os.environ["MBX_FUSE_BWD_ONLY"]) if os.environ.get("MBX_FUSE_BWD_ONLY") else None   # consumers by name (A/B)
 
         def member_at(buf, c):
             for u in units:
@@ -810,7 +812,7 @@ class Net:
             for X in self.fwd:
                 if not isinstance(X, ConvOp) or not X.need_dx or not X.trainable or X.stride != 1:
                     continue
-                if X.x.img_stride != X.x.H * X.x.W * X.x.ld or X.Cin % 8:
+                if X.x.img_stride != X.x.H * X.x.W * X.x.ld or X.Cin % 8 or (only is not None and not only.search(X.name)):
                     continue
                 if not pairs_ok and X.kind == "bn" and X.group is not None and len(X.group.members) == 2:
                     continue
@@ -1052,7 +1054,8 @@ class Net:
                     fpool.fused_fwd = True
                 # the layer's BN apply as the tail of the convolution launch (mbx_conv_desc.bn_apply), where the library has it
                 fd = ba = None
-                if use16 and self.fuse_apply and not S_ and torch.device(self.dev).type == "cuda" and out.img_stride == out.H * out.W * out.ld:
+                if use16 and self.fuse_apply and not S_ and torch.device(self.dev).type == "cuda" and out.img_stride == out.H * out.W * out.ld \
+                        and (not os.environ.get("MBX_FUSE_APPLY_ONLY") or re.search(os.environ["MBX_FUSE_APPLY_ONLY"], op.name)):
                     ba = ops.BnApplyDesc()
                     ba.barrier = self._fwd_barrier_base + ops.GRID_BARRIER_BYTES * self._fwd_barriers_used
                     ba.a, ba.ld_a, ba.beta, ba.mean, ba.rstd = out.ptr, out.ld, beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()

@@ -288,7 +288,7 @@ def resident_applies(desc: ConvDesc, min_images=32):
     return ok
 
 
-PWRES_DEFAULT = "0"                            # (off until it beats the persistent tiles in the step: LAB_NOTES round 5)
+PWRES_DEFAULT = "2"                            # data gradients only: -0.035 ms per step (LAB_NOTES round 6); "1" adds the residual forwards (level or slower)
 PWRES_TILE_CONFIG = 99                         # the pixel-resident pointwise launch for the epilogue-bound 1x1 layers (csrc/convr.hip, conv_pwres_kernel)
 
 
@@ -296,8 +296,9 @@ def pwres_applies(desc: ConvDesc, min_pixels=4096):
     """The pixel-resident pointwise launch by rule: a 1x1 / stride-1 convolution with C_in 96 / 128 / 320 / 384 / 448 whose epilogue
     streams trunk tensors -- the residual "up" convolutions of block35 / block17 / block8 (model.py:19-23, 39-43, 59-63) and the
     accumulate (+ relu mask) data gradients of their fused first 1x1s -- with at least 256 output channels.  MBX_PWRES=0 turns it
-    off (A/B).  The library has the last word (mbx_conv_supported)."""
-    if os.environ.get("MBX_PWRES", PWRES_DEFAULT) == "0":
+    off (A/B), MBX_PWRES=2 keeps it for the data gradients only.  The library has the last word (mbx_conv_supported)."""
+    mode = os.environ.get("MBX_PWRES", PWRES_DEFAULT)
+    if mode == "0":
         return False
     if desc.R != 1 or desc.S != 1 or desc.stride != 1 or desc.pad_t or desc.pad_l or desc.stats_partial or desc.bn_bwd_stats:
         return False
@@ -305,7 +306,7 @@ def pwres_applies(desc: ConvDesc, min_pixels=4096):
         return False
     res = desc.epilogue == EPI_RESIDUAL
     accm = desc.epilogue == EPI_STORE and desc.relu_bits and not desc.skip
-    if not (res or accm):
+    if not (res or accm) or (mode == "2" and not accm):
         return False
     return desc.N * desc.H_out * desc.W_out >= int(os.environ.get("MBX_PWRES_MIN_PIXELS", min_pixels))
 

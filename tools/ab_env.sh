@@ -1,12 +1,14 @@
-# A/B of environment knobs on ONE box: tools/ab_env.sh "<VAR=val ...>" "<...>" ...   ("-" = defaults); two repetitions each
+#!/bin/bash
+# A/B of environment settings on one box: tools/ab_env.sh <reps> "<VAR=.. VAR=..>" "<VAR=..>" ...   (bench.py train leg only, 30
+# steps; the settings alternate, "-" is the shipped default)
 cd "$(dirname "$0")/.."
-B="--steps 30 --warmup 5 --no-cpu-baseline --no-detect --no-roofline --no-configs"
-for rep in 1 2; do
-for envs in "$@"; do
-  e="$envs"; [ "$e" = "-" ] && e=""
-  env $e python bench.py $B 2>/dev/null | python -c "
+reps="$1"; shift
+for rep in $(seq 1 "$reps"); do
+  for setting in "$@"; do
+    s="$setting"; [ "$s" = "-" ] && s=""
+    env $s python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-detect --no-roofline --no-configs 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('[%s] rep $rep: %.3f ms/step %.1f img/s' % ('$envs', j['ms_per_step'], j['value']))"
-done
+print('%-28s %.3f ms/step %.1f img/s  kernels %s' % ('$setting', j['ms_per_step'], j['value'], j.get('kernels_per_step')))"
+  done
 done

@@ -14,7 +14,7 @@ names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "pack_input" in n]
 step = rows[starts[-1]:]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-ig = [r for r in step if any(k in r["Kernel_Name"] for k in ("conv_igemm3", "conv_igemm5", "conv_igemm7", "conv_direct3", "conv_directw", "conv_resident", "conv_stem"))]      # igemm5: the persistent launches
+ig = [r for r in step if any(k in r["Kernel_Name"] for k in ("conv_igemm3", "conv_igemm5", "conv_igemm7", "conv_direct3", "conv_directw", "conv_resident", "conv_pwres", "conv_stem"))]      # igemm5: the persistent launches
 wg = [r for r in step if "conv_wgrad2" in r["Kernel_Name"]]
 net = Net(batch=B, device="cpu")
 convs = [op for op in net.fwd if isinstance(op, ConvOp)]
@@ -22,7 +22,7 @@ bw = [op for op in reversed(net.fwd) if isinstance(op, ConvOp) and op.trainable]
 # Walk the igemm launches in order.  A batch-norm group of two may run as ONE pair launch (conv_igemm3_pair_kernel, issued at
 # the position of the group's last member, forward, and of its first member in backward order): its time is split between
 # the two convolutions by their FLOPs.
-kname = lambda r: ("pair:" if "pair_kernel" in r["Kernel_Name"] else "i5:" if "igemm5" in r["Kernel_Name"] else "i7:" if "igemm7" in r["Kernel_Name"] else "d3:" if "direct3" in r["Kernel_Name"] else "dw:" if "directw" in r["Kernel_Name"] else "res:" if "conv_resident" in r["Kernel_Name"] else "stem:" if "conv_stem" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1)
+kname = lambda r: ("pair:" if "pair_kernel" in r["Kernel_Name"] else "i5:" if "igemm5" in r["Kernel_Name"] else "i7:" if "igemm7" in r["Kernel_Name"] else "d3:" if "direct3" in r["Kernel_Name"] else "dw:" if "directw" in r["Kernel_Name"] else "res:" if "conv_resident" in r["Kernel_Name"] else "pw:" if "conv_pwres" in r["Kernel_Name"] else "stem:" if "conv_stem" in r["Kernel_Name"] else "") + re.search(r"<([^>]*)>", r["Kernel_Name"]).group(1)
 flops = lambda op: 2.0 * op.M * op.K * op.R * op.S * op.Cin
 rec = {}
 pos = 0
