@@ -258,9 +258,17 @@ def traced_kernel_times(step_fn, steps=3):
         out = {}
         seen = 0
         allk = [0.0, 0]
-        for e in prof.events():
-            if e.device_type != torch.autograd.DeviceType.CUDA:
-                continue
+        evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+        evs.sort(key=lambda e: e.time_range.start)
+        # The tracer can lose the first kernels after it starts: cut the trace into steps at pack_input_kernel (the first kernel of
+        # a step) and keep the steps that have every kernel (the longest ones); what precedes the first marker is a torn step.
+        marks = [i for i, e in enumerate(evs) if "pack_input" in e.name]
+        if marks:
+            segs = [evs[a:b] for a, b in zip(marks, marks[1:] + [len(evs)])]
+            full = max(len(sg) for sg in segs)
+            segs = [sg for sg in segs if len(sg) == full]
+            evs, steps = [e for sg in segs for e in sg], len(segs)
+        for e in evs:
             seen += 1
             us = float(getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0))
             if "Memcpy" not in e.name and "Memset" not in e.name:
@@ -275,7 +283,9 @@ def traced_kernel_times(step_fn, steps=3):
         if not seen or "igemm" not in out:
             return None
         out["_all_kernels"] = allk                       # every kernel of the traced steps (optimiser launches included)
-        return {c: (v[0] / steps * 1e-3, v[1] / float(steps)) for c, v in out.items()}
+        out = {c: (v[0] / steps * 1e-3, v[1] / float(steps)) for c, v in out.items()}
+        out["_steps"] = (float(steps), float(steps))      # complete steps the figures are averaged over
+        return out
     except Exception:
         return None
 
@@ -752,6 +762,7 @@ def main():
                 # every kernel of a replayed step + its eager optimiser launches, from the same trace
                 out["kernels_per_step"] = round(traced["_all_kernels"][1], 1)
                 out["kernel_time_ms_per_step"] = round(traced["_all_kernels"][0], 3)
+                out["roofline"]["traced_steps"] = int(traced.get("_steps", (3, 3))[0])    # complete steps of the live trace
         except Exception as e:      # evidence only; never fail the benchmark line on it
             out["roofline"] = {"error": repr(e)}
     if pg is not None:
