@@ -463,10 +463,12 @@ def test_conv_directw_bit_identical(T, g):
                                ("r7", 70, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)), ("r8", 5, 8, 8, 192, 224, 1, 3, 1, (0, 1, 0, 1)),
                                ("r9", 64, 8, 8, 224, 256, 3, 1, 1, (1, 0, 1, 0)), ("r10", 70, 8, 8, 192, 224, 1, 3, 1, (0, 1, 0, 1)),
                                ("r11", 150, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)), ("r12", 256, 17, 17, 160, 192, 7, 1, 1, (3, 0, 3, 0)),
-                               ("r13", 256, 8, 8, 224, 256, 3, 1, 1, (1, 0, 1, 0))],
+                               ("r13", 256, 8, 8, 224, 256, 3, 1, 1, (1, 0, 1, 0)), ("r14", 256, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3)),
+                               ("r15", 300, 17, 17, 128, 160, 1, 7, 1, (0, 3, 0, 3))],
                          ids=["1x7_128_160", "7x1_160_192", "1x7_12x15", "7x1_9x11", "1x7_b64", "7x1_b64", "7x1_b70_two_tiles_per_wg",
                               "block8_1x3_192_224", "block8_3x1_224_256_b64", "block8_1x3_b70_two_tiles_per_wg",
-                              "1x7_b150_three_tiles_across_images", "7x1_b256_image_per_wg", "block8_3x1_b256_image_per_wg"])
+                              "1x7_b150_three_tiles_across_images", "7x1_b256_image_per_wg", "block8_3x1_b256_image_per_wg",
+                              "1x7_b256_image_per_wg", "1x7_b300_ragged_tiles_per_wg"])
 def test_conv_resident_bit_identical(T, g):
     """tile_config 98 (round 5, csrc/convr.hip conv_resident_kernel): block17's 1x7 / 7x1 layers (model.py:33-37) with the whole
     input image of a tile resident in LDS and the filter streamed per tap -- against the implicit-GEMM launch of the same
