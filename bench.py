@@ -145,6 +145,7 @@ def _work_table():
     W["mbx_conv_pair"] = ("igemm", "mfma", lambda a: _conv_flops(a[0]._obj) + _conv_flops(a[1]._obj))      # two sibling convs, one launch
     W["mbx_conv_wgrad_scaled"] = ("wgrad", "mfma", lambda a: _conv_flops(a[0]._obj))
     W["mbx_conv_wgrad_grouped"] = ("wgrad", "mfma", lambda a: float(a[1]._obj.flops))  # mbx_wgrad_plan_info.flops
+    W["mbx_conv_wgrad_grouped_capped"] = W["mbx_conv_wgrad_grouped"]                    # (the entry point the engine calls)
     W["mbx_bn_apply_fused"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[6] * a[7])
     # finalize + apply in one launch from the few statistics rows the convolution ADDED (a[6], a[7] = M, C)
     W["mbx_bn_apply_fused_mapped"] = ("bn_fwd", "hbm", lambda a: 4.0 * a[6] * a[7])
@@ -322,6 +323,22 @@ def committed_traffic(pattern="r*_hbm_traffic_pmc.json"):
     return None, "no committed PMC profile matches the current csrc/conv*.hip + conv_common.h (%s)" % shas
 
 
+def committed_kernel_traffic(kernel, ms_per_launch, pattern="r*_hbm_traffic_pmc.json"):
+    """HBM bytes per launch of one kernel from the newest committed PMC profile that has it, and the rate at the given duration."""
+    import glob
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            j = json.load(open(pj))
+            if kernel in j and ms_per_launch > 0:
+                mb = float(j[kernel]["MB_per_launch"])
+                gbs = mb * 1e6 / (ms_per_launch * 1e-3) / 1e9
+                return {"traffic_MB_per_launch": round(mb, 1), "GB/s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                        "source": os.path.relpath(pj, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominant="igemm", traced=None):
     """(roofline of the dominant kernel, list of per-class rooflines).  Work (FLOPs / bytes) and launch counts come
     from timed_eager_pass(); times from traced_kernel_times() when the tracer is available (then `ms` is the tracer's and
@@ -357,6 +374,10 @@ def roofline_objects(classes, pair_ms, plain_ms, whole_step_tflops=None, dominan
         kernels.append({"kernel": cls, "bound": o["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
                         "frac": round(ach / peak, 4), "launches": o["calls"], "ms_per_step": round(o["ms"], 3),
                         "avg_launch_us": round(1e3 * o["ms"] / o["calls"], 2), "ms_per_step_hip_events": round(o["event_ms"], 3)})
+        if cls == "wgrad":
+            # the grouped weight gradient reads every convolution input and every output gradient of the step once: beside its
+            # MFMA fraction, the HBM rate of the launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE per launch)
+            kernels[-1]["hbm"] = committed_kernel_traffic("conv_wgrad_grouped_kernel", o["ms"] / o["calls"])
     d = classes[dominant]
     ach = d["work"] / (d["ms"] * 1e-3) / 1e12
     traffic, src = committed_traffic()
